@@ -1,0 +1,109 @@
+/*
+ * include/twl_align.h -- C ABI of libtwl_align: the MI355X (gfx950) level-batch aligner.
+ *
+ * TWILIGHT has no FFI: its boundary is the C++ std::function
+ *     msa::alnFunction  = void(Tree*, NodePairVec&, SequenceDB*, Option*, Params&)   (reference src/msa.hpp:175)
+ * whose CPU implementation cpu::parallelAlignmentCPU (src/alignment-cpu.cpp:36-183) calls, per pair,
+ *     Talco_xdrop::Align_freq(Params*, freqRef, freqQry, gapOp, gapEx, num, aln, errorType)   (src/TALCO-XDrop.hpp:56-65).
+ * This header is the flat, batched equivalent of that inner call for all pairs of one guide-tree
+ * level; its array shapes are the ones the reference's own GPU host code already flattens to
+ * (src/hip/alignment-gpu.hip.cpp:270-293: freq[pairs][2][seqLen][P], gapOpen/gapExtend[pairs][2][seqLen],
+ * len[2*pairs], num[2*pairs]; out aln[pairs][2*seqLen], alnLen[pairs]).  The host-side mirror of
+ * alignmentKernel_GPU that calls it lives in twilight_amd/csrc/host/ (see INTEGRATION.md).
+ *
+ * Plain C types only.  All functions return 0 on success or a negative twl_status; algorithmic
+ * failures of a pair are NOT errors: they travel in err_out[] as the reference's errorType so the
+ * caller can apply the reference's retry/defer policy unchanged (alignment-cpu.cpp:108-129).
+ */
+#ifndef TWL_ALIGN_H
+#define TWL_ALIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWL_MAX_MATRIX 21          /* matrixSize: 5 nucleotide, 21 protein (msa.hpp:98-109) */
+#define TWL_MAX_MARKER 1024        /* Talco_xdrop::Params::marker default, TALCO-XDrop.cpp:51 */
+
+enum twl_status {
+    TWL_OK = 0,
+    TWL_ERR_NOT_INITIALIZED = -1,
+    TWL_ERR_BAD_ARGUMENT = -2,
+    TWL_ERR_HIP = -3,              /* a HIP runtime call failed; see twl_last_error() */
+    TWL_ERR_UNSUPPORTED = -4       /* parameter outside what the kernels implement */
+};
+
+/* Replaces Talco_xdrop::Params (TALCO-XDrop.hpp:37-54, ctor TALCO-XDrop.cpp:36-53). */
+typedef struct twl_params {
+    int32_t P;                                       /* profile width = matrixSize+1: 6 or 22 */
+    float   matrix[TWL_MAX_MATRIX * TWL_MAX_MATRIX]; /* scoreMatrix[l][m] row-major, (P-1)x(P-1) used */
+    float   gap_open;                                /* gapOpen */
+    float   gap_extend;                              /* gapExtend */
+    float   gap_boundary;                            /* gapBoundary (unused by Align_freq when alnType==0; kept for layout parity) */
+    float   gap_char;                                /* gapCharScore: gapExtend, or 0 per alignment-cpu.cpp:88 */
+    int32_t xdrop;                                   /* 1000*-gapExtend by default (TALCO-XDrop.cpp:49) */
+    int32_t flen;                                    /* max anti-diagonal width, default 4096 (:50) */
+    int32_t marker;                                  /* tile marker, default 1024 (:51); 2 <= marker <= TWL_MAX_MARKER */
+} twl_params;
+
+/* Counters of the most recent twl_align_batch* call on the calling device. */
+typedef struct twl_stats {
+    uint64_t band_cells;      /* executions of the i-loop body, TALCO-XDrop.cpp:353, summed over pairs/tiles/relaunches */
+    uint64_t nominal_cells;   /* sum of R*Q */
+    double   kernel_ms;       /* HIP-event time of the DP kernel launches only */
+    double   pack_ms;         /* HIP-event time of the column-packing kernel */
+    double   total_ms;        /* HIP-event time first enqueue -> last completion (incl. H2D/D2H for the host form) */
+    int32_t  n_launches;      /* DP kernel launches (1 + relaunches for pairs that overflowed the fast window) */
+    int32_t  n_relaunched;    /* pairs re-run with the wide-window kernel */
+    int32_t  window;          /* rows of the fast-path window used */
+    int32_t  grid;            /* persistent workgroups launched */
+} twl_stats;
+
+/* Select devices (HIP ordinals).  n_devices==0 or device_ids==NULL -> device 0 only.
+   With several devices the pairs of a batch are dealt to them in cost order (no collective). */
+int  twl_init(const int *device_ids, int n_devices);
+void twl_shutdown(void);
+const char *twl_last_error(void);
+const char *twl_version(void);
+
+/*
+ * Align every pair of one level batch.  Host pointers; the library stages through its own device
+ * buffers.  Replaces the per-pair Align_freq calls inside the tbb::parallel_for at
+ * alignment-cpu.cpp:46-134.
+ *
+ *   freq        [n_pairs][2][seq_len][P]  weighted letter counts, 0 = reference, 1 = query, zero padded
+ *   gap_open    [n_pairs][2][seq_len]     position-specific gap open   (calculatePSGP)
+ *   gap_extend  [n_pairs][2][seq_len]     position-specific gap extend
+ *   len         [n_pairs][2]              R, Q (after gappy-column removal)
+ *   num         [n_pairs][2]              member-sequence counts; denominator = float(R_num)*float(Q_num)
+ *   aln_out     [n_pairs][2*seq_len]      path codes 0 (both) / 1 (gap in ref, consumes query) / 2 (gap in query), forward order
+ *   aln_len_out [n_pairs]                 path length; 0 if an input side is empty (caller emits the all-gap path,
+ *                                         alignment-cpu.cpp:89-90) or if err_out != 0
+ *   err_out     [n_pairs]                 errorType 0 ok / 1 X-drop emptied the band / 2 band wider than flen / 3 inconsistency
+ */
+int twl_align_batch(const twl_params *p, int32_t n_pairs, int32_t seq_len,
+                    const float *freq, const float *gap_open, const float *gap_extend,
+                    const int32_t *len, const int32_t *num,
+                    int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out);
+
+/*
+ * Same, with every array already resident in device memory of `device` (HBM in, HBM out; no PCIe
+ * traffic).  `stream` is a hipStream_t (NULL = the library's stream for that device).  The call
+ * returns after the work completed.  This is the form bench.py times.
+ */
+int twl_align_batch_device(int device, void *stream, const twl_params *p, int32_t n_pairs, int32_t seq_len,
+                           const float *d_freq, const float *d_gap_open, const float *d_gap_extend,
+                           const int32_t *d_len, const int32_t *d_num,
+                           int8_t *d_aln_out, int32_t *d_aln_len_out, int16_t *d_err_out);
+
+int twl_get_stats(int device, twl_stats *out);
+
+/* Per-pair band-cell counts of the last call on `device` (n entries, host buffer). */
+int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

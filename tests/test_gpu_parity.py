@@ -1,0 +1,93 @@
+"""HIP path vs oracle through the C ABI: bit-exact paths, error codes and band-cell counts (-m gpu)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from twilight_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+M = synth.nucleotide_matrix()
+
+
+def _compare(twl, batch, **pk):
+    p = twl.make_params(M, **pk)
+    aln, n, err = twl.align_batch(p, batch)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), batch, threads=8)
+    assert np.array_equal(err, oerr), f"errorType differs: gpu {err.tolist()} oracle {oerr.tolist()}"
+    assert np.array_equal(n, on), f"path length differs: gpu {n.tolist()} oracle {on.tolist()}"
+    for i in range(batch.n_pairs):
+        if not np.array_equal(aln[i, : n[i]], oa[i, : on[i]]):
+            first = int(np.flatnonzero(aln[i, : n[i]] != oa[i, : on[i]])[0])
+            raise AssertionError(f"pair {i}: path differs first at step {first} of {n[i]}")
+    st = twl.get_stats(0)
+    cells_ok = ost.cells
+    if np.all(oerr == 0):
+        assert st.band_cells == cells_ok, f"band cells gpu {st.band_cells} oracle {cells_ok}"
+    return st, ost
+
+
+@pytest.mark.parametrize("members", [(1, 1), ((2, 6), (2, 6)), (1, (3, 9))])
+def test_small_pairs_default_params(gpu, members):
+    batch = synth.make_level_batch(12, 600, members=members, seed=11)
+    _compare(gpu, batch)
+
+
+def test_multi_tile_small_marker(gpu):
+    # marker 128 -> many tiles per pair, exercises convergence pointers, tile stitching, tb flush of partial groups
+    batch = synth.make_level_batch(10, 900, members=((1, 5), (1, 5)), seed=3)
+    st, ost = _compare(gpu, batch, marker=128)
+    assert ost.tiles > 3 * batch.n_pairs
+
+
+@pytest.mark.parametrize("marker", [16, 33, 250])
+def test_marker_sweep(gpu, marker):
+    batch = synth.make_level_batch(6, 500, members=((1, 3), (1, 3)), seed=5 + marker)
+    _compare(gpu, batch, marker=marker)
+
+
+def test_rnasim_shaped_1600(gpu):
+    batch = synth.make_level_batch(24, 1600, members=((1, 8), (1, 8)), seed=20260502)
+    st, ost = _compare(gpu, batch)
+    assert ost.max_width > 300
+
+
+def test_error_type_2_small_flen(gpu):
+    batch = synth.make_level_batch(8, 800, members=(1, 1), seed=9)
+    p = dict(flen=128)
+    st, ost = _compare(gpu, batch, **p)
+
+
+def test_error_type_1_tiny_xdrop(gpu):
+    # unrelated sequences with a tiny X-drop: the band dies
+    rng = np.random.default_rng(4)
+    batch = synth.make_level_batch(6, 400, members=(1, 1), seed=21, sub=0.75, indel=0.05)
+    _compare(gpu, batch, xdrop=40)
+
+
+def test_ragged_and_tiny(gpu):
+    b1 = synth.make_level_batch(5, 40, members=((1, 3), (1, 3)), seed=1, length_jitter=0.5)
+    _compare(gpu, b1)
+    b2 = synth.make_level_batch(4, 9, members=(1, 1), seed=2, indel=0.0)
+    _compare(gpu, b2)
+
+
+def test_empty_side_and_single_column(gpu):
+    batch = synth.make_level_batch(4, 50, members=(1, 1), seed=8)
+    batch.len[1, 0] = 0          # empty reference side -> aln_len 0, err 0 (caller emits the all-gap path)
+    batch.len[2, 1] = 1          # single query column
+    p = gpu.make_params(M)
+    aln, n, err = gpu.align_batch(p, batch)
+    oa, on, oerr, _ = O.align_batch(O.make_params(M), batch, threads=1)
+    assert n[1] == 0 and err[1] == 0
+    assert np.array_equal(n, on) and np.array_equal(err, oerr)
+    for i in range(batch.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[i, : on[i]])
+
+
+def test_length_mismatch_pairs(gpu):
+    # very different lengths: long end gaps, band hugging one edge, trailing runs at tile exit
+    rng = np.random.default_rng(12)
+    b = synth.make_level_batch(6, 700, members=(1, 1), seed=31)
+    b.len[:, 1] = (b.len[:, 1] * np.array([0.3, 0.5, 0.7, 0.9, 0.2, 1.0])).astype(np.int32).clip(1)
+    _compare(gpu, b, marker=64)

@@ -1,0 +1,139 @@
+"""ctypes binding of libtwl_align.so (C ABI: include/twl_align.h).  No fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtwl_align.so")
+TWL_MAX_MATRIX = 21
+
+_lib = None
+
+
+class TwlError(RuntimeError):
+    pass
+
+
+class TwlParams(C.Structure):
+    """twl_params -- replaces Talco_xdrop::Params (reference TALCO-XDrop.hpp:37-54)."""
+    _fields_ = [("P", C.c_int32), ("matrix", C.c_float * (TWL_MAX_MATRIX * TWL_MAX_MATRIX)), ("gap_open", C.c_float),
+                ("gap_extend", C.c_float), ("gap_boundary", C.c_float), ("gap_char", C.c_float), ("xdrop", C.c_int32),
+                ("flen", C.c_int32), ("marker", C.c_int32)]
+
+
+class TwlStats(C.Structure):
+    _fields_ = [("band_cells", C.c_uint64), ("nominal_cells", C.c_uint64), ("kernel_ms", C.c_double),
+                ("pack_ms", C.c_double), ("total_ms", C.c_double), ("n_launches", C.c_int32),
+                ("n_relaunched", C.c_int32), ("window", C.c_int32), ("grid", C.c_int32)]
+
+
+_SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
+            "twl_get_stats", "twl_get_pair_cells"]
+
+
+def exported_symbols():
+    return list(_SYMBOLS)
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TwlError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(LIB_PATH)
+        lib.twl_last_error.restype = C.c_char_p
+        lib.twl_version.restype = C.c_char_p
+        lib.twl_init.restype = C.c_int
+        lib.twl_align_batch.restype = C.c_int
+        lib.twl_align_batch_device.restype = C.c_int
+        lib.twl_get_stats.restype = C.c_int
+        lib.twl_get_pair_cells.restype = C.c_int
+        lib.twl_shutdown.restype = None
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise TwlError(f"libtwl_align error {rc}: {load_library().twl_last_error().decode()}")
+
+
+def make_params(matrix, *, gap_open=-50.0, gap_extend=-5.0, gap_boundary=None, gap_char=None, xdrop=None, flen=4096,
+                marker=1024) -> TwlParams:
+    """Defaults follow Talco_xdrop::Params(msa::Params&), reference TALCO-XDrop.cpp:36-53."""
+    m = np.asarray(matrix, dtype=np.float32)
+    n = m.shape[0]
+    p = TwlParams()
+    p.P = n + 1
+    flat = np.zeros(TWL_MAX_MATRIX * TWL_MAX_MATRIX, dtype=np.float32)
+    flat[: n * n] = m.reshape(-1)
+    p.matrix[:] = flat.tolist()
+    p.gap_open = gap_open
+    p.gap_extend = gap_extend
+    p.gap_boundary = gap_extend if gap_boundary is None else gap_boundary
+    p.gap_char = gap_extend if gap_char is None else gap_char
+    p.xdrop = int(1000 * -gap_extend) if xdrop is None else int(xdrop)
+    p.flen = flen
+    p.marker = marker
+    return p
+
+
+def init(device_ids=None):
+    lib = load_library()
+    if device_ids is None:
+        _check(lib.twl_init(None, 0))
+    else:
+        arr = (C.c_int * len(device_ids))(*device_ids)
+        _check(lib.twl_init(arr, len(device_ids)))
+
+
+def shutdown():
+    load_library().twl_shutdown()
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def align_batch(params: TwlParams, batch):
+    """Host-buffer form (twl_align_batch).  `batch` is a synth.LevelBatch-like object."""
+    lib = load_library()
+    n, sl = batch.n_pairs, batch.seq_len
+    freq = np.ascontiguousarray(batch.freq, dtype=np.float32)
+    go = np.ascontiguousarray(batch.gap_open, dtype=np.float32)
+    ge = np.ascontiguousarray(batch.gap_extend, dtype=np.float32)
+    ln = np.ascontiguousarray(batch.len, dtype=np.int32)
+    nm = np.ascontiguousarray(batch.num, dtype=np.int32)
+    aln = np.zeros((n, 2 * sl), dtype=np.int8)
+    aln_len = np.zeros(n, dtype=np.int32)
+    err = np.zeros(n, dtype=np.int16)
+    _check(lib.twl_align_batch(C.byref(params), C.c_int32(n), C.c_int32(sl), _ptr(freq, C.c_float), _ptr(go, C.c_float),
+                               _ptr(ge, C.c_float), _ptr(ln, C.c_int32), _ptr(nm, C.c_int32), _ptr(aln, C.c_int8),
+                               _ptr(aln_len, C.c_int32), _ptr(err, C.c_int16)))
+    return aln, aln_len, err
+
+
+def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex, d_len, d_num, d_aln, d_aln_len, d_err,
+                       device=0, stream=None):
+    """Device-pointer form (twl_align_batch_device).  Pointers are integers (e.g. torch.Tensor.data_ptr())."""
+    lib = load_library()
+    vp = C.c_void_p
+    _check(lib.twl_align_batch_device(C.c_int(device), vp(stream or 0), C.byref(params), C.c_int32(n_pairs), C.c_int32(seq_len),
+                                      vp(d_freq), vp(d_gop), vp(d_gex), vp(d_len), vp(d_num), vp(d_aln), vp(d_aln_len),
+                                      vp(d_err)))
+
+
+def get_stats(device=0) -> TwlStats:
+    st = TwlStats()
+    _check(load_library().twl_get_stats(C.c_int(device), C.byref(st)))
+    return st
+
+
+def get_pair_cells(n, device=0):
+    out = np.zeros(n, dtype=np.uint64)
+    _check(load_library().twl_get_pair_cells(C.c_int(device), _ptr(out, C.c_uint64), C.c_int32(n)))
+    return out

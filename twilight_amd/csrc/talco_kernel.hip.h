@@ -1,0 +1,521 @@
+// twilight_amd/csrc/talco_kernel.hip.h -- gfx950 device code of the tiled TALCO-XDrop level-batch aligner.
+//
+// What it computes is exactly Talco_xdrop::Align_freq / Tile / Traceback of the reference CPU path
+// (/root/reference/src/TALCO-XDrop.cpp:62-108, :233-689, :134-231) in fp32 with the x86 TALCO_SIMD
+// operation order; how it computes it is MI355X-specific and shares no structure with the
+// reference's own GPU kernels (src/hip/device-function.hip.cpp -- int16 scores, marker 200, a
+// different algorithm variant; not the oracle, not consulted for this design).
+//
+// Mapping:
+//   * one persistent workgroup of W waves aligns one pair at a time, pulled from a device queue;
+//   * lane <-> query row i ("systolic"): a 64-row block of the query profile lives in the lanes of a
+//     virtual wave for as long as the band [L,U] touches it; the products q[m]*M[l][m] (the first
+//     rounding of the reference's (q*M)*r) are computed once per row and kept in 25 VGPRs;
+//   * the reference column r[j], j = k - i, streams past the lanes: it is staged once per 64 columns
+//     into an LDS ring and read conflict-free (consecutive lanes -> consecutive 32-byte columns);
+//   * H/I of row i-1 arrive by one DPP wave_shr:1 per value (lane 0 patched from an LDS mailbox),
+//     H/D of row i stay in the lane's own registers: no DP row ever goes to LDS or HBM;
+//   * per anti-diagonal the workgroup reduces {running max, first/last unpruned row} with three LDS
+//     atomics and ONE barrier; convergence pointers (k > marker) add a second barrier;
+//   * traceback pointers (4 bit/cell, k <= marker) are packed 8 diagonals per dword per lane and
+//     written coalesced to an HBM scratch tile [k/8][row mod window]; the tile's path is walked by
+//     one lane and streamed reversed into the output.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace twl {
+
+constexpr int kIB = -2;   // I_BOUNDARY, TALCO-XDrop.cpp:33
+constexpr int kDB = -3;   // D_BOUNDARY, TALCO-XDrop.cpp:34
+constexpr int kMaxMarker = 1024;
+constexpr int kErrOverflow = -1;   // internal: band outgrew this kernel's row window -> relaunch wide
+
+struct KArgs {
+    const float *cols;        // packed columns [pair][2][seq_len][8]: f0..f5, gapOpen, gapExtend
+    const int32_t *len;       // [pair][2]
+    const int32_t *num;       // [pair][2]
+    int8_t *aln;              // [pair][2*seq_len]
+    int32_t *aln_len;         // [pair]
+    int16_t *err;             // [pair]
+    unsigned long long *cells;// [pair]
+    uint32_t *tb;             // [grid][tb_words]
+    int32_t *queue;           // [1] next work item
+    const int32_t *items;     // [n_items] pair ids in launch order (cost-sorted)
+    int32_t n_items;
+    int32_t seq_len;
+    int32_t tb_words;         // per workgroup
+    float gap_open, gap_extend, gap_char;
+    int32_t xdrop, flen, marker;
+    float M[25];              // scoreMatrix[l][m], 5x5
+};
+
+__device__ __forceinline__ float dpp_shr1_f(float from_prev_wave, float src)
+{
+    // lane t <- src[t-1]; lane 0 keeps `from_prev_wave` (DPP wave_shr:1, bound_ctrl=0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(from_prev_wave), __float_as_int(src), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int dpp_shr1_i(int from_prev_wave, int src)
+{
+    return __builtin_amdgcn_update_dpp(from_prev_wave, src, 0x138, 0xf, 0xf, false);
+}
+
+// max over the 64 lanes (all lanes must be active); result broadcast as a wave-uniform value.
+__device__ __forceinline__ float wave_max_f32(float x)
+{
+#define TWL_DPP_MAX(ctrl, rmask, bmask) \
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, bmask, false)))
+    TWL_DPP_MAX(0x111, 0xf, 0xf);   // row_shr:1
+    TWL_DPP_MAX(0x112, 0xf, 0xf);   // row_shr:2
+    TWL_DPP_MAX(0x114, 0xf, 0xf);   // row_shr:4
+    TWL_DPP_MAX(0x118, 0xf, 0xf);   // row_shr:8
+    TWL_DPP_MAX(0x142, 0xa, 0xf);   // row_bcast:15
+    TWL_DPP_MAX(0x143, 0xc, 0xf);   // row_bcast:31
+#undef TWL_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// order-preserving float <-> int key for LDS integer atomic max
+__device__ __forceinline__ int f2key(float f)
+{
+    int b = __float_as_int(f);
+    return b >= 0 ? b : (b ^ 0x7fffffff);
+}
+__device__ __forceinline__ float key2f(int k)
+{
+    return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff));
+}
+
+template <int W, int RPL, bool PRE, bool REFLDS>
+struct Cfg {
+    static constexpr int NV = W * RPL;          // virtual waves = 64-row blocks resident at once
+    static constexpr int WINDOW = 64 * NV;      // rows
+    static constexpr int NB = NV + 2;           // ring blocks
+    static constexpr int CAP = 64 * NB;         // ring columns
+    static constexpr int RING_F4 = REFLDS ? CAP * 2 : 2;
+    static constexpr int THREADS = 64 * W;
+};
+
+template <int W, int RPL, bool PRE, bool REFLDS>
+__global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
+{
+    using C = Cfg<W, RPL, PRE, REFLDS>;
+    constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
+
+    __shared__ float4 s_ring[C::RING_F4];
+    __shared__ int4 s_exch[2][NV];
+    __shared__ int s_red[3][4];      // {max key, first unpruned row (min), last unpruned row (max), -}
+    __shared__ int s_conv[2][4];     // {vmin, vmax, flags, -}
+    __shared__ int s_misc[4];
+    __shared__ int8_t s_rev[2 * kMaxMarker + 16];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *tb = a.tb + (size_t)blockIdx.x * (size_t)a.tb_words;
+    const float gapOpen = a.gap_open, gapExtend = a.gap_extend, gc = a.gap_char;
+    const int marker = a.marker;
+    const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
+    const float xdropf = (float)a.xdrop;
+
+    for (;;) {
+        if (threadIdx.x == 0) s_misc[0] = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        if (item >= a.n_items) break;
+        const int pair = __builtin_amdgcn_readfirstlane(a.items[item]);
+        const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
+        const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
+        const bool denomOne = (denom == 1.0f);
+        const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * 8);
+        const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * 8);
+        int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
+
+        if (R <= 0 || Q <= 0) {
+            if (threadIdx.x == 0) { a.aln_len[pair] = 0; a.err[pair] = 0; a.cells[pair] = 0; }
+            __syncthreads();
+            continue;
+        }
+
+        int ref_idx = 0, qry_idx = 0, tile = 0, pos = 0, err = 0;
+        bool last_tile = false;
+        unsigned long long cells = 0;
+
+        while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
+            int refLen = R - ref_idx, qLen = Q - qry_idx;
+            const int fLen = min(a.flen, min(refLen, qLen));                          // :258
+            // ---- per-slot (virtual wave) state ----
+            float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
+            int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
+            float qv[RPL][6], gopq[RPL], gexq[RPL];
+            float qM[RPL][PRE ? 25 : 1];
+            int blk[RPL], uph[RPL];
+            uint32_t tbacc[RPL];
+            bool tbdirty[RPL], q5any[RPL];
+
+            auto load_q = [&](int r) {
+                const int i = 64 * blk[r] + lane;
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+                if (qry_idx + i < Q) { c0 = colsQ[2 * (size_t)(qry_idx + i)]; c1 = colsQ[2 * (size_t)(qry_idx + i) + 1]; }
+                qv[r][0] = c0.x; qv[r][1] = c0.y; qv[r][2] = c0.z; qv[r][3] = c0.w; qv[r][4] = c1.x; qv[r][5] = c1.y;
+                gopq[r] = c1.z; gexq[r] = c1.w;
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int l = 0; l < 5; ++l)
+#pragma unroll
+                        for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = qv[r][m] * a.M[5 * l + m];   // first rounding of (q*M)*r, :386
+                }
+                q5any[r] = __builtin_amdgcn_ballot_w64(qv[r][5] != 0.0f) != 0ull;
+            };
+            auto load_ring_block = [&](int B) {
+                if constexpr (REFLDS) {
+                    const int col = 64 * B + lane;
+                    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+                    if (col < refLen) { c0 = colsR[2 * (size_t)(ref_idx + col)]; c1 = colsR[2 * (size_t)(ref_idx + col) + 1]; }
+                    const int slot = (B % NB) * 64 + lane;
+                    s_ring[2 * slot] = c0; s_ring[2 * slot + 1] = c1;
+                }
+            };
+
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int vw = r * W + w;
+                blk[r] = vw;
+                uph[r] = (vw == 0) ? 0 : CAP - 64 * vw;       // (k - 64*blk) mod CAP at k = 0
+                tbacc[r] = 0; tbdirty[r] = false;
+                S1[r] = I1[r] = D1[r] = LS2[r] = -1.0f;       // never read before written for in-band cells
+                CS1[r] = -1; CI1[r] = kIB; CD1[r] = kDB; LCS2[r] = -1;
+                load_q(r);
+            }
+            int hiBlk = 1;
+            if (w == 0 % W) load_ring_block(0);
+            if (w == 1 % W) load_ring_block(1);
+            if (threadIdx.x == 0) {
+                s_red[0][0] = f2key(-inf); s_red[0][1] = 0x7fffffff; s_red[0][2] = -1;
+                s_conv[0][0] = 0x7fffffff; s_conv[0][1] = (int)0x80000000; s_conv[0][2] = 0;
+                s_conv[1][0] = 0x7fffffff; s_conv[1][1] = (int)0x80000000; s_conv[1][2] = 0;
+            }
+            __syncthreads();
+
+            // ---- Tile, TALCO-XDrop.cpp:233-689 ----
+            int Lk = 0, Uk = 0, L1 = 2, U1 = -2, L2 = 1, U2 = -1;      // :296-297 (rows k, k-1, k-2)
+            float msp = -inf, max_score = 0.0f, conv_score = 0.0f;      // :259-260
+            bool converged = false, conv_logic = false;
+            int conv_value = 0, prev_conv_s = -1, last_k = 0;
+            const int kEnd = refLen + qLen - 1;
+            int k = 0;
+            int tile_err = 0;
+
+            for (; k < kEnd; ++k) {
+                if (Lk >= Uk + 1) { tile_err = 1; break; }                // :323-329
+                if (Uk - Lk + 1 > fLen) { tile_err = 2; break; }          // :331-338
+                if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; break; }
+                cells += (unsigned long long)(Uk - Lk + 1);
+                const int par = k & 1;
+                const int rs3 = k % 3;
+                const float thr = max_score - xdropf;                      // :495
+                const bool pb = (k >= marker - 1);
+                const bool edgeStep = (tile == 0) && (Lk == 0 || Uk == k);
+
+                if constexpr (REFLDS) {
+                    const int need_hi = ((k - Lk) >> 6) + 1;
+                    if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
+                }
+                if (threadIdx.x == 0) {   // reset the reduction slot of the next diagonal
+                    const int nx = (k + 1) % 3;
+                    s_red[nx][0] = f2key(-inf); s_red[nx][1] = 0x7fffffff; s_red[nx][2] = -1;
+                }
+
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int vw = r * W + w;
+                    if (64 * blk[r] + 63 < Lk) {               // block fell out of the band: take the next one
+                        while (64 * blk[r] + 63 < Lk) { blk[r] += NV; uph[r] -= WINDOW; if (uph[r] < 0) uph[r] += CAP; }
+                        load_q(r);
+                    }
+                    const int b = 64 * blk[r];
+                    const bool fetchActive = (b <= Uk + 1) && (b + 63 >= Lk);
+                    const bool active = (b <= Uk);
+                    float LS1 = 0.f, LI1 = 0.f; int LCS1 = 0, LCI1 = 0;
+                    if (fetchActive) {
+                        const int4 e = s_exch[par ^ 1][(vw + NV - 1) % NV];
+                        LS1 = dpp_shr1_f(__int_as_float(e.x), S1[r]);
+                        LI1 = dpp_shr1_f(__int_as_float(e.y), I1[r]);
+                        if (pb) { LCS1 = dpp_shr1_i(e.z, CS1[r]); LCI1 = dpp_shr1_i(e.w, CI1[r]); }
+                    }
+                    if (fetchActive && active) {
+                        const int i = b + lane;
+                        const int j = k - i;
+                        const bool inband = (i >= Lk) && (i <= Uk);
+                        // reference column r[j]
+                        float4 ra, rb;
+                        if constexpr (REFLDS) {
+                            int rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
+                            ra = s_ring[2 * rs]; rb = s_ring[2 * rs + 1];
+                        } else {
+                            ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra;
+                            if (inband) { ra = colsR[2 * (size_t)(ref_idx + j)]; rb = colsR[2 * (size_t)(ref_idx + j) + 1]; }
+                        }
+                        const float rr[5] = {ra.x, ra.y, ra.z, ra.w, rb.x};
+                        const float r5 = rb.y, gopr = rb.z, gexr = rb.w;
+                        // column score, :378-395,444 (order: ((t0+t1)+t2)+t3)+t4 per l, accumulated over l)
+                        float numer = 0.0f;
+#pragma unroll
+                        for (int l = 0; l < 5; ++l) {
+                            float t[5];
+#pragma unroll
+                            for (int m = 0; m < 5; ++m) {
+                                if constexpr (PRE) t[m] = qM[r][5 * l + m] * rr[l];
+                                else t[m] = (qv[r][m] * a.M[5 * l + m]) * rr[l];
+                            }
+                            const float s = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+                            numer = (l == 0) ? s : numer + s;
+                        }
+                        if (q5any[r]) {
+#pragma unroll
+                            for (int l = 0; l < 5; ++l) numer += (rr[l] * qv[r][5]) * gc;       // :394
+                        }
+                        if (__builtin_amdgcn_ballot_w64(inband && r5 != 0.0f) != 0ull) {
+#pragma unroll
+                            for (int m = 0; m < 5; ++m) numer += (r5 * qv[r][m]) * gc;          // :395
+                        }
+                        const float sim = denomOne ? numer : numer / denom;                     // :444
+
+                        const bool diag_ok = (i - 1 >= L2) && (i - 1 <= U2);
+                        const bool up_ok = (i >= L1) && (i <= U1);
+                        const bool left_ok = (i - 1 >= L1) && (i - 1 <= U1);
+                        float match;                                                            // :445-450
+                        if (k == 0) match = sim;
+                        else match = diag_ok ? LS2[r] + sim : -inf;
+                        if (edgeStep && k > 0) {
+                            if (i == 0 || j == 0) {
+                                int far = max(i, j) - 1; far = far < 0 ? 0 : far;
+                                match = (sim + gapOpen) + gapExtend * (float)far;
+                            }
+                        }
+                        const float delOp = up_ok ? S1[r] + gopr : -inf;                          // :456-463
+                        const float delExt = up_ok ? D1[r] + gexr : -inf;
+                        const float insOp = left_ok ? LS1 + gopq[r] : -inf;
+                        const float insExt = left_ok ? LI1 + gexq[r] : -inf;
+                        const bool Iptr = insExt >= insOp;                                        // :468-475
+                        const bool Dptr = delExt >= delOp;
+                        const float Iv = Iptr ? insExt : insOp;
+                        const float Dv = Dptr ? delExt : delOp;
+                        float Sv; int ptr;                                                      // :477-494
+                        if (match >= Iv) {
+                            if (match >= Dv) { Sv = match; ptr = 0; } else { Sv = Dv; ptr = 2; }
+                        } else if (Iv > Dv) { Sv = Iv; ptr = 1; }
+                        else { Sv = Dv; ptr = 2; }
+                        if (Sv < thr) Sv = -inf;                                                // :495-497
+
+                        if (pb) {                                                               // :520-547
+                            int CSn, CIn = CI1[r], CDn = CD1[r];
+                            if (k == marker - 1) CSn = (3 << 16) | (i & 0xFFFF);
+                            else if (k == marker) {
+                                CSn = i & 0xFFFF; CIn = (1 << 16) | (i & 0xFFFF); CDn = (2 << 16) | (i & 0xFFFF);
+                            } else {
+                                CIn = Iptr ? (left_ok ? LCI1 : kIB) : ((left_ok && LCS1 != -1) ? LCS1 : kIB);
+                                CDn = Dptr ? CD1[r] : ((CS1[r] != -1) ? CS1[r] : kDB);
+                                CSn = (ptr == 0) ? LCS2[r] : ((ptr == 1) ? CIn : CDn);
+                            }
+                            if (inband) { CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn; }
+                        }
+                        if (inband) { S1[r] = Sv; I1[r] = Iv; D1[r] = Dv; }
+                        if (k <= marker) {                                                      // :548-557
+                            const uint32_t nib = (uint32_t)ptr | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
+                            tbacc[r] |= nib << (4 * (k & 7));
+                            tbdirty[r] = true;
+                        }
+                        // wave summaries -> LDS reduction slot of this diagonal
+                        const unsigned long long vm = __builtin_amdgcn_ballot_w64(inband && Sv > -inf);
+                        const bool raise = __builtin_amdgcn_ballot_w64(inband && Sv > msp) != 0ull;
+                        float wmax = 0.f;
+                        if (raise) wmax = wave_max_f32(inband ? Sv : -inf);
+                        if (lane == 0) {
+                            if (raise) atomicMax(&s_red[rs3][0], f2key(wmax));
+                            if (vm) {
+                                atomicMin(&s_red[rs3][1], b + (int)__builtin_ctzll(vm));
+                                atomicMax(&s_red[rs3][2], b + 63 - (int)__builtin_clzll(vm));
+                            }
+                        }
+                        if (lane == 63) s_exch[par][vw] = make_int4(__float_as_int(S1[r]), __float_as_int(I1[r]), CS1[r], CI1[r]);
+                    }
+                    if (fetchActive) { LS2[r] = LS1; LCS2[r] = LCS1; }
+                    if (tbdirty[r] && (((k & 7) == 7) || k == marker)) {
+                        tb[(size_t)(k >> 3) * WINDOW + 64 * vw + lane] = tbacc[r];
+                        tbacc[r] = 0; tbdirty[r] = false;
+                    }
+                    uph[r] += 1; if (uph[r] == CAP) uph[r] = 0;
+                }
+                __syncthreads();
+
+                const int gkey = __builtin_amdgcn_readfirstlane(s_red[rs3][0]);
+                const int gfirst = __builtin_amdgcn_readfirstlane(s_red[rs3][1]);
+                const int glast = __builtin_amdgcn_readfirstlane(s_red[rs3][2]);
+                const bool anyValid = glast >= 0;
+                const int newL = anyValid ? gfirst : Uk + 1;                  // :563-583
+                const int newU = anyValid ? glast : Lk - 1;
+                msp = fmaxf(msp, key2f(gkey));                                // :501-503
+
+                if (!converged && k < kEnd - 1) {                             // :585-595
+                    int conv_S = -1;
+                    bool all3 = false;
+                    if (k == marker - 1) conv_S = (newL == newU) ? ((3 << 16) | (newL & 0xFFFF)) : -1;
+                    else if (k == marker) conv_S = (newL == newU) ? (newL & 0xFFFF) : -1;
+                    else if (k > marker) {
+                        if (threadIdx.x == 0) {
+                            s_conv[par ^ 1][0] = 0x7fffffff; s_conv[par ^ 1][1] = (int)0x80000000; s_conv[par ^ 1][2] = 0;
+                        }
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) {
+                            const int b = 64 * blk[r];
+                            if (b <= newU && b + 63 >= newL) {
+                                const int i = b + lane;
+                                const bool inr = (i >= newL) && (i <= newU);
+                                const unsigned long long rm = __builtin_amdgcn_ballot_w64(inr);
+                                if (rm) {
+                                    const int fl = (int)__builtin_ctzll(rm);
+                                    const int v = __builtin_amdgcn_readlane(CS1[r], fl);
+                                    const bool badS = __builtin_amdgcn_ballot_w64(inr && CS1[r] != v) != 0ull;
+                                    const bool badID = __builtin_amdgcn_ballot_w64(inr && (CI1[r] != v || CD1[r] != v)) != 0ull;
+                                    if (lane == 0) {
+                                        atomicMin(&s_conv[par][0], v);
+                                        atomicMax(&s_conv[par][1], v);
+                                        if (badS || badID) atomicOr(&s_conv[par][2], (badS ? 1 : 0) | (badID ? 2 : 0));
+                                    }
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        const int vmin = __builtin_amdgcn_readfirstlane(s_conv[par][0]);
+                        const int vmax = __builtin_amdgcn_readfirstlane(s_conv[par][1]);
+                        const int fl = __builtin_amdgcn_readfirstlane(s_conv[par][2]);
+                        if (newU >= newL && vmin == vmax && !(fl & 1)) { conv_S = vmin; all3 = !(fl & 2); }
+                    }
+                    if (all3 && prev_conv_s == conv_S && conv_S != -1) {
+                        converged = true; conv_value = prev_conv_s; conv_score = msp;
+                    }
+                    prev_conv_s = conv_S;
+                }
+
+                {                                                             // :597-604
+                    const int v2 = k + 2 - refLen;
+                    const int Lprime = v2 > 0 ? v2 : 0;
+                    const int nL = newL > Lprime ? newL : Lprime;
+                    const int nU = (qLen - 1) < (newU + 1) ? (qLen - 1) : (newU + 1);
+                    L2 = L1; U2 = U1; L1 = Lk; U1 = Uk; Lk = nL; Uk = nU;
+                }
+                max_score = (msp < 0.0f) ? 0.0f : msp;                        // :607
+                last_k = k;
+                if (converged && max_score > conv_score) { conv_logic = true; break; }   // :609-612
+            }
+
+            if (tile_err != 0) { err = tile_err; break; }
+
+            // a tile that ends before the marker leaves its last (partial) group of 8 diagonals unflushed
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                if (tbdirty[r]) { tb[(size_t)(last_k >> 3) * WINDOW + 64 * (r * W + w) + lane] = tbacc[r]; tbdirty[r] = false; }
+            }
+
+            // ---- tile exit, :615-682 ----
+            // after the loop (L1,U1) is the band of diagonal last_k (rotated once more at its end)
+            int conv_q = 0, conv_r = 0, tb_state = 0, start_k = 0;
+            bool bad = false;
+            if (!conv_logic && last_k >= marker) {                            // :633-635 needs CS[last_k][0]
+                const int Llast = L1;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int b = 64 * blk[r];
+                    if (Llast >= b && Llast <= b + 63 && lane == Llast - b) s_misc[1] = CS1[r];
+                }
+                __syncthreads();
+                conv_value = __builtin_amdgcn_readfirstlane(s_misc[1]);
+            }
+            if (conv_logic || last_k >= marker) {
+                conv_q = conv_value & 0xFFFF;
+                tb_state = (conv_value >> 16) & 0xFFFF;
+                if (tb_state > 3) bad = true;      // boundary sentinel / unset: the reference indexes out of range here
+                else {
+                    conv_r = marker - conv_q - ((tb_state == 3) ? 1 : 0);
+                    start_k = (tb_state == 3) ? marker - 1 : marker;
+                    if (conv_r < 0) bad = true;
+                }
+            } else {                                                          // :625-632
+                conv_q = qLen - 1; conv_r = refLen - 1; start_k = last_k; tb_state = 0; last_tile = true;
+            }
+            if (bad) { err = 3; break; }
+            ref_idx += conv_r; qry_idx += conv_q;                             // :654-655
+            if (R - ref_idx < 0 || Q - qry_idx < 0) { err = 3; break; }       // :659-668
+            int tailDir = 0, tailLen = 0;
+            if (ref_idx == R - 1 && qry_idx < Q - 1) { tailDir = 1; tailLen = Q - qry_idx - 1; last_tile = true; }   // :671-674
+            if (qry_idx == Q - 1 && ref_idx < R - 1) { tailDir = 2; tailLen = R - ref_idx - 1; last_tile = true; }   // :675-678
+            if (ref_idx == R - 1 && qry_idx == Q - 1) last_tile = true;       // :679
+
+            __syncthreads();   // all traceback-pointer stores of this tile are complete and visible
+            if (w == 0) {
+                int n = 0;
+                if (lane == 0) {   // Traceback, :134-231, addressed by (diagonal, row) instead of a ragged offset
+                    int kk = start_k, ii = conv_q, qi = conv_q, ri = conv_r, st = tb_state % 3;
+                    const bool first = (tile == 0);
+                    while (kk >= 0) {
+                        const uint32_t word = __hip_atomic_load(&tb[(size_t)(kk >> 3) * WINDOW + (ii % WINDOW)], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                        const int v = (int)((word >> (4 * (kk & 7))) & 0xFu);
+                        int dir;
+                        if (st == 0) {
+                            st = v & 3;
+                            if (st == 0) dir = 0;
+                            else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
+                            else { dir = 2; st = (v & 8) ? 2 : 0; }
+                        } else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
+                        else { dir = 2; st = (v & 8) ? 2 : 0; }
+                        if (dir == 0) { kk -= 2; ii -= 1; qi--; ri--; }
+                        else if (dir == 1) { kk -= 1; ii -= 1; qi--; }
+                        else { kk -= 1; ri--; }
+                        s_rev[n++] = (int8_t)dir;
+                        if (first && (ri < 0 || qi < 0)) break;
+                        if (ii < 0) break;   // defensive: a pointer chain left the tile (never on valid data)
+                    }
+                    if (first) {
+                        while (ri > -1) { s_rev[n++] = 2; ri--; }
+                        while (qi > -1) { s_rev[n++] = 1; qi--; }
+                    }
+                }
+                n = __builtin_amdgcn_readfirstlane(n);
+                const int skip = (tile > 0) ? 1 : 0;                          // :98-102
+                const int cnt = n - skip;
+                if (pos + cnt + tailLen > 2 * a.seq_len) { err = 3; }
+                else {
+                    for (int t = lane; t < cnt; t += 64) out[pos + t] = s_rev[n - 1 - skip - t];
+                    for (int t = lane; t < tailLen; t += 64) out[pos + cnt + t] = (int8_t)tailDir;
+                    pos += cnt + tailLen;
+                }
+                if (lane == 0) s_misc[2] = err;
+            }
+            __syncthreads();
+            err = __builtin_amdgcn_readfirstlane(s_misc[2] == 3 ? 3 : err);
+            if (err != 0) break;
+            ++tile;
+        }
+
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.err[pair] = (int16_t)err;
+            a.aln_len[pair] = (err == 0) ? pos : 0;
+            a.cells[pair] = cells;
+        }
+    }
+}
+
+// ---- column packing: freq[pair][2][seq_len][6] + gapOpen/gapExtend[pair][2][seq_len] -> cols[pair][2][seq_len][8] ----
+__global__ void pack_nuc_kernel(const float *__restrict__ freq, const float *__restrict__ gop, const float *__restrict__ gex,
+                                float4 *__restrict__ cols, size_t n_cols)
+{
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (size_t)gridDim.x * blockDim.x) {
+        const float *f = freq + c * 6;
+        cols[2 * c] = make_float4(f[0], f[1], f[2], f[3]);
+        cols[2 * c + 1] = make_float4(f[4], f[5], gop[c], gex[c]);
+    }
+}
+
+}  // namespace twl

@@ -1,0 +1,399 @@
+// twilight_amd/csrc/twl_align.hip -- host side of libtwl_align (C ABI in include/twl_align.h).
+//
+// Owns device buffers, streams and the launch policy.  There is no CPU fallback: without a HIP
+// device every entry point fails with TWL_ERR_HIP / TWL_ERR_NOT_INITIALIZED.
+#include "../../include/twl_align.h"
+#include "talco_kernel.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                         \
+            return TWL_ERR_HIP;                                                                                \
+        }                                                                                                      \
+    } while (0)
+
+// Fast path: 16 waves, one 64-row block per wave  -> 1024-row window (bands up to 961 wide), ref ring in LDS.
+// Wide path: 8 waves x 9 blocks                   -> 4608-row window (covers flen = 4096), ref columns from L2/HBM.
+using FastCfg = twl::Cfg<16, 1, true, true>;
+using WideCfg = twl::Cfg<8, 9, false, false>;
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return TWL_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return TWL_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Device {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    int num_cu = 0;
+    int fast_blocks_per_cu = 0, wide_blocks_per_cu = 0;
+    Buf cols, tb, cells, queue, items, errs;
+    Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
+    twl_stats stats{};
+    std::vector<uint64_t> pair_cells;
+    std::mutex mu;
+};
+
+std::vector<Device *> g_devs;
+bool g_init = false;
+
+int find_dev(int device, Device **out)
+{
+    for (auto *d : g_devs) if (d->id == device) { *out = d; return TWL_OK; }
+    g_err = "device not selected in twl_init";
+    return TWL_ERR_BAD_ARGUMENT;
+}
+
+int check_params(const twl_params *p)
+{
+    if (!p) { g_err = "params is null"; return TWL_ERR_BAD_ARGUMENT; }
+    if (p->P != 6) { g_err = "only P=6 (nucleotide) profiles are implemented in this build"; return TWL_ERR_UNSUPPORTED; }
+    if (p->marker < 2 || p->marker > TWL_MAX_MARKER) { g_err = "marker outside [2, TWL_MAX_MARKER]"; return TWL_ERR_UNSUPPORTED; }
+    if (p->flen < 1 || p->flen > 4096) { g_err = "flen outside [1, 4096]"; return TWL_ERR_UNSUPPORTED; }
+    if (p->xdrop < 0) { g_err = "xdrop < 0"; return TWL_ERR_BAD_ARGUMENT; }
+    return TWL_OK;
+}
+
+template <class CfgT>
+size_t tb_words_for(int marker) { return ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW; }
+
+template <int W, int RPL, bool PRE, bool REFLDS>
+int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int blocks_per_cu, int *grid_out)
+{
+    using CfgT = twl::Cfg<W, RPL, PRE, REFLDS>;
+    int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
+    if (grid < 1) grid = 1;
+    const size_t tbw = tb_words_for<CfgT>(base.marker);
+    int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
+    if (rc) return rc;
+    twl::KArgs a = base;
+    a.tb = (uint32_t *)d->tb.p;
+    a.tb_words = (int32_t)tbw;
+    a.items = d_items;
+    a.n_items = n_items;
+    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, PRE, REFLDS>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    *grid_out = grid;
+    return TWL_OK;
+}
+
+// Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
+int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
+               const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
+               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len)
+{
+    HIP_TRY(hipSetDevice(d->id));
+    d->stats = twl_stats{};
+    d->pair_cells.assign((size_t)n_pairs, 0);
+    if (n_pairs == 0) return TWL_OK;
+
+    int rc;
+    const size_t n_cols = (size_t)n_pairs * 2 * (size_t)seq_len;
+    if ((rc = d->cols.ensure(n_cols * 8 * sizeof(float)))) return rc;
+    if ((rc = d->cells.ensure((size_t)n_pairs * sizeof(unsigned long long)))) return rc;
+    if ((rc = d->queue.ensure(64))) return rc;
+    if ((rc = d->items.ensure((size_t)n_pairs * sizeof(int32_t)))) return rc;
+
+    // cost order: longest first (LPT) so the persistent workgroups finish together
+    std::vector<int32_t> len_host;
+    if (!h_len) {
+        len_host.resize((size_t)n_pairs * 2);
+        HIP_TRY(hipMemcpyAsync(len_host.data(), d_len, len_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h_len = len_host.data();
+    }
+    std::vector<int32_t> order((size_t)n_pairs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return (int64_t)h_len[2 * x] + h_len[2 * x + 1] > (int64_t)h_len[2 * y] + h_len[2 * y + 1];
+    });
+    uint64_t nominal = 0;
+    for (int32_t n = 0; n < n_pairs; ++n) nominal += (uint64_t)std::max(0, h_len[2 * n]) * (uint64_t)std::max(0, h_len[2 * n + 1]);
+    HIP_TRY(hipMemcpyAsync(d->items.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    {
+        const int threads = 256;
+        const int blocks = (int)std::min<size_t>((n_cols + threads - 1) / threads, (size_t)d->num_cu * 8);
+        hipLaunchKernelGGL(twl::pack_nuc_kernel, dim3(std::max(blocks, 1)), dim3(threads), 0, st, d_freq, d_gop, d_gex,
+                           (float4 *)d->cols.p, n_cols);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(d->ev[1], st));
+
+    twl::KArgs a{};
+    a.cols = (const float *)d->cols.p;
+    a.len = d_len; a.num = d_num;
+    a.aln = d_aln; a.aln_len = d_alnlen; a.err = d_err;
+    a.cells = (unsigned long long *)d->cells.p;
+    a.queue = (int32_t *)d->queue.p;
+    a.seq_len = seq_len;
+    a.gap_open = p->gap_open; a.gap_extend = p->gap_extend; a.gap_char = p->gap_char;
+    a.xdrop = p->xdrop; a.flen = p->flen; a.marker = p->marker;
+    for (int l = 0; l < 5; ++l) for (int m = 0; m < 5; ++m) a.M[5 * l + m] = p->matrix[5 * l + m];
+
+    int grid = 0;
+    const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
+    if (!force_wide)
+        rc = launch_dp<16, 1, true, true>(d, st, a, (const int32_t *)d->items.p, n_pairs, d->fast_blocks_per_cu, &grid);
+    else
+        rc = launch_dp<8, 9, false, false>(d, st, a, (const int32_t *)d->items.p, n_pairs, d->wide_blocks_per_cu, &grid);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(d->ev[2], st));
+    d->stats.n_launches = 1;
+    d->stats.grid = grid;
+    d->stats.window = force_wide ? WideCfg::WINDOW : FastCfg::WINDOW;
+
+    // pairs whose band outgrew the fast window are re-run (bit-identically) by the wide kernel
+    std::vector<int16_t> h_err((size_t)n_pairs);
+    HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int32_t> redo;
+    for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
+    float ms_redo = 0.f;
+    std::vector<unsigned long long> cells_first;
+    if (!redo.empty()) {
+        if (force_wide) { g_err = "band wider than the wide window"; return TWL_ERR_UNSUPPORTED; }
+        cells_first.resize((size_t)n_pairs);
+        HIP_TRY(hipMemcpyAsync(cells_first.data(), d->cells.p, cells_first.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(d->ev[3], st));
+        int grid2 = 0;
+        rc = launch_dp<8, 9, false, false>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), d->wide_blocks_per_cu, &grid2);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(d->ev[4], st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventElapsedTime(&ms_redo, d->ev[3], d->ev[4]));
+        d->stats.n_launches = 2;
+        d->stats.n_relaunched = (int32_t)redo.size();
+    }
+    std::vector<unsigned long long> cells((size_t)n_pairs);
+    HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
+    // work done by the abandoned fast-window attempts is real GPU work but not algorithmic cells: not counted
+    float ms_pack = 0.f, ms_k = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms_pack, d->ev[0], d->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms_k, d->ev[1], d->ev[2]));
+    d->stats.band_cells = total;
+    d->stats.nominal_cells = nominal;
+    d->stats.pack_ms = ms_pack;
+    d->stats.kernel_ms = ms_k + ms_redo;
+    d->stats.total_ms = ms_pack + ms_k + ms_redo;
+    return TWL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *twl_last_error(void) { return g_err.c_str(); }
+const char *twl_version(void) { return "twilight_amd 0.1 (gfx950)"; }
+
+int twl_init(const int *device_ids, int n_devices)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init) return TWL_OK;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count < 1) { g_err = "no HIP device"; return TWL_ERR_HIP; }
+    std::vector<int> ids;
+    if (!device_ids || n_devices <= 0) ids.push_back(0);
+    else ids.assign(device_ids, device_ids + n_devices);
+    for (int id : ids) {
+        if (id < 0 || id >= count) { g_err = "device id out of range"; return TWL_ERR_BAD_ARGUMENT; }
+        HIP_TRY(hipSetDevice(id));
+        auto *d = new Device();
+        d->id = id;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, id));
+        d->num_cu = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        for (auto &e : d->ev) HIP_TRY(hipEventCreate(&e));
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<16, 1, true, true>), FastCfg::THREADS, 0));
+        d->fast_blocks_per_cu = std::max(1, nb);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<8, 9, false, false>), WideCfg::THREADS, 0));
+        d->wide_blocks_per_cu = std::max(1, std::min(nb, 1));
+        g_devs.push_back(d);
+    }
+    g_init = true;
+    return TWL_OK;
+}
+
+void twl_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto *d : g_devs) {
+        (void)hipSetDevice(d->id);
+        (void)hipStreamSynchronize(d->stream);
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->h2d_freq, &d->h2d_gop, &d->h2d_gex,
+                       &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
+            b->release();
+        for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
+        if (d->stream) (void)hipStreamDestroy(d->stream);
+        delete d;
+    }
+    g_devs.clear();
+    g_init = false;
+}
+
+int twl_align_batch_device(int device, void *stream, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
+                           const float *d_gap_open, const float *d_gap_extend, const int32_t *d_len, const int32_t *d_num,
+                           int8_t *d_aln_out, int32_t *d_aln_len_out, int16_t *d_err_out)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_pairs < 0 || seq_len < 1) { g_err = "bad n_pairs/seq_len"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = nullptr;
+    if ((rc = find_dev(device, &d))) return rc;
+    std::lock_guard<std::mutex> lk(d->mu);
+    hipStream_t st = stream ? (hipStream_t)stream : d->stream;
+    return run_device(d, st, p, n_pairs, seq_len, d_freq, d_gap_open, d_gap_extend, d_len, d_num, d_aln_out, d_aln_len_out,
+                      d_err_out, nullptr);
+}
+
+static int run_host_slice(Device *d, const twl_params *p, const std::vector<int32_t> &ids, int32_t seq_len, const float *freq,
+                          const float *gop, const float *gex, const int32_t *len, const int32_t *num, int8_t *aln_out,
+                          int32_t *aln_len_out, int16_t *err_out)
+{
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    const int32_t n = (int32_t)ids.size();
+    if (n == 0) return TWL_OK;
+    const size_t P = (size_t)p->P, sl = (size_t)seq_len;
+    int rc;
+    if ((rc = d->h2d_freq.ensure((size_t)n * 2 * sl * P * sizeof(float)))) return rc;
+    if ((rc = d->h2d_gop.ensure((size_t)n * 2 * sl * sizeof(float)))) return rc;
+    if ((rc = d->h2d_gex.ensure((size_t)n * 2 * sl * sizeof(float)))) return rc;
+    if ((rc = d->h2d_len.ensure((size_t)n * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = d->h2d_num.ensure((size_t)n * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = d->d_aln.ensure((size_t)n * 2 * sl))) return rc;
+    if ((rc = d->d_alnlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = d->d_err.ensure((size_t)n * sizeof(int16_t)))) return rc;
+    hipStream_t st = d->stream;
+    std::vector<int32_t> hl((size_t)n * 2), hn((size_t)n * 2);
+    HIP_TRY(hipEventRecord(d->ev[5], st));
+    for (int32_t t = 0; t < n; ++t) {
+        const size_t s = (size_t)ids[t];
+        hl[2 * t] = len[2 * s]; hl[2 * t + 1] = len[2 * s + 1];
+        hn[2 * t] = num[2 * s]; hn[2 * t + 1] = num[2 * s + 1];
+        HIP_TRY(hipMemcpyAsync((float *)d->h2d_freq.p + (size_t)t * 2 * sl * P, freq + s * 2 * sl * P, 2 * sl * P * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((float *)d->h2d_gop.p + (size_t)t * 2 * sl, gop + s * 2 * sl, 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((float *)d->h2d_gex.p + (size_t)t * 2 * sl, gex + s * 2 * sl, 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(d->h2d_len.p, hl.data(), hl.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->h2d_num.p, hn.data(), hn.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    rc = run_device(d, st, p, n, seq_len, (const float *)d->h2d_freq.p, (const float *)d->h2d_gop.p, (const float *)d->h2d_gex.p,
+                    (const int32_t *)d->h2d_len.p, (const int32_t *)d->h2d_num.p, (int8_t *)d->d_aln.p, (int32_t *)d->d_alnlen.p,
+                    (int16_t *)d->d_err.p, hl.data());
+    if (rc) return rc;
+    std::vector<int32_t> alen((size_t)n);
+    std::vector<int16_t> aerr((size_t)n);
+    HIP_TRY(hipMemcpyAsync(alen.data(), d->d_alnlen.p, alen.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(aerr.data(), d->d_err.p, aerr.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int32_t t = 0; t < n; ++t) {
+        const size_t s = (size_t)ids[t];
+        aln_len_out[s] = alen[t];
+        err_out[s] = aerr[t];
+        if (alen[t] > 0)
+            HIP_TRY(hipMemcpyAsync(aln_out + s * 2 * sl, (int8_t *)d->d_aln.p + (size_t)t * 2 * sl, (size_t)alen[t], hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(d->ev[3], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[5], d->ev[3]));
+    d->stats.total_ms = ms;
+    return TWL_OK;
+}
+
+int twl_align_batch(const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *freq, const float *gap_open,
+                    const float *gap_extend, const int32_t *len, const int32_t *num, int8_t *aln_out, int32_t *aln_len_out,
+                    int16_t *err_out)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_pairs < 0 || seq_len < 1 || (n_pairs > 0 && (!freq || !gap_open || !gap_extend || !len || !num || !aln_out || !aln_len_out || !err_out))) {
+        g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT;
+    }
+    const size_t nd = g_devs.size();
+    // deal pairs to devices in descending cost order (independent units, no collective)
+    std::vector<int32_t> order((size_t)n_pairs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return (int64_t)len[2 * x] + len[2 * x + 1] > (int64_t)len[2 * y] + len[2 * y + 1];
+    });
+    std::vector<std::vector<int32_t>> slices(nd);
+    for (size_t t = 0; t < order.size(); ++t) slices[t % nd].push_back(order[t]);
+    if (nd == 1) return run_host_slice(g_devs[0], p, slices[0], seq_len, freq, gap_open, gap_extend, len, num, aln_out, aln_len_out, err_out);
+    std::vector<int> rcs(nd, 0);
+    std::vector<std::string> errs(nd);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < nd; ++i)
+        th.emplace_back([&, i] {
+            rcs[i] = run_host_slice(g_devs[i], p, slices[i], seq_len, freq, gap_open, gap_extend, len, num, aln_out, aln_len_out, err_out);
+            errs[i] = g_err;
+        });
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < nd; ++i) if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
+    return TWL_OK;
+}
+
+int twl_get_stats(int device, twl_stats *out)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    if (!out) { g_err = "out is null"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    *out = d->stats;
+    return TWL_OK;
+}
+
+int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    if (!cells_out || n < 0 || (size_t)n > d->pair_cells.size()) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    for (int32_t i = 0; i < n; ++i) cells_out[i] = d->pair_cells[i];
+    return TWL_OK;
+}
+
+}  // extern "C"
