@@ -45,10 +45,18 @@ struct KArgs {
     int32_t n_items;
     int32_t seq_len;
     int32_t tb_words;         // per workgroup
+    int32_t *dbg;             // optional [pair][16] debug record (nullptr = off)
+    int32_t *hb;              // optional host-mapped heartbeat [16] written by workgroup 0 (debug only)
+    int32_t step_slack;       // watchdog: a pair may run at most 32*(R+Q) + step_slack diagonals in total
     float gap_open, gap_extend, gap_char;
     int32_t xdrop, flen, marker;
     float M[25];              // scoreMatrix[l][m], 5x5
 };
+
+__device__ __forceinline__ void heartbeat(const KArgs &a, int slot, int v)
+{
+    if (a.hb && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&a.hb[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ float dpp_shr1_f(float from_prev_wave, float src)
 {
@@ -117,10 +125,12 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
 
+    heartbeat(a, 0, 1);
     for (;;) {
         if (threadIdx.x == 0) s_misc[0] = atomicAdd(a.queue, 1);
         __syncthreads();
         const int item = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        heartbeat(a, 1, item);
         if (item >= a.n_items) break;
         const int pair = __builtin_amdgcn_readfirstlane(a.items[item]);
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
@@ -130,15 +140,16 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
         const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * 8);
         int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
 
-        if (R <= 0 || Q <= 0) {
-            if (threadIdx.x == 0) { a.aln_len[pair] = 0; a.err[pair] = 0; a.cells[pair] = 0; }
-            __syncthreads();
-            continue;
-        }
-
+        // An empty side produces no path (the caller emits the all-gap path, alignment-cpu.cpp:89-90).
+        // NOTE on control flow: no `continue`, and every single-lane block is followed by a workgroup
+        // barrier before a loop back-edge.  With a divergent block next to the latch LLVM splits the
+        // back-edge and lets the other lanes run ahead into the next iteration's barrier (observed: the
+        // workgroup re-read a stale work item forever).
         int ref_idx = 0, qry_idx = 0, tile = 0, pos = 0, err = 0;
-        bool last_tile = false;
+        bool last_tile = (R <= 0 || Q <= 0);
         unsigned long long cells = 0;
+        long long steps_left = 32ll * (R + Q) + a.step_slack;   // watchdog: every loop below is bounded by it
+        int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
             int refLen = R - ref_idx, qLen = Q - qry_idx;
@@ -205,7 +216,10 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
             int k = 0;
             int tile_err = 0;
 
+            heartbeat(a, 2, tile);
             for (; k < kEnd; ++k) {
+                heartbeat(a, 3, k);
+                if (--steps_left < 0) { tile_err = 3; break; }
                 if (Lk >= Uk + 1) { tile_err = 1; break; }                // :323-329
                 if (Uk - Lk + 1 > fLen) { tile_err = 2; break; }          // :331-338
                 if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; break; }
@@ -346,7 +360,9 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
                     }
                     uph[r] += 1; if (uph[r] == CAP) uph[r] = 0;
                 }
+                heartbeat(a, 4, k);
                 __syncthreads();
+                heartbeat(a, 5, k);
 
                 const int gkey = __builtin_amdgcn_readfirstlane(s_red[rs3][0]);
                 const int gfirst = __builtin_amdgcn_readfirstlane(s_red[rs3][1]);
@@ -409,6 +425,7 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
                 if (converged && max_score > conv_score) { conv_logic = true; break; }   // :609-612
             }
 
+            dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
             if (tile_err != 0) { err = tile_err; break; }
 
             // a tile that ends before the marker leaves its last (partial) group of 8 diagonals unflushed
@@ -451,7 +468,9 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
             if (qry_idx == Q - 1 && ref_idx < R - 1) { tailDir = 2; tailLen = R - ref_idx - 1; last_tile = true; }   // :675-678
             if (ref_idx == R - 1 && qry_idx == Q - 1) last_tile = true;       // :679
 
+            heartbeat(a, 6, tile);
             __syncthreads();   // all traceback-pointer stores of this tile are complete and visible
+            heartbeat(a, 7, tile);
             if (w == 0) {
                 int n = 0;
                 if (lane == 0) {   // Traceback, :134-231, addressed by (diagonal, row) instead of a ragged offset
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
                     }
                 }
                 n = __builtin_amdgcn_readfirstlane(n);
+                heartbeat(a, 8, n);
                 const int skip = (tile > 0) ? 1 : 0;                          // :98-102
                 const int cnt = n - skip;
                 if (pos + cnt + tailLen > 2 * a.seq_len) { err = 3; }
@@ -498,12 +518,20 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
             ++tile;
         }
 
+        heartbeat(a, 9, err);
         __syncthreads();
         if (threadIdx.x == 0) {
             a.err[pair] = (int16_t)err;
             a.aln_len[pair] = (err == 0) ? pos : 0;
             a.cells[pair] = cells;
+            heartbeat(a, 10, pair);
+            if (a.dbg) {
+                int32_t *g = a.dbg + 16 * (size_t)pair;
+                g[0] = tile; g[1] = dbg_lastk; g[2] = dbg_conv; g[3] = dbg_L; g[4] = dbg_U; g[5] = ref_idx; g[6] = qry_idx;
+                g[7] = pos; g[8] = err; g[9] = (int32_t)(steps_left >> 0); g[10] = R; g[11] = Q;
+            }
         }
+        __syncthreads();   // keeps the single-lane block above out of the loop latch (see NOTE on control flow)
     }
 }
 

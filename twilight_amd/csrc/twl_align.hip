@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -20,6 +21,9 @@ namespace {
 
 thread_local std::string g_err;
 std::mutex g_mu;
+
+static bool dbg_on() { static int v = -1; if (v < 0) v = getenv("TWL_DEBUG") ? 1 : 0; return v == 1; }
+#define TRACE(...) do { if (dbg_on()) { fprintf(stderr, "[twl trace] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -57,7 +61,8 @@ struct Device {
     hipEvent_t ev[6] = {};
     int num_cu = 0;
     int fast_blocks_per_cu = 0, wide_blocks_per_cu = 0;
-    Buf cols, tb, cells, queue, items, errs;
+    Buf cols, tb, cells, queue, items, errs, dbg;
+    std::vector<int32_t> dbg_host;
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
     std::vector<uint64_t> pair_cells;
@@ -102,8 +107,26 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.items = d_items;
     a.n_items = n_items;
     HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    int32_t *hb = nullptr;
+    if (dbg_on()) {
+        HIP_TRY(hipHostMalloc((void **)&hb, 16 * sizeof(int32_t), hipHostMallocMapped));
+        for (int i = 0; i < 16; ++i) hb[i] = -777;
+        a.hb = hb;
+    }
+    TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
     hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, PRE, REFLDS>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
+    if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
+        for (int t = 0; t < 200; ++t) {
+            if (hipStreamQuery(st) == hipSuccess) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            if (t % 10 == 9)
+                TRACE("hb: start %d item %d tile %d k %d preB %d postB %d preTB %d postTB %d n %d err %d done %d", hb[0], hb[1], hb[2], hb[3],
+                      hb[4], hb[5], hb[6], hb[7], hb[8], hb[9], hb[10]);
+        }
+        TRACE("hb final: start %d item %d tile %d k %d preB %d postB %d preTB %d postTB %d n %d err %d done %d", hb[0], hb[1], hb[2], hb[3],
+              hb[4], hb[5], hb[6], hb[7], hb[8], hb[9], hb[10]);
+    }
     *grid_out = grid;
     return TWL_OK;
 }
@@ -142,6 +165,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     for (int32_t n = 0; n < n_pairs; ++n) nominal += (uint64_t)std::max(0, h_len[2 * n]) * (uint64_t)std::max(0, h_len[2 * n + 1]);
     HIP_TRY(hipMemcpyAsync(d->items.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
 
+    TRACE("run_device n_pairs=%d seq_len=%d", n_pairs, seq_len);
     HIP_TRY(hipEventRecord(d->ev[0], st));
     {
         const int threads = 256;
@@ -151,6 +175,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(d->ev[1], st));
+    if (dbg_on()) { HIP_TRY(hipStreamSynchronize(st)); TRACE("pack done"); }
 
     twl::KArgs a{};
     a.cols = (const float *)d->cols.p;
@@ -161,6 +186,14 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     a.seq_len = seq_len;
     a.gap_open = p->gap_open; a.gap_extend = p->gap_extend; a.gap_char = p->gap_char;
     a.xdrop = p->xdrop; a.flen = p->flen; a.marker = p->marker;
+    a.step_slack = 1 << 16;
+    const bool want_dbg = getenv("TWL_DEBUG") != nullptr;
+    a.dbg = nullptr;
+    if (want_dbg) {
+        if ((rc = d->dbg.ensure((size_t)n_pairs * 16 * sizeof(int32_t)))) return rc;
+        HIP_TRY(hipMemsetAsync(d->dbg.p, 0xff, (size_t)n_pairs * 16 * sizeof(int32_t), st));
+        a.dbg = (int32_t *)d->dbg.p;
+    }
     for (int l = 0; l < 5; ++l) for (int m = 0; m < 5; ++m) a.M[5 * l + m] = p->matrix[5 * l + m];
 
     int grid = 0;
@@ -179,6 +212,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     std::vector<int16_t> h_err((size_t)n_pairs);
     HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    TRACE("dp kernel done");
     std::vector<int32_t> redo;
     for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
     float ms_redo = 0.f;
@@ -203,6 +237,15 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t total = 0;
     for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
+    if (want_dbg) {
+        d->dbg_host.resize((size_t)n_pairs * 16);
+        HIP_TRY(hipMemcpy(d->dbg_host.data(), d->dbg.p, d->dbg_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int32_t n = 0; n < n_pairs && n < 64; ++n) {
+            const int32_t *g = &d->dbg_host[(size_t)n * 16];
+            fprintf(stderr, "[twl dbg] pair %d: tiles %d last_k %d conv 0x%x L %d U %d ref_idx %d qry_idx %d pos %d err %d steps_left %d R %d Q %d\n",
+                    n, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11]);
+        }
+    }
     // work done by the abandoned fast-window attempts is real GPU work but not algorithmic cells: not counted
     float ms_pack = 0.f, ms_k = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_pack, d->ev[0], d->ev[1]));
@@ -259,7 +302,7 @@ void twl_shutdown(void)
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->h2d_freq, &d->h2d_gop, &d->h2d_gex,
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->h2d_freq, &d->h2d_gop, &d->h2d_gex,
                        &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
