@@ -115,6 +115,11 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
     __shared__ int s_red[3][4];      // {max key, first unpruned row (min), last unpruned row (max), -}
     __shared__ int s_conv[2][4];     // {vmin, vmax, flags, -}
     __shared__ int s_misc[4];
+    // Offset-addressed mirror of the reference's two rotating CD rows (TALCO-XDrop.cpp:279,294,308).  The
+    // reference reads CD[(k+1)%2][offsetUp] unguarded above (:535): for the new top cell of a growing band
+    // offsetUp == width(k-1), i.e. whatever an older, wider diagonal left there -- and that value takes part in
+    // the convergence test (:587).  Only this row's addressing is observable, so only it is mirrored.
+    __shared__ int s_cd[2][WINDOW + 1];
     __shared__ int8_t s_rev[2 * kMaxMarker + 16];
 
     const int lane = threadIdx.x & 63;
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
             int hiBlk = 1;
             if (w == 0 % W) load_ring_block(0);
             if (w == 1 % W) load_ring_block(1);
+            for (int t = threadIdx.x; t < 2 * (WINDOW + 1); t += C::THREADS) (&s_cd[0][0])[t] = kDB;      // :308
             if (threadIdx.x == 0) {
                 s_red[0][0] = f2key(-inf); s_red[0][1] = 0x7fffffff; s_red[0][2] = -1;
                 s_conv[0][0] = 0x7fffffff; s_conv[0][1] = (int)0x80000000; s_conv[0][2] = 0;
@@ -328,10 +334,15 @@ __global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
                                 CSn = i & 0xFFFF; CIn = (1 << 16) | (i & 0xFFFF); CDn = (2 << 16) | (i & 0xFFFF);
                             } else {
                                 CIn = Iptr ? (left_ok ? LCI1 : kIB) : ((left_ok && LCS1 != -1) ? LCS1 : kIB);
-                                CDn = Dptr ? CD1[r] : ((CS1[r] != -1) ? CS1[r] : kDB);
+                                // :534-538; offsetUp >= 0 always holds; above the stored band it reads the stale slot
+                                const int cdUp = up_ok ? CD1[r] : s_cd[par ^ 1][U1 - L1 + 1];
+                                CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
                                 CSn = (ptr == 0) ? LCS2[r] : ((ptr == 1) ? CIn : CDn);
                             }
-                            if (inband) { CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn; }
+                            if (inband) {
+                                CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn;
+                                if (k >= marker) s_cd[par][i - Lk] = CDn;
+                            }
                         }
                         if (inband) { S1[r] = Sv; I1[r] = Iv; D1[r] = Dv; }
                         if (k <= marker) {                                                      // :548-557
