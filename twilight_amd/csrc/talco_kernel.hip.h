@@ -104,8 +104,8 @@ struct Cfg {
     static constexpr int THREADS = 64 * W;
 };
 
-template <int W, int RPL, bool PRE, bool REFLDS>
-__global__ __launch_bounds__(64 * W) void talco_nuc_kernel(KArgs a)
+template <int W, int RPL, bool PRE, bool REFLDS, int MINW = 1>
+__global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(KArgs a)
 {
     using C = Cfg<W, RPL, PRE, REFLDS>;
     constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;

@@ -34,7 +34,7 @@ static bool dbg_on() { static int v = -1; if (v < 0) v = getenv("TWL_DEBUG") ? 1
         }                                                                                                      \
     } while (0)
 
-// Fast path: 16 waves, one 64-row block per wave  -> 1024-row window (bands up to 961 wide), ref ring in LDS.
+// Fast path: 8 waves x 2 row blocks per lane     -> 1024-row window (bands up to 961 wide), ref ring in LDS, 2 workgroups/CU.
 // Wide path: 8 waves x 9 blocks                   -> 4608-row window (covers flen = 4096), ref columns from L2/HBM.
 using FastCfg = twl::Cfg<16, 1, true, true>;
 using WideCfg = twl::Cfg<8, 9, false, false>;
@@ -92,10 +92,17 @@ int check_params(const twl_params *p)
 template <class CfgT>
 size_t tb_words_for(int marker) { return ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW; }
 
-template <int W, int RPL, bool PRE, bool REFLDS>
-int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int blocks_per_cu, int *grid_out)
+template <int W, int RPL, bool PRE, bool REFLDS, int MINW = 1>
+int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int blocks_per_cu, int *grid_out,
+              int *window_out = nullptr)
 {
     using CfgT = twl::Cfg<W, RPL, PRE, REFLDS>;
+    if (blocks_per_cu <= 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, PRE, REFLDS, MINW>), CfgT::THREADS, 0));
+        blocks_per_cu = std::max(1, nb);
+    }
+    if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
     if (grid < 1) grid = 1;
     const size_t tbw = tb_words_for<CfgT>(base.marker);
@@ -114,7 +121,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         a.hb = hb;
     }
     TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
-    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, PRE, REFLDS>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, PRE, REFLDS, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
         for (int t = 0; t < 200; ++t) {
@@ -196,17 +203,30 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     for (int l = 0; l < 5; ++l) for (int m = 0; m < 5; ++m) a.M[5 * l + m] = p->matrix[5 * l + m];
 
-    int grid = 0;
+    int grid = 0, window = 0;
     const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
-    if (!force_wide)
-        rc = launch_dp<16, 1, true, true>(d, st, a, (const int32_t *)d->items.p, n_pairs, d->fast_blocks_per_cu, &grid);
-    else
-        rc = launch_dp<8, 9, false, false>(d, st, a, (const int32_t *)d->items.p, n_pairs, d->wide_blocks_per_cu, &grid);
+    const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry
+    const std::string c = cfg ? cfg : "w8r2";
+    const int32_t *items = (const int32_t *)d->items.p;
+    if (force_wide) rc = launch_dp<8, 9, false, false>(d, st, a, items, n_pairs, d->wide_blocks_per_cu, &grid, &window);
+    else if (c == "w16") rc = launch_dp<16, 1, true, true>(d, st, a, items, n_pairs, d->fast_blocks_per_cu, &grid, &window);
+    else if (c == "w8") rc = launch_dp<8, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8m6") rc = launch_dp<8, 1, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8m8") rc = launch_dp<8, 1, true, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8np6") rc = launch_dp<8, 1, false, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8np8") rc = launch_dp<8, 1, false, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2") rc = launch_dp<8, 2, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2m6") rc = launch_dp<8, 2, false, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2pre") rc = launch_dp<8, 2, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w4r4") rc = launch_dp<4, 4, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w16m8") rc = launch_dp<16, 1, true, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w16np8") rc = launch_dp<16, 1, false, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(d->ev[2], st));
     d->stats.n_launches = 1;
     d->stats.grid = grid;
-    d->stats.window = force_wide ? WideCfg::WINDOW : FastCfg::WINDOW;
+    d->stats.window = window;
 
     // pairs whose band outgrew the fast window are re-run (bit-identically) by the wide kernel
     std::vector<int16_t> h_err((size_t)n_pairs);
