@@ -28,6 +28,18 @@ from twilight_amd import synth  # noqa: E402
 
 B_CELL_NUC = 64          # algorithmic operand bytes per band cell, P=6: 2*P*4 + 4*4
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "w8r2_pmc_summary.json")
+
+
+def measured_traffic_per_launch(cells_per_launch):
+    """HBM bytes per DP-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, per the
+    gfx950 correction in MI355X_MICROARCH.md), scaled by band cells to this launch size.  None if no profile is committed."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            h = json.load(f)["hbm_per_launch"]
+        return h["traffic_bytes_per_cell"] * cells_per_launch
+    except Exception:
+        return None
 
 
 def parse():
@@ -167,7 +179,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic_per_launch(cells // max(1, launches)),
+                "traffic_source": "profiles/r01/w8r2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per band cell x cells per launch)",
                 "kernel": "twl::talco_nuc_kernel", "kernel_ms_per_launch": kernel_ms / max(1, launches),
                 "algorithmic_bytes_per_cell": B_CELL_NUC, "cells_per_launch": cells // max(1, launches),
                 "note": "achieved = band cells x 64 B / DP-kernel time (HIP events on the library stream); the path is "
