@@ -144,13 +144,9 @@ def main():
     dt = time.perf_counter() - t0
 
     n_bad = int((err != 0).sum().item())
-    t_dt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    t_cells = torch.tensor([float(cells)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_dt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_cells, op=dist.ReduceOp.SUM)
-    dt_max = float(t_dt.item())
-    cells_all = float(t_cells.item())
+    from twilight_amd.dist import reduce_report
+
+    cells_all, dt_max = reduce_report(cells, dt, device=dev)      # SUM of cells, MAX of seconds over ranks
 
     if rank == 0:
         value = cells_all / dt_max
