@@ -1,0 +1,119 @@
+// oracle/e2e_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// End-to-end CPU checker: the host mirror (twilight_amd/csrc/host, tree -> levels -> profiles -> write-back) with the
+// level kernel cpu::alignmentKernel_CPU restated from /root/reference/src/alignment-cpu.cpp:32-183 on top of the oracle
+// DP (talco_oracle.c).  Its purpose is to pin the oracle against the only outputs of the reference that are on record
+// (BASELINE.md section 2): the final MSAs of dataset/sars_20 and dataset/RNASim (dimensions, md5, band-cell totals,
+// pairs per level).  Usage:
+//   e2e_oracle -t tree.nwk -i seqs.fa -o out.aln [-v] [--threads N]     prints "E2E levels=... pairs_per_level=... band_cells=... aln_len=..."
+#include "../twilight_amd/csrc/host/twl_host.hpp"
+#include "talco_oracle.h"
+
+#include <omp.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+
+namespace {
+
+std::atomic<uint64_t> g_cells{0}, g_diags{0};
+std::atomic<int> g_maxw{0};
+std::vector<size_t> g_pairsPerLevel;
+std::vector<uint64_t> g_cellsPerLevel;
+
+// alignment-cpu.cpp:36-183
+void alignmentKernel_CPU(msa::Tree *, msa::NodePairVec &nodes, msa::SequenceDB *database, msa::Option *option, msa::Params &param)
+{
+    using namespace msa;
+    const int P = param.matrixSize + 1;
+    const int n = (int)nodes.size();
+    std::vector<float> matrix((size_t)param.matrixSize * param.matrixSize);
+    for (int l = 0; l < param.matrixSize; ++l)
+        for (int m = 0; m < param.matrixSize; ++m) matrix[(size_t)l * param.matrixSize + m] = param.scoringMatrix[l][m];
+    std::vector<int> fallbackPairs;
+    std::mutex fallbackMutex;
+    uint64_t levelCells = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : levelCells)
+    for (int i = 0; i < n; ++i) {
+        progressive::PairInputs in;
+        progressive::preparePair(nodes[i], database, option, param, in);
+        twlo_params tp;                                   // Talco_xdrop::Params(param), TALCO-XDrop.cpp:36-53
+        tp.P = P;
+        tp.matrix = matrix.data();
+        tp.gap_open = param.gapOpen;
+        tp.gap_extend = param.gapExtend;
+        tp.gap_char = param.gapExtend;
+        tp.xdrop = static_cast<int32_t>(1000 * -1 * param.gapExtend);
+        tp.flen = 1 << 12;
+        tp.marker = 1 << 10;
+        if (database->currentTask == 1 || database->currentTask == 2 || in.refNum > 10000 || in.qryNum > 10000) tp.gap_char = 0;   // :88
+        alnPath aln_wo_gc;
+        if (in.refLen == 0) aln_wo_gc.assign(in.qryLen, 1);
+        if (in.qryLen == 0) aln_wo_gc.insert(aln_wo_gc.end(), in.refLen, 2);
+        bool deferred = false;
+        if (!in.lowQ_r && !in.lowQ_q) {
+            const float *fr = in.freq.data(), *fq = in.freq.data() + (size_t)P * in.memLen;
+            std::vector<int8_t> buf((size_t)in.lens.first + in.lens.second + 2);
+            while (aln_wo_gc.empty()) {                   // :95-130
+                int16_t errorType = 0;
+                int32_t len = 0;
+                twlo_stats st;
+                memset(&st, 0, sizeof st);
+                twlo_align_pair(&tp, fr, in.lens.first, fq, in.lens.second, in.gapOp.data(), in.gapEx.data(), in.gapOp.data() + in.memLen,
+                                in.gapEx.data() + in.memLen, (float)in.refNum, (float)in.qryNum, buf.data(), &len, &errorType, &st, nullptr, nullptr);
+                levelCells += st.cells;
+                g_diags += st.diags;
+                int mw = g_maxw.load();
+                while (st.max_width > mw && !g_maxw.compare_exchange_weak(mw, st.max_width)) {}
+                if (errorType == 0) aln_wo_gc.assign(buf.begin(), buf.begin() + len);
+                if (database->currentTask == 0 && errorType != 0) {
+                    aln_wo_gc.clear();
+                    deferred = true;
+                    break;
+                }
+                if (errorType == 2) tp.flen = std::min(static_cast<int32_t>(tp.flen * 1.2) << 1, std::min(in.lens.first, in.lens.second));
+                else if (errorType == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
+                else if (errorType == 1) {
+                    tp.xdrop = static_cast<int32_t>(tp.xdrop * 2);
+                    tp.flen = std::min(static_cast<int32_t>(tp.xdrop * 4) << 1, std::min(in.lens.first, in.lens.second));
+                }
+            }
+        }
+        if (database->currentTask == 0 && (in.refNum == 1 || in.qryNum == 1) && (in.lowQ_r || in.lowQ_q)) deferred = true;   // :136-144
+        progressive::finishPair(nodes[i], database, option, param, in, aln_wo_gc);
+        if (deferred) { std::lock_guard<std::mutex> lk(fallbackMutex); fallbackPairs.push_back(i); }
+    }
+    g_cells += levelCells;
+    g_pairsPerLevel.push_back(nodes.size());
+    g_cellsPerLevel.push_back(levelCells);
+    if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    msa::Option option;
+    std::vector<char *> rest;
+    int threads = 0;
+    for (int i = 0; i < argc; ++i) {
+        if (!strcmp(argv[i], "--threads") && i + 1 < argc) { threads = atoi(argv[++i]); continue; }
+        rest.push_back(argv[i]);
+    }
+    if (threads > 0) omp_set_num_threads(threads);
+    if (!msa::parseCommandLine((int)rest.size(), rest.data(), option)) {
+        std::cerr << "usage: e2e_oracle -t tree.nwk -i seqs.fa -o out.aln [-v] [--threads N]\n";
+        return 1;
+    }
+    auto t0 = std::chrono::high_resolution_clock::now();
+    const int alnLen = msa::runDefaultAlignment(option, alignmentKernel_CPU, alignmentKernel_CPU);
+    const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    std::cout << "E2E levels=" << g_pairsPerLevel.size() << " pairs_per_level=";
+    for (size_t i = 0; i < g_pairsPerLevel.size(); ++i) std::cout << (i ? "/" : "") << g_pairsPerLevel[i];
+    std::cout << " band_cells=" << g_cells.load() << " diags=" << g_diags.load() << " max_width=" << g_maxw.load() << " aln_len=" << alnLen
+              << " seconds=" << secs << "\n";
+    return 0;
+}

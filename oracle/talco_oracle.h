@@ -12,13 +12,12 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product path (twilight_amd/) never links it.
  *
- * PARITY STATUS: the reference cannot be compiled in this image (msa.hpp needs
- * Boost.ProgramOptions and TBB headers, neither installed; no stand-ins are
- * written).  The oracle is pinned end-to-end: oracle/e2e_oracle (host mirror +
- * this DP) must reproduce the reference's recorded outputs for its own sample
- * data (sars_20 -> 20x29705, md5 53ccbd43...; RNASim ->
- * 579x3988, md5 d6a19d18...; band-cell totals).  See tests/test_e2e_pin.py.
- * Until that test is green this oracle is "parity unpinned".
+ * PARITY STATUS: PINNED end to end.  The reference cannot be compiled in this image (msa.hpp needs
+ * Boost.ProgramOptions and TBB headers, neither installed; no stand-ins are written) and ships no tests, so the
+ * oracle is pinned against the only outputs of the reference on record, using the reference's
+ * own sample data: oracle/e2e_oracle (host mirror + this DP) reproduces dataset/sars_20 -> 20x29705, md5 53ccbd43...,
+ * 468765465 band cells, levels 8/4/4/2/1, and dataset/RNASim -> 579x3988, md5 d6a19d18..., 855516114 band cells,
+ * 22 levels with the recorded pair counts, max band 685 (tests/test_e2e_pin.py, tests/golden/e2e_expected.json).
  */
 #ifndef TWL_TALCO_ORACLE_H
 #define TWL_TALCO_ORACLE_H

@@ -1,0 +1,75 @@
+// twilight_amd/csrc/host/driver.cpp -- DEFAULT_ALN flow of /root/reference/src/twilight-main.cpp:115-176 for the
+// single-partition case (no -m), plus the handful of CLI flags the hot path needs (names as in twilight-main.cpp:13-84).
+#include "twl_host.hpp"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+namespace msa {
+
+static bool flag(const char *a, const char *s, const char *l) { return (s && !strcmp(a, s)) || (l && !strcmp(a, l)); }
+
+bool parseCommandLine(int argc, char **argv, Option &o)
+{
+    bool typeGiven = false;
+    for (int i = 1; i < argc; ++i) {
+        const char *a = argv[i];
+        auto val = [&]() -> const char * { if (i + 1 >= argc) { std::cerr << "ERROR: missing value for " << a << '\n'; exit(1); } return argv[++i]; };
+        if (flag(a, "-t", "--tree")) o.treeFile = val();
+        else if (flag(a, "-i", "--sequences")) o.seqFile = val();
+        else if (flag(a, "-o", "--output")) o.outFile = val();
+        else if (flag(a, "-r", "--remove-gappy")) o.gappyVertical = (float)atof(val());
+        else if (flag(a, "-C", "--cpu")) o.cpuNum = atoi(val());
+        else if (flag(a, "-G", "--gpu")) o.gpuNum = atoi(val());
+        else if (flag(a, nullptr, "--gpu-index")) { o.gpuIdx.clear(); for (char *tok = strtok(const_cast<char *>(val()), ","); tok; tok = strtok(nullptr, ",")) o.gpuIdx.push_back(atoi(tok)); }
+        else if (flag(a, nullptr, "--cpu-only")) o.cpuOnly = true;
+        else if (flag(a, nullptr, "--type")) { o.type = val()[0]; typeGiven = true; }
+        else if (flag(a, "-w", "--wildcard")) o.wildcard = true;
+        else if (flag(a, nullptr, "--rooted")) o.reroot = false;
+        else if (flag(a, nullptr, "--match")) o.match = (float)atof(val());
+        else if (flag(a, nullptr, "--mismatch")) o.mismatch = (float)atof(val());
+        else if (flag(a, nullptr, "--transition")) o.transition = (float)atof(val());
+        else if (flag(a, nullptr, "--gap-open")) o.gapOpen = (float)atof(val());
+        else if (flag(a, nullptr, "--gap-extend")) o.gapExtend = (float)atof(val());
+        else if (flag(a, nullptr, "--gap-ends")) { o.gapEnds = (float)atof(val()); o.hasGapEnds = true; }
+        else if (flag(a, nullptr, "--xdrop")) o.xdrop = (float)atof(val());
+        else if (flag(a, "-b", "--blosum")) o.blosum = atoi(val());
+        else if (flag(a, nullptr, "--length-deviation")) o.lenDev = (float)atof(val());
+        else if (flag(a, nullptr, "--max-ambig")) o.maxAmbig = (float)atof(val());
+        else if (flag(a, nullptr, "--max-len")) o.maxLen = atoi(val());
+        else if (flag(a, nullptr, "--min-len")) o.minLen = atoi(val());
+        else if (flag(a, nullptr, "--filter")) o.noFilter = false;
+        else if (flag(a, nullptr, "--check")) o.debug = true;
+        else if (flag(a, "-v", "--verbose")) o.printDetail = true;
+        else if (flag(a, nullptr, "--overwrite")) {}
+        else if (flag(a, "-h", "--help")) return false;
+        else { std::cerr << "ERROR: unsupported option " << a << " (this build covers the tree+sequences alignment mode only)\n"; exit(1); }
+    }
+    if (o.treeFile.empty() || o.seqFile.empty() || o.outFile.empty()) return false;
+    if (o.gappyVertical > 1 || o.gappyVertical <= 0) { std::cerr << "ERROR: Invalid value for --remove-gappy. The value of --remove-gappy should be in (0,1]\n"; exit(1); }
+    if (o.gpuIdx.empty() && o.gpuNum > 0) for (int g = 0; g < o.gpuNum; ++g) o.gpuIdx.push_back(g);
+    if (!typeGiven) o.type = io::detectType(o.seqFile);
+    return true;
+}
+
+int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput)
+{
+    SequenceDB database;
+    Params param(option, option.type);
+    Tree *T = new Tree(option.treeFile);                                    // twilight-main.cpp:122
+    phylogeny::assignSinglePartition(T->root);                              // :129-130 with maxSubtree = INT32_MAX
+    Tree *subT = new Tree(T->root, option.reroot);                          // :145
+    io::readSequences(option.seqFile, &database, &option, subT);           // :146
+    progressive::msaOnSubtree(subT, &database, &option, param, kernel, deferredKernel);   // :148
+    if (option.debug && !database.debug()) std::cerr << "WARNING: --check found an illegal alignment row.\n";
+    const int alnLen = subT->root->getAlnLen(database.currentTask);
+    if (writeOutput) io::writeFinalMSA(&database, &option, alnLen);        // :165
+    delete subT;
+    delete T;
+    return alnLen;
+}
+
+}  // namespace msa

@@ -1,0 +1,204 @@
+// twilight_amd/csrc/host/progressive.cpp -- level schedule and the caller of the level kernel.
+// Behavioural mirror of /root/reference/src/progressive.cpp:10-299 (modes 0 and 1; DEFAULT_ALN).
+#include "twl_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <iostream>
+
+namespace msa {
+namespace progressive {
+
+// progressive.cpp:10-107.  mode 0: siblings are paired left to right, a pair's level is one more than the later of
+// its two members' previous levels; mode 1: every node is paired with its parent (deferred pass).
+void getProgressivePairs(std::vector<std::pair<NodePair, int>> &alnOrder, std::stack<Node *> postStack, int grpID, int mode)
+{
+    std::map<std::string, int> levelOf;
+    auto nextLevel = [&](const std::string &id) { auto it = levelOf.find(id); return it == levelOf.end() ? 0 : it->second + 1; };
+    if (mode == 0) {
+        for (; !postStack.empty(); postStack.pop()) {
+            Node *node = postStack.top();
+            if (!(node->grpID == -1 || node->grpID == grpID) || node->is_leaf()) continue;
+            std::vector<Node *> children;
+            for (Node *c : node->children)
+                if (c->grpID == grpID) children.push_back(c);
+            if (children.empty() && node->seqsIncluded.empty()) {          // useless node: drop it from the subtree
+                node->grpID = -2;
+                auto &sib = node->parent->children;
+                for (auto it = sib.begin(); it != sib.end(); ++it)
+                    if ((*it)->identifier == node->identifier) { sib.erase(it); break; }
+                continue;
+            }
+            if (children.size() == 1 && node->parent != nullptr && node->seqsIncluded.empty() && node->parent->grpID == grpID) {
+                for (auto &slot : node->parent->children)                  // unary node: splice its child into the parent
+                    if (slot->identifier == node->identifier) {
+                        slot = children[0];
+                        children[0]->branchLength += node->branchLength;
+                        children[0]->parent = node->parent;
+                        break;
+                    }
+                continue;
+            }
+            while (children.size() > 1) {
+                std::vector<Node *> left;
+                for (size_t i = 0; i + 1 < children.size(); i += 2) {
+                    const int lvl = std::max(nextLevel(children[i]->identifier), nextLevel(children[i + 1]->identifier));
+                    levelOf[children[i]->identifier] = lvl;
+                    levelOf[children[i + 1]->identifier] = lvl;
+                    alnOrder.push_back({{children[i], children[i + 1]}, lvl});
+                    left.push_back(children[i]);
+                }
+                if (children.size() % 2 == 1) left.push_back(children.back());
+                children = left;
+            }
+            if (children.size() == 1 && !node->seqsIncluded.empty()) {
+                const int lvl = std::max(nextLevel(node->identifier), nextLevel(node->children[0]->identifier));
+                levelOf[node->identifier] = lvl;
+                levelOf[node->children[0]->identifier] = lvl;
+                alnOrder.push_back({{node, node->children[0]}, lvl});
+            }
+            levelOf[node->identifier] = levelOf[children[0]->identifier];
+        }
+    } else if (mode == 1) {
+        for (; !postStack.empty(); postStack.pop()) {
+            Node *node = postStack.top();
+            if (node->parent == nullptr) continue;
+            const int lvl = std::max(nextLevel(node->identifier), nextLevel(node->parent->identifier));
+            levelOf[node->identifier] = lvl;
+            levelOf[node->parent->identifier] = lvl;
+            alnOrder.push_back({{node->parent, node}, lvl});
+        }
+    } else {
+        for (; !postStack.empty(); postStack.pop())
+            if (postStack.top()->parent != nullptr) alnOrder.push_back({{postStack.top()->parent, postStack.top()}, 0});
+    }
+}
+
+void scheduling(Node *root, std::vector<NodePairVec> &levels, int mode)       // progressive.cpp:109-124
+{
+    levels.clear();
+    std::stack<Node *> post;
+    root->collectPostOrder(post);
+    std::vector<std::pair<NodePair, int>> pairs;
+    getProgressivePairs(pairs, post, root->grpID, mode);
+    for (auto &h : pairs) {
+        if (levels.size() < (size_t)h.second + 1) levels.resize(h.second + 1);
+        levels[h.second].push_back(h.first);
+    }
+}
+
+// progressive.cpp:126-172: leaves take their sequence; an internal node adopts the result held by its already aligned child
+static void materialise(Node *n, Node *partner, SequenceDB *db)
+{
+    if (n->is_leaf() && n->seqsIncluded.empty()) {
+        auto *s = db->name_map[n->identifier];
+        n->seqsIncluded.push_back(s->id);
+        n->alnLen = s->len;
+        n->alnNum = 1;
+        n->alnWeight = s->weight;
+    } else if (n->seqsIncluded.empty()) {
+        const int grp = n->grpID;
+        for (Node *c : n->children) {
+            if ((c->grpID == -1 || c->grpID == grp) && c->identifier != partner->identifier) {
+                n->msaFreq = c->msaFreq;
+                c->msaFreq.clear();
+                n->seqsIncluded = c->seqsIncluded;
+                n->alnLen = c->alnLen;
+                n->alnNum = c->alnNum;
+                n->alnWeight = c->alnWeight;
+                break;
+            }
+        }
+    }
+}
+
+void updateNode(Tree *, NodePairVec &nodes, SequenceDB *database)
+{
+    for (auto &n : nodes) {
+        materialise(n.first, n.second, database);
+        materialise(n.second, n.first, database);
+    }
+}
+
+void progressiveAlignment(Tree *T, SequenceDB *database, Option *option, std::vector<NodePairVec> &levels, Params &param, alnFunction kernel)
+{
+    int level = 0;
+    if (option->printDetail) std::cerr << "Total " << levels.size() << " levels.\n";
+    for (auto m : levels) {                     // serial over levels: tree dependency (progressive.cpp:177)
+        auto t0 = std::chrono::high_resolution_clock::now();
+        updateNode(T, m, database);
+        kernel(T, m, database, option, param);
+        auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        if (option->printDetail)
+            std::cerr << "Level " << level + 1 << ", aligned " << m.size() << (m.size() > 1 ? " pairs in " : " pair in ") << ms << " ms\n";
+        ++level;
+    }
+}
+
+// progressive.cpp:194-230: expand members that were compressed into a group path
+void updateAlignment(Node *node, SequenceDB *database)
+{
+    const int n = (int)database->sequences.size();
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int idx = 0; idx < n; ++idx) {
+        auto *s = database->sequences[idx];
+        if (s->subtreeIdx >= -1) continue;
+        const alnPath &aln = database->subtreeAln[s->subtreeIdx];
+        s->memCheck((int)aln.size());
+        const char *from = s->alnStorage[s->storage];
+        char *to = s->alnStorage[1 - s->storage];
+        int org = 0;
+        for (size_t k = 0; k < aln.size(); ++k) to[k] = (aln[k] == 0) ? from[org++] : '-';
+        s->len = (int)aln.size();
+        s->changeStorage();
+    }
+    std::vector<int> members;
+    for (int sIdx : node->seqsIncluded)
+        if (sIdx >= 0) members.push_back(sIdx);
+    for (auto *s : database->sequences)
+        if (s->subtreeIdx < 0) members.push_back(s->id);
+    node->seqsIncluded = members;
+}
+
+// progressive.cpp:232-299
+void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, alnFunction kernel, alnFunction deferredKernel)
+{
+    auto t0 = std::chrono::high_resolution_clock::now();
+    std::cerr << "============================\n";
+    std::vector<NodePairVec> levels;
+    scheduling(T->root, levels, database->currentTask == 0 ? 0 : 1);
+    progressiveAlignment(T, database, option, levels, param, kernel);
+    if (database->currentTask == 0) {                       // push the result to the root
+        Node *last = levels.back()[0].first;
+        T->root->seqsIncluded = last->seqsIncluded;
+        if (!last->msaFreq.empty()) T->root->msaFreq = last->msaFreq;
+        T->root->alnLen = last->alnLen;
+        T->root->alnNum = last->alnNum;
+        T->root->alnWeight = last->alnWeight;
+        last->seqsIncluded.clear();
+        last->msaFreq.clear();
+    }
+    if (database->fallback_nodes.empty()) updateAlignment(T->root, database);
+    auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    std::cerr << "Alignment (length: " << T->root->alnLen << ") completed in " << secs << " s\n";
+    if (database->fallback_nodes.empty()) return;
+
+    // second pass: deferred profiles/sequences are aligned to the root one per level (progressive.cpp:270-298)
+    database->currentTask = 1;
+    int deferredSeqs = 0;
+    levels.clear();
+    for (Node *bad : database->fallback_nodes) deferredSeqs += (int)bad->seqsIncluded.size();
+    std::sort(database->fallback_nodes.begin(), database->fallback_nodes.end(), [&](Node *&a, Node *&b) {
+        if (a->alnNum == b->alnNum) return a->getAlnLen(database->currentTask) > b->getAlnLen(database->currentTask);
+        return a->alnNum > b->alnNum;
+    });
+    for (Node *bad : database->fallback_nodes) levels.push_back(NodePairVec(1, {T->root, bad}));
+    std::cerr << "Realign profiles that have been deferred. Total profiles/sequences: " << database->fallback_nodes.size() << " / " << deferredSeqs << '\n';
+    database->fallback_nodes.clear();
+    progressiveAlignment(T, database, option, levels, param, deferredKernel);
+    updateAlignment(T->root, database);
+    database->currentTask = 0;
+}
+
+}  // namespace progressive
+}  // namespace msa

@@ -1,0 +1,229 @@
+// twilight_amd/csrc/host/twl_host.hpp -- host-side mirror of TWILIGHT's level-batch call surface.
+//
+// Same namespaces, type and function names, argument meaning and error behaviour as the reference
+// (/root/reference/src/msa.hpp, phylogeny.hpp) for the DEFAULT_ALN path, so that the level kernel
+// msa::progressive::gpu::alignmentKernel_GPU (align_gpu.cpp, calls the C ABI of include/twl_align.h)
+// is injected exactly where the reference injects cpu::alignmentKernel_CPU (twilight-main.cpp:148).
+// No Boost, no TBB: options are a plain struct, parallel loops are OpenMP.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <stack>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+namespace phylogeny {
+
+using Profile = std::vector<std::vector<float>>;
+
+// reference phylogeny.hpp:16-53
+struct Node {
+    Node(const std::string &id, float len);
+    Node(const std::string &id, Node *par, float len);
+    bool is_leaf() const { return identifier.compare(0, 4, "node") != 0; }
+    void collectPostOrder(std::stack<Node *> &postStack);
+
+    std::string identifier;
+    Node *parent = nullptr;
+    float branchLength = 0;
+    size_t level = 1;
+    std::vector<Node *> children;
+    size_t numLeaves = 0;
+    float weight = 0;
+    bool placed = false;
+    int grpID = -1;
+
+    std::vector<int> seqsIncluded;
+    Profile msaFreq;
+    int alnLen = 0;
+    int alnNum = 0;
+    float alnWeight = 0;
+    int getAlnNum(int) const { return alnNum; }
+    int getAlnLen(int) const { return alnLen; }
+};
+
+// reference phylogeny.hpp:73-107 (the members the DEFAULT_ALN path touches)
+struct Tree {
+    size_t m_currInternalNode = 0;
+    size_t m_maxDepth = 0;
+    size_t m_numLeaves = 0;
+    float m_meanDepth = 0;
+    Node *root = nullptr;
+    std::unordered_map<std::string, Node *> allNodes;   // iteration order is observable (reroot start leaf, tree.cpp:601-605)
+
+    std::string newInternalNodeId() { return "node_" + std::to_string(++m_currInternalNode); }
+    void calLeafNum();
+    void calSeqWeight();
+    void parseNewick(std::string &newick);
+    void reroot();
+    void convert2binaryTree();
+    Tree *prune(std::unordered_set<std::string> &seqs);
+
+    Tree() = default;
+    explicit Tree(const std::string &newickFileName);
+    Tree(Node *node, bool reroot);          // copy of the nodes that share node->grpID
+    ~Tree();
+};
+
+void pruneTree(Tree *&T, std::unordered_set<std::string> &seqs);
+void updateLevels(Node *node, size_t currentLevel);
+// single-partition form of PartitionInfo::partitionTree (partitionInfo.cpp:75-85): every node joins group 0
+void assignSinglePartition(Node *root);
+
+}  // namespace phylogeny
+
+char checkOnly(char c);
+int letterIdx(char type, char c);
+
+namespace msa {
+
+enum Type { DEFAULT_ALN = 0, MERGE_MSA = 1, PLACE_WO_TREE = 2, PLACE_W_TREE = 3 };
+
+using Node = phylogeny::Node;
+using Tree = phylogeny::Tree;
+using NodePair = std::pair<Node *, Node *>;
+using NodePairVec = std::vector<NodePair>;
+using stringPair = std::pair<std::string, std::string>;
+using IntPair = std::pair<int, int>;
+using IntPairVec = std::vector<IntPair>;
+using FloatPair = std::pair<float, float>;
+using alnPath = std::vector<int8_t>;
+using Profile = std::vector<std::vector<float>>;
+
+// reference msa.hpp:55-96; values are the CLI defaults of twilight-main.cpp:13-84
+struct Option {
+    int alnMode = DEFAULT_ALN;
+    int gpuNum = 0;
+    int cpuNum = 1;
+    std::vector<int> gpuIdx;
+    bool cpuOnly = false;
+    int maxSubtree = INT32_MAX;
+    float gappyVertical = 0.95f;
+    float lenDev = 0;
+    float maxAmbig = 0.1f;
+    int maxLen = INT32_MAX;
+    int minLen = 0;
+    bool writeFiltered = false;
+    bool debug = false;          // --check
+    bool noFilter = true;        // !--filter
+    bool reroot = true;          // !--rooted
+    bool compressed = false;
+    char type = 'n';
+    bool alignGappy = true;
+    std::string treeFile, seqFile, outFile;
+    bool printDetail = false;    // -v
+    // scoring flags (consumed by Params)
+    float match = 18, mismatch = -8, transition = -4, gapOpen = -50, gapExtend = -5, xdrop = 600;
+    bool hasGapEnds = false;
+    float gapEnds = 0;
+    bool wildcard = false;
+    int blosum = 62;
+};
+
+// reference msa.hpp:98-109, ctor scoring-matrix.cpp:81-236 (built-in matrices only)
+struct Params {
+    float gapOpen, gapExtend, gapBoundary, xdrop, scaleFactor = 1;
+    float **scoringMatrix;
+    int matrixSize;
+    Params(const Option &opt, char type);
+    ~Params();
+    Params(const Params &) = delete;
+};
+
+// reference msa.hpp:111-155
+struct SequenceDB {
+    struct SequenceInfo {
+        int id;
+        std::string name;
+        std::string unalignedSeq;
+        int len;
+        bool lowQuality = false;
+        int subtreeIdx;
+        float weight;
+        bool storage = false;
+        int memLen = 0;
+        char *alnStorage[2] = {nullptr, nullptr};
+        static constexpr int timesBigger = 2;
+        void changeStorage() { storage = !storage; }
+        void memCheck(int len);
+        SequenceInfo(int id_, const std::string &name_, std::string &seq, int subtreeIdx_, float weight_, bool debug);
+        ~SequenceInfo();
+    };
+    int currentTask = 0;
+    std::vector<SequenceInfo *> sequences;
+    std::vector<Node *> fallback_nodes;
+    std::unordered_map<std::string, SequenceInfo *> name_map;
+    std::unordered_map<int, alnPath> subtreeAln;
+    void addSequence(int id, const std::string &name, std::string &seq, int subtreeIdx, float weight, bool debug);
+    bool debug();      // --check: true when every aligned row reproduces its input sequence and all rows are equally long
+    ~SequenceDB();
+};
+
+namespace io {
+void readSequences(const std::string &fileName, SequenceDB *database, Option *option, Tree *&T);
+void writeAlignment(const std::string &fileName, SequenceDB *database, int alnLen);
+void writeFinalMSA(SequenceDB *database, Option *option, int alnLen);
+char detectType(const std::string &seqFile);
+}  // namespace io
+
+using alnFunction = std::function<void(Tree *, NodePairVec &, SequenceDB *, Option *, Params &)>;
+
+namespace alignment_helper {
+constexpr int _CAL_PROFILE_TH = 1000;
+constexpr int _UPDATE_SEQ_TH = 1000;
+void calculateProfile(float *profile, NodePair &nodes, SequenceDB *database, Option *option, int32_t memLen);
+void removeGappyColumns(float *hostFreq, NodePair &nodes, Option *option, std::pair<IntPairVec, IntPairVec> &gappyColumns, int32_t memLen,
+                        IntPair &lens, int currentTask);
+void calculatePSGP(float *hostFreq, float *hostGapOp, float *hostGapEx, NodePair &nodes, SequenceDB *database, Option *option, int memLen,
+                   IntPair offset, IntPair lens, Params &param);
+void getConsensus(Option *option, float *profile, std::string &consensus, int len);
+void pairwiseGlobal(const std::string &seq1, const std::string &seq2, alnPath &path, Params &param);
+void addGappyColumnsBack(alnPath &aln_before, alnPath &aln_after, std::pair<IntPairVec, IntPairVec> &gappyColumns, Params &param,
+                         IntPair rgcLens, stringPair orgSeqs);
+void updateAlignment(NodePair &nodes, SequenceDB *database, Option *option, alnPath &aln);
+void updateFrequency(NodePair &nodes, SequenceDB *database, alnPath &aln, FloatPair weights);
+void fallback2cpu(std::vector<int> &fallbackPairs, NodePairVec &nodes, SequenceDB *database, Option *option);
+}  // namespace alignment_helper
+
+namespace progressive {
+void getProgressivePairs(std::vector<std::pair<NodePair, int>> &alnOrder, std::stack<Node *> postStack, int grpID, int mode);
+void scheduling(Node *root, std::vector<NodePairVec> &levels, int mode);
+void updateNode(Tree *tree, NodePairVec &nodes, SequenceDB *database);
+void progressiveAlignment(Tree *T, SequenceDB *database, Option *option, std::vector<NodePairVec> &levels, Params &param, alnFunction kernel);
+// `deferredKernel` aligns the deferred sequences against the root in the second pass; the reference hard-wires
+// cpu::alignmentKernel_CPU there (progressive.cpp:291).
+void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, alnFunction kernel, alnFunction deferredKernel);
+void updateAlignment(Node *node, SequenceDB *database);
+
+// What one pair needs before / after the DP (alignment-cpu.cpp:50-93 and :136-175), shared by every level kernel.
+struct PairInputs {
+    std::vector<float> freq, gapOp, gapEx;          // freq[2][memLen][P], gapOp/gapEx[2][memLen]
+    std::pair<IntPairVec, IntPairVec> gappyColumns;
+    stringPair consensus;
+    IntPair lens;                                    // after gappy-column removal
+    int32_t refLen, qryLen, refNum, qryNum, memLen;
+    bool lowQ_r, lowQ_q;
+};
+void preparePair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in);
+// Returns false when the pair must be deferred (fallbackPairs), true when it was written back.
+bool finishPair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in, alnPath &aln_wo_gc);
+
+namespace gpu {
+void alignmentKernel_GPU(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
+struct LevelTotals { uint64_t band_cells = 0, pairs = 0; double kernel_ms = 0, total_ms = 0; };
+extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
+}
+
+}  // namespace progressive
+
+// DEFAULT_ALN driver shared by the product CLI and the oracle's end-to-end checker (twilight-main.cpp:121-176,
+// single partition): tree -> partition -> reroot -> read sequences -> msaOnSubtree -> write MSA.  Returns the MSA length.
+int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput = true);
+bool parseCommandLine(int argc, char **argv, Option &option);
+
+}  // namespace msa
