@@ -55,12 +55,24 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cpus():
+    """CPUs this process may really use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(batch, pool_idx, gpu_paths, gpu_lens):
     """Oracle ("port" of the reference CPU path) timed on the host cores of this box, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     threads = min(cores, len(pool_idx))
     sub = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq[pool_idx], gap_open=batch.gap_open[pool_idx],
                            gap_extend=batch.gap_extend[pool_idx], len=batch.len[pool_idx], num=batch.num[pool_idx])
@@ -184,7 +196,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            k = args.cpu_sample or min(pool_n, max(8, min(os.cpu_count() or 8, 64)))
+            k = args.cpu_sample or min(pool_n, max(8, min(2 * effective_cpus(), 64)))
             pool_idx = np.arange(k)
             gpu_paths = aln[:k].cpu().numpy()
             gpu_lens = alen[:k].cpu().numpy()

@@ -7,14 +7,33 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <thread>
+
+#include <omp.h>
 
 namespace msa {
+
+// CPUs this process may really use: the cgroup quota (cpu.max) can be far below what the OS reports
+static int effectiveCpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string quota;
+    long period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0) {
+        long q = atol(quota.c_str());
+        if (q > 0) n = std::min<long>(n, std::max<long>(1, (q + period - 1) / period));
+    }
+    return n;
+}
 
 static bool flag(const char *a, const char *s, const char *l) { return (s && !strcmp(a, s)) || (l && !strcmp(a, l)); }
 
 bool parseCommandLine(int argc, char **argv, Option &o)
 {
     bool typeGiven = false;
+    o.cpuNum = 0;
     for (int i = 1; i < argc; ++i) {
         const char *a = argv[i];
         auto val = [&]() -> const char * { if (i + 1 >= argc) { std::cerr << "ERROR: missing value for " << a << '\n'; exit(1); } return argv[++i]; };
@@ -52,6 +71,9 @@ bool parseCommandLine(int argc, char **argv, Option &o)
     if (o.gappyVertical > 1 || o.gappyVertical <= 0) { std::cerr << "ERROR: Invalid value for --remove-gappy. The value of --remove-gappy should be in (0,1]\n"; exit(1); }
     if (o.gpuIdx.empty() && o.gpuNum > 0) for (int g = 0; g < o.gpuNum; ++g) o.gpuIdx.push_back(g);
     if (!typeGiven) o.type = io::detectType(o.seqFile);
+    const int maxCpu = effectiveCpus();
+    if (o.cpuNum <= 0 || o.cpuNum > maxCpu) o.cpuNum = maxCpu;       // -C/--cpu, default: all usable cores (option.cpp:41-46)
+    omp_set_num_threads(o.cpuNum);
     return true;
 }
 
