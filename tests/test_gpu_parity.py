@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 M = synth.nucleotide_matrix()
 
 
-def _compare(twl, batch, **pk):
-    p = twl.make_params(M, **pk)
+def _compare(twl, batch, matrix=None, **pk):
+    mat = M if matrix is None else matrix
+    p = twl.make_params(mat, **pk)
     aln, n, err = twl.align_batch(p, batch)
-    oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), batch, threads=8)
+    oa, on, oerr, ost = O.align_batch(O.make_params(mat, **pk), batch, threads=8)
     assert np.array_equal(err, oerr), f"errorType differs: gpu {err.tolist()} oracle {oerr.tolist()}"
     assert np.array_equal(n, on), f"path length differs: gpu {n.tolist()} oracle {on.tolist()}"
     for i in range(batch.n_pairs):
@@ -91,3 +92,24 @@ def test_length_mismatch_pairs(gpu):
     b = synth.make_level_batch(6, 700, members=(1, 1), seed=31)
     b.len[:, 1] = (b.len[:, 1] * np.array([0.3, 0.5, 0.7, 0.9, 0.2, 1.0])).astype(np.int32).clip(1)
     _compare(gpu, b, marker=64)
+
+
+# ---- protein: P = 22, 5 x BLOSUM62 (BASELINE config 5) ----
+MP = synth.protein_matrix()
+
+
+@pytest.mark.parametrize("members", [(1, 1), ((2, 5), (1, 4))])
+def test_protein_small(gpu, members):
+    batch = synth.make_level_batch(8, 400, P=synth.PROT_P, members=members, seed=17, sub=0.15)
+    _compare(gpu, batch, matrix=MP)
+
+
+def test_protein_multi_tile_and_wildcard(gpu):
+    batch = synth.make_level_batch(6, 700, P=synth.PROT_P, members=((1, 4), (1, 4)), seed=23, sub=0.12)
+    st, ost = _compare(gpu, batch, matrix=synth.protein_matrix(wildcard=True), marker=96)
+    assert ost.tiles > 3 * batch.n_pairs
+
+
+def test_protein_2k(gpu):
+    batch = synth.make_level_batch(6, 2000, P=synth.PROT_P, members=((1, 6), (1, 6)), seed=29, sub=0.2)
+    _compare(gpu, batch, matrix=MP)

@@ -32,7 +32,7 @@ constexpr int kMaxMarker = 1024;
 constexpr int kErrOverflow = -1;   // internal: band outgrew this kernel's row window -> relaunch wide
 
 struct KArgs {
-    const float *cols;        // packed columns [pair][2][seq_len][8]: f0..f5, gapOpen, gapExtend
+    const float *cols;        // packed columns [pair][2][seq_len][P+2]: f0..f(P-1), gapOpen, gapExtend (32 B for P=6, 96 B for P=22)
     const int32_t *len;       // [pair][2]
     const int32_t *num;       // [pair][2]
     int8_t *aln;              // [pair][2*seq_len]
@@ -50,7 +50,7 @@ struct KArgs {
     int32_t step_slack;       // watchdog: a pair may run at most 32*(R+Q) + step_slack diagonals in total
     float gap_open, gap_extend, gap_char;
     int32_t xdrop, flen, marker;
-    float M[25];              // scoreMatrix[l][m], 5x5
+    float M[441];             // scoreMatrix[l][m] row-major, (P-1)x(P-1): 5x5 or 21x21
 };
 
 __device__ __forceinline__ void heartbeat(const KArgs &a, int slot, int v)
@@ -94,21 +94,26 @@ __device__ __forceinline__ float key2f(int k)
     return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff));
 }
 
-template <int W, int RPL, bool PRE, bool REFLDS>
+template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true>
 struct Cfg {
+    static_assert(P == 6 || P == 22, "profile width");
+    static_assert(!(PRE && P != 6), "precomputed q*M rows exist for P=6 only");
+    static constexpr int CW = P + 2;            // floats per packed column
+    static constexpr int F4 = CW / 4;           // float4 per packed column
     static constexpr int NV = W * RPL;          // virtual waves = 64-row blocks resident at once
     static constexpr int WINDOW = 64 * NV;      // rows
     static constexpr int NB = NV + 2;           // ring blocks
     static constexpr int CAP = 64 * NB;         // ring columns
-    static constexpr int RING_F4 = REFLDS ? CAP * 2 : 2;
+    static constexpr int RING_F4 = REFLDS ? CAP * F4 : F4;
     static constexpr int THREADS = 64 * W;
 };
 
-template <int W, int RPL, bool PRE, bool REFLDS, int MINW = 1>
-__global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(KArgs a)
+template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1>
+__global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
 {
-    using C = Cfg<W, RPL, PRE, REFLDS>;
-    constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
+    using C = Cfg<P, W, RPL, PRE, REFLDS, QREG>;
+    constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP, CW = C::CW, F4 = C::F4;
+    constexpr int MS = P - 1;                    // matrix side
 
     __shared__ float4 s_ring[C::RING_F4];
     __shared__ int4 s_exch[2][NV];
@@ -141,8 +146,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(KArgs a)
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
         const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
         const bool denomOne = (denom == 1.0f);
-        const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * 8);
-        const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * 8);
+        const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * CW);
+        const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * CW);
         int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
 
         // An empty side produces no path (the caller emits the all-gap path, alignment-cpu.cpp:89-90).
@@ -162,33 +167,46 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(KArgs a)
             // ---- per-slot (virtual wave) state ----
             float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
             int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
-            float qv[RPL][6], gopq[RPL], gexq[RPL];
+            float qv[RPL][QREG ? P : 1], gopq[RPL], gexq[RPL];
             float qM[RPL][PRE ? 25 : 1];
             int blk[RPL], uph[RPL];
             uint32_t tbacc[RPL];
             bool tbdirty[RPL], q5any[RPL];
 
+            auto load_col = [&](const float4 *base, size_t col, bool ok, float *dst /*[CW]*/) {
+#pragma unroll
+                for (int t = 0; t < F4; ++t) {
+                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) c = base[F4 * col + t];
+                    dst[4 * t] = c.x; dst[4 * t + 1] = c.y; dst[4 * t + 2] = c.z; dst[4 * t + 3] = c.w;
+                }
+            };
             auto load_q = [&](int r) {
+                if constexpr (!QREG) { q5any[r] = true; gopq[r] = gexq[r] = 0.f; return; }     // columns are re-read per cell
                 const int i = 64 * blk[r] + lane;
-                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-                if (qry_idx + i < Q) { c0 = colsQ[2 * (size_t)(qry_idx + i)]; c1 = colsQ[2 * (size_t)(qry_idx + i) + 1]; }
-                qv[r][0] = c0.x; qv[r][1] = c0.y; qv[r][2] = c0.z; qv[r][3] = c0.w; qv[r][4] = c1.x; qv[r][5] = c1.y;
-                gopq[r] = c1.z; gexq[r] = c1.w;
+                float cb[CW];
+                load_col(colsQ, (size_t)(qry_idx + i), qry_idx + i < Q, cb);
+#pragma unroll
+                for (int t = 0; t < P; ++t) qv[r][QREG ? t : 0] = cb[t];
+                gopq[r] = cb[P]; gexq[r] = cb[P + 1];
                 if constexpr (PRE) {
 #pragma unroll
                     for (int l = 0; l < 5; ++l)
 #pragma unroll
-                        for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = qv[r][m] * a.M[5 * l + m];   // first rounding of (q*M)*r, :386
+                        for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = cb[m] * a.M[5 * l + m];   // first rounding of (q*M)*r, :386
                 }
-                q5any[r] = __builtin_amdgcn_ballot_w64(qv[r][5] != 0.0f) != 0ull;
+                q5any[r] = __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
             };
             auto load_ring_block = [&](int B) {
                 if constexpr (REFLDS) {
                     const int col = 64 * B + lane;
-                    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-                    if (col < refLen) { c0 = colsR[2 * (size_t)(ref_idx + col)]; c1 = colsR[2 * (size_t)(ref_idx + col) + 1]; }
                     const int slot = (B % NB) * 64 + lane;
-                    s_ring[2 * slot] = c0; s_ring[2 * slot + 1] = c1;
+#pragma unroll
+                    for (int t = 0; t < F4; ++t) {
+                        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (col < refLen) c = colsR[F4 * (size_t)(ref_idx + col) + t];
+                        s_ring[F4 * slot + t] = c;
+                    }
                 }
             };
 
@@ -266,37 +284,58 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(KArgs a)
                         const int i = b + lane;
                         const int j = k - i;
                         const bool inband = (i >= Lk) && (i <= Uk);
-                        // reference column r[j]
-                        float4 ra, rb;
+                        // reference column r[j] (and, when it is not register-resident, the query column q[i])
+                        float rc[CW];
                         if constexpr (REFLDS) {
                             int rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
-                            ra = s_ring[2 * rs]; rb = s_ring[2 * rs + 1];
-                        } else {
-                            ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra;
-                            if (inband) { ra = colsR[2 * (size_t)(ref_idx + j)]; rb = colsR[2 * (size_t)(ref_idx + j) + 1]; }
-                        }
-                        const float rr[5] = {ra.x, ra.y, ra.z, ra.w, rb.x};
-                        const float r5 = rb.y, gopr = rb.z, gexr = rb.w;
-                        // column score, :378-395,444 (order: ((t0+t1)+t2)+t3)+t4 per l, accumulated over l)
-                        float numer = 0.0f;
 #pragma unroll
-                        for (int l = 0; l < 5; ++l) {
-                            float t[5];
-#pragma unroll
-                            for (int m = 0; m < 5; ++m) {
-                                if constexpr (PRE) t[m] = qM[r][5 * l + m] * rr[l];
-                                else t[m] = (qv[r][m] * a.M[5 * l + m]) * rr[l];
+                            for (int t = 0; t < F4; ++t) {
+                                const float4 c = s_ring[F4 * rs + t];
+                                rc[4 * t] = c.x; rc[4 * t + 1] = c.y; rc[4 * t + 2] = c.z; rc[4 * t + 3] = c.w;
                             }
-                            const float s = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
-                            numer = (l == 0) ? s : numer + s;
+                        } else {
+                            load_col(colsR, (size_t)(ref_idx + j), inband, rc);
+                        }
+                        float qcb[QREG ? 1 : CW];
+                        if constexpr (!QREG) { load_col(colsQ, (size_t)(qry_idx + i), inband, qcb); gopq[r] = qcb[P]; gexq[r] = qcb[P + 1]; }
+                        const float *q = QREG ? qv[r] : qcb;
+                        const float rg = rc[P - 1], gopr = rc[P], gexr = rc[P + 1];
+                        const bool rgAny = __builtin_amdgcn_ballot_w64(inband && rg != 0.0f) != 0ull;
+                        float numer = 0.0f;
+                        if constexpr (P == 6) {
+                            // column score, :378-395 (order: (((t0+t1)+t2)+t3)+t4 per l, accumulated over l)
+#pragma unroll
+                            for (int l = 0; l < 5; ++l) {
+                                float t[5];
+#pragma unroll
+                                for (int m = 0; m < 5; ++m) {
+                                    if constexpr (PRE) t[m] = qM[r][5 * l + m] * rc[l];
+                                    else t[m] = (q[m] * a.M[5 * l + m]) * rc[l];
+                                }
+                                const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+                                numer = (l == 0) ? sl : numer + sl;
+                            }
+                        } else {
+                            // protein column score, :409-430: per l the scalar tail m=16..20 first, then the two 8-lane
+                            // blocks v[t] = (q[t]*M[l][t])*r[l] + (q[8+t]*M[l][8+t])*r[l] summed left to right
+#pragma unroll
+                            for (int l = 0; l < 21; ++l) {
+                                const float rl = rc[l];
+#pragma unroll
+                                for (int m = 16; m < 21; ++m) numer += (rl * q[m]) * a.M[21 * l + m];
+                                float v[8];
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) v[t] = (q[t] * a.M[21 * l + t]) * rl + (q[8 + t] * a.M[21 * l + 8 + t]) * rl;
+                                numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
+                            }
                         }
                         if (q5any[r]) {
 #pragma unroll
-                            for (int l = 0; l < 5; ++l) numer += (rr[l] * qv[r][5]) * gc;       // :394
+                            for (int l = 0; l < MS; ++l) numer += (rc[l] * q[P - 1]) * gc;       // :394 / :432
                         }
-                        if (__builtin_amdgcn_ballot_w64(inband && r5 != 0.0f) != 0ull) {
+                        if (rgAny) {
 #pragma unroll
-                            for (int m = 0; m < 5; ++m) numer += (r5 * qv[r][m]) * gc;          // :395
+                            for (int m = 0; m < MS; ++m) numer += (rg * q[m]) * gc;              // :395 / :433
                         }
                         const float sim = denomOne ? numer : numer / denom;                     // :444
 
@@ -546,14 +585,21 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(KArgs a)
     }
 }
 
-// ---- column packing: freq[pair][2][seq_len][6] + gapOpen/gapExtend[pair][2][seq_len] -> cols[pair][2][seq_len][8] ----
-__global__ void pack_nuc_kernel(const float *__restrict__ freq, const float *__restrict__ gop, const float *__restrict__ gex,
-                                float4 *__restrict__ cols, size_t n_cols)
+// ---- column packing: freq[pair][2][seq_len][P] + gapOpen/gapExtend[pair][2][seq_len] -> cols[pair][2][seq_len][P+2] ----
+template <int P>
+__global__ void pack_kernel(const float *__restrict__ freq, const float *__restrict__ gop, const float *__restrict__ gex,
+                            float *__restrict__ cols, size_t n_cols)
 {
+    constexpr int CW = P + 2;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (size_t)gridDim.x * blockDim.x) {
-        const float *f = freq + c * 6;
-        cols[2 * c] = make_float4(f[0], f[1], f[2], f[3]);
-        cols[2 * c + 1] = make_float4(f[4], f[5], gop[c], gex[c]);
+        const float *f = freq + c * P;
+        float4 *dst = reinterpret_cast<float4 *>(cols + c * CW);
+        float v[CW];
+#pragma unroll
+        for (int t = 0; t < P; ++t) v[t] = f[t];
+        v[P] = gop[c]; v[P + 1] = gex[c];
+#pragma unroll
+        for (int t = 0; t < CW / 4; ++t) dst[t] = make_float4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
     }
 }
 

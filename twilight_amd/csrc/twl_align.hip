@@ -36,8 +36,7 @@ static bool dbg_on() { static int v = -1; if (v < 0) v = getenv("TWL_DEBUG") ? 1
 
 // Fast path: 8 waves x 2 row blocks per lane     -> 1024-row window (bands up to 961 wide), ref ring in LDS, 2 workgroups/CU.
 // Wide path: 8 waves x 9 blocks                   -> 4608-row window (covers flen = 4096), ref columns from L2/HBM.
-using FastCfg = twl::Cfg<16, 1, true, true>;
-using WideCfg = twl::Cfg<8, 9, false, false>;
+// Protein (P = 22): 8 waves x 1 block (512-row window, 96-byte columns in the LDS ring); wide path re-reads both columns per cell.
 
 struct Buf {
     void *p = nullptr;
@@ -82,7 +81,7 @@ int find_dev(int device, Device **out)
 int check_params(const twl_params *p)
 {
     if (!p) { g_err = "params is null"; return TWL_ERR_BAD_ARGUMENT; }
-    if (p->P != 6) { g_err = "only P=6 (nucleotide) profiles are implemented in this build"; return TWL_ERR_UNSUPPORTED; }
+    if (p->P != 6 && p->P != 22) { g_err = "profile width P must be 6 (nucleotide) or 22 (protein)"; return TWL_ERR_UNSUPPORTED; }
     if (p->marker < 2 || p->marker > TWL_MAX_MARKER) { g_err = "marker outside [2, TWL_MAX_MARKER]"; return TWL_ERR_UNSUPPORTED; }
     if (p->flen < 1 || p->flen > 4096) { g_err = "flen outside [1, 4096]"; return TWL_ERR_UNSUPPORTED; }
     if (p->xdrop < 0) { g_err = "xdrop < 0"; return TWL_ERR_BAD_ARGUMENT; }
@@ -92,15 +91,19 @@ int check_params(const twl_params *p)
 template <class CfgT>
 size_t tb_words_for(int marker) { return ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW; }
 
-template <int W, int RPL, bool PRE, bool REFLDS, int MINW = 1>
+template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1>
 int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int blocks_per_cu, int *grid_out,
               int *window_out = nullptr)
 {
-    using CfgT = twl::Cfg<W, RPL, PRE, REFLDS>;
+    using CfgT = twl::Cfg<P, W, RPL, PRE, REFLDS, QREG>;
     if (blocks_per_cu <= 0) {
-        int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, PRE, REFLDS, MINW>), CfgT::THREADS, 0));
-        blocks_per_cu = std::max(1, nb);
+        static int cached = 0;      // one value per template instantiation
+        if (cached == 0) {
+            int nb = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW>), CfgT::THREADS, 0));
+            cached = std::max(1, nb);
+        }
+        blocks_per_cu = cached;
     }
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
@@ -121,7 +124,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         a.hb = hb;
     }
     TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
-    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, PRE, REFLDS, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
         for (int t = 0; t < 200; ++t) {
@@ -150,7 +153,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 
     int rc;
     const size_t n_cols = (size_t)n_pairs * 2 * (size_t)seq_len;
-    if ((rc = d->cols.ensure(n_cols * 8 * sizeof(float)))) return rc;
+    const bool prot = (p->P == 22);
+    if ((rc = d->cols.ensure(n_cols * (size_t)(p->P + 2) * sizeof(float)))) return rc;
     if ((rc = d->cells.ensure((size_t)n_pairs * sizeof(unsigned long long)))) return rc;
     if ((rc = d->queue.ensure(64))) return rc;
     if ((rc = d->items.ensure((size_t)n_pairs * sizeof(int32_t)))) return rc;
@@ -177,8 +181,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     {
         const int threads = 256;
         const int blocks = (int)std::min<size_t>((n_cols + threads - 1) / threads, (size_t)d->num_cu * 8);
-        hipLaunchKernelGGL(twl::pack_nuc_kernel, dim3(std::max(blocks, 1)), dim3(threads), 0, st, d_freq, d_gop, d_gex,
-                           (float4 *)d->cols.p, n_cols);
+        if (prot) hipLaunchKernelGGL(twl::pack_kernel<22>, dim3(std::max(blocks, 1)), dim3(threads), 0, st, d_freq, d_gop, d_gex, (float *)d->cols.p, n_cols);
+        else hipLaunchKernelGGL(twl::pack_kernel<6>, dim3(std::max(blocks, 1)), dim3(threads), 0, st, d_freq, d_gop, d_gex, (float *)d->cols.p, n_cols);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(d->ev[1], st));
@@ -201,26 +205,23 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         HIP_TRY(hipMemsetAsync(d->dbg.p, 0xff, (size_t)n_pairs * 16 * sizeof(int32_t), st));
         a.dbg = (int32_t *)d->dbg.p;
     }
-    for (int l = 0; l < 5; ++l) for (int m = 0; m < 5; ++m) a.M[5 * l + m] = p->matrix[5 * l + m];
+    { const int ms = p->P - 1; for (int l = 0; l < ms; ++l) for (int m = 0; m < ms; ++m) a.M[ms * l + m] = p->matrix[ms * l + m]; }
 
     int grid = 0, window = 0;
     const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
-    const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry
+    const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "w8r2";
     const int32_t *items = (const int32_t *)d->items.p;
-    if (force_wide) rc = launch_dp<8, 9, false, false>(d, st, a, items, n_pairs, d->wide_blocks_per_cu, &grid, &window);
-    else if (c == "w16") rc = launch_dp<16, 1, true, true>(d, st, a, items, n_pairs, d->fast_blocks_per_cu, &grid, &window);
-    else if (c == "w8") rc = launch_dp<8, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8m6") rc = launch_dp<8, 1, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8m8") rc = launch_dp<8, 1, true, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8np6") rc = launch_dp<8, 1, false, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8np8") rc = launch_dp<8, 1, false, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8r2") rc = launch_dp<8, 2, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8r2m6") rc = launch_dp<8, 2, false, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8r2pre") rc = launch_dp<8, 2, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w4r4") rc = launch_dp<4, 4, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w16m8") rc = launch_dp<16, 1, true, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w16np8") rc = launch_dp<16, 1, false, true, 8>(d, st, a, items, n_pairs, 0, &grid, &window);
+    auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
+        return prot ? launch_dp<22, 8, 9, false, false, false>(d, st, a, it, n_it, 1, g, w)
+                    : launch_dp<6, 8, 9, false, false, true>(d, st, a, it, n_it, 1, g, w);
+    };
+    if (force_wide) rc = launch_wide(items, n_pairs, &grid, &window);
+    else if (prot) rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2") rc = launch_dp<6, 8, 2, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8") rc = launch_dp<6, 8, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w4r4") rc = launch_dp<6, 4, 4, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
     else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(d->ev[2], st));
@@ -244,7 +245,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
         int grid2 = 0;
-        rc = launch_dp<8, 9, false, false>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), d->wide_blocks_per_cu, &grid2);
+        int w2 = 0;
+        rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(d->ev[4], st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -305,11 +307,6 @@ int twl_init(const int *device_ids, int n_devices)
         d->num_cu = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         for (auto &e : d->ev) HIP_TRY(hipEventCreate(&e));
-        int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<16, 1, true, true>), FastCfg::THREADS, 0));
-        d->fast_blocks_per_cu = std::max(1, nb);
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<8, 9, false, false>), WideCfg::THREADS, 0));
-        d->wide_blocks_per_cu = std::max(1, std::min(nb, 1));
         g_devs.push_back(d);
     }
     g_init = true;
