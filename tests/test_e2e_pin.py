@@ -64,3 +64,26 @@ def test_product_cli_reproduces_reference_msa_on_gpu(built, tmp_path, name):
     tail = [l for l in r.stderr.splitlines() if "band cells" in l][-1]
     cells = int(tail.split(" band cells")[0].split()[-1])
     assert cells == e["band_cells"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,length", [("n", 40, 1200), ("p", 24, 500)])
+@pytest.mark.timeout(900)
+def test_product_equals_oracle_on_synthetic_family(built, tmp_path, kind, n, length):
+    """No reference output is on record for proteins: here the product CLI (GPU) must equal the CPU checker end to end."""
+    from twilight_amd import synth
+
+    nwk, seqs = synth.make_family(n, length, P=(6 if kind == "n" else 22), seed=5 + n)
+    (tmp_path / "t.nwk").write_text(nwk + "\n")
+    (tmp_path / "s.fa").write_text("".join(f">{name}\n{seq}\n" for name, seq in seqs))
+    outs = {}
+    for tag, exe in (("oracle", os.path.join(ROOT, "oracle", "e2e_oracle")), ("gpu", os.path.join(ROOT, "twilight_amd", "twilight-mi355x"))):
+        out = tmp_path / f"{tag}.aln"
+        r = subprocess.run([exe, "-t", str(tmp_path / "t.nwk"), "-i", str(tmp_path / "s.fa"), "-o", str(out), "--type", kind, "--check"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "illegal alignment" not in r.stderr
+        outs[tag] = out
+    assert _md5(outs["gpu"]) == _md5(outs["oracle"])
+    names, rows = _rows(outs["gpu"])
+    assert len(names) == n and len(set(len(x) for x in rows)) == 1

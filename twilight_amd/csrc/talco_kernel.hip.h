@@ -53,10 +53,24 @@ struct KArgs {
     float M[441];             // scoreMatrix[l][m] row-major, (P-1)x(P-1): 5x5 or 21x21
 };
 
+#ifdef TWL_KERNEL_DEBUG
 __device__ __forceinline__ void heartbeat(const KArgs &a, int slot, int v)
 {
     if (a.hb && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&a.hb[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#else
+__device__ __forceinline__ void heartbeat(const KArgs &, int, int) {}
+#endif
+
+// Single-lane LDS atomics issued directly: hipcc otherwise wraps every LDS atomic in its wave-reduction prologue
+// (v_mbcnt/readfirstlane) even when the call site is already restricted to one lane.
+__device__ __forceinline__ unsigned lds_off(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void lds_max_i32(int *p, int v) { asm volatile("ds_max_i32 %0, %1" ::"v"(lds_off(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_min_i32(int *p, int v) { asm volatile("ds_min_i32 %0, %1" ::"v"(lds_off(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_or_b32(int *p, int v) { asm volatile("ds_or_b32 %0, %1" ::"v"(lds_off(p)), "v"(v) : "memory"); }
 
 __device__ __forceinline__ float dpp_shr1_f(float from_prev_wave, float src)
 {
@@ -134,6 +148,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
     const int marker = a.marker;
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
+    // Default nucleotide matrix: the N row and column are all zero (scoring-matrix.cpp:104).  Their 9 products are +-0
+    // and adding +-0 never changes a non-zero partial sum, so they are skipped (can only flip the sign of a zero).
+    bool nZero = (P == 6);
+    if constexpr (P == 6) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) nZero = nZero && (a.M[20 + t] == 0.0f) && (a.M[5 * t + 4] == 0.0f);
+    }
 
     heartbeat(a, 0, 1);
     for (;;) {
@@ -158,7 +179,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         int ref_idx = 0, qry_idx = 0, tile = 0, pos = 0, err = 0;
         bool last_tile = (R <= 0 || Q <= 0);
         unsigned long long cells = 0;
-        long long steps_left = 32ll * (R + Q) + a.step_slack;   // watchdog: every loop below is bounded by it
+        int steps_left = (int)min(32ll * (R + Q) + a.step_slack, 0x7fffffffll);   // watchdog: every loop below is bounded by it
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
@@ -239,6 +260,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             const int kEnd = refLen + qLen - 1;
             int k = 0;
             int tile_err = 0;
+            unsigned tile_cells = 0;                     // < 2^32 per tile: at most (refLen+qLen) diagonals x 4096 cells
 
             heartbeat(a, 2, tile);
             for (; k < kEnd; ++k) {
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 if (Lk >= Uk + 1) { tile_err = 1; break; }                // :323-329
                 if (Uk - Lk + 1 > fLen) { tile_err = 2; break; }          // :331-338
                 if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; break; }
-                cells += (unsigned long long)(Uk - Lk + 1);
+                tile_cells += (unsigned)(Uk - Lk + 1);
                 const int par = k & 1;
                 const int rs3 = k % 3;
                 const float thr = max_score - xdropf;                      // :495
@@ -303,6 +325,19 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const bool rgAny = __builtin_amdgcn_ballot_w64(inband && rg != 0.0f) != 0ull;
                         float numer = 0.0f;
                         if constexpr (P == 6) {
+                          if (nZero) {
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) {
+                                float t[4];
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    if constexpr (PRE) t[m] = qM[r][5 * l + m] * rc[l];
+                                    else t[m] = (q[m] * a.M[5 * l + m]) * rc[l];
+                                }
+                                const float sl = ((t[0] + t[1]) + t[2]) + t[3];
+                                numer = (l == 0) ? sl : numer + sl;
+                            }
+                          } else {
                             // column score, :378-395 (order: (((t0+t1)+t2)+t3)+t4 per l, accumulated over l)
 #pragma unroll
                             for (int l = 0; l < 5; ++l) {
@@ -315,6 +350,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
                                 numer = (l == 0) ? sl : numer + sl;
                             }
+                          }
                         } else {
                             // protein column score, :409-430: per l the scalar tail m=16..20 first, then the two 8-lane
                             // blocks v[t] = (q[t]*M[l][t])*r[l] + (q[8+t]*M[l][8+t])*r[l] summed left to right
@@ -395,10 +431,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         float wmax = 0.f;
                         if (raise) wmax = wave_max_f32(inband ? Sv : -inf);
                         if (lane == 0) {
-                            if (raise) atomicMax(&s_red[rs3][0], f2key(wmax));
+                            if (raise) lds_max_i32(&s_red[rs3][0], f2key(wmax));
                             if (vm) {
-                                atomicMin(&s_red[rs3][1], b + (int)__builtin_ctzll(vm));
-                                atomicMax(&s_red[rs3][2], b + 63 - (int)__builtin_clzll(vm));
+                                lds_min_i32(&s_red[rs3][1], b + (int)__builtin_ctzll(vm));
+                                lds_max_i32(&s_red[rs3][2], b + 63 - (int)__builtin_clzll(vm));
                             }
                         }
                         if (lane == 63) s_exch[par][vw] = make_int4(__float_as_int(S1[r]), __float_as_int(I1[r]), CS1[r], CI1[r]);
@@ -444,9 +480,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                     const bool badS = __builtin_amdgcn_ballot_w64(inr && CS1[r] != v) != 0ull;
                                     const bool badID = __builtin_amdgcn_ballot_w64(inr && (CI1[r] != v || CD1[r] != v)) != 0ull;
                                     if (lane == 0) {
-                                        atomicMin(&s_conv[par][0], v);
-                                        atomicMax(&s_conv[par][1], v);
-                                        if (badS || badID) atomicOr(&s_conv[par][2], (badS ? 1 : 0) | (badID ? 2 : 0));
+                                        lds_min_i32(&s_conv[par][0], v);
+                                        lds_max_i32(&s_conv[par][1], v);
+                                        if (badS || badID) lds_or_b32(&s_conv[par][2], (badS ? 1 : 0) | (badID ? 2 : 0));
                                     }
                                 }
                             }
@@ -475,6 +511,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 if (converged && max_score > conv_score) { conv_logic = true; break; }   // :609-612
             }
 
+            cells += tile_cells;
             dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
             if (tile_err != 0) { err = tile_err; break; }
 
@@ -578,7 +615,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             if (a.dbg) {
                 int32_t *g = a.dbg + 16 * (size_t)pair;
                 g[0] = tile; g[1] = dbg_lastk; g[2] = dbg_conv; g[3] = dbg_L; g[4] = dbg_U; g[5] = ref_idx; g[6] = qry_idx;
-                g[7] = pos; g[8] = err; g[9] = (int32_t)(steps_left >> 0); g[10] = R; g[11] = Q;
+                g[7] = pos; g[8] = err; g[9] = steps_left; g[10] = R; g[11] = Q;
             }
         }
         __syncthreads();   // keeps the single-lane block above out of the loop latch (see NOTE on control flow)

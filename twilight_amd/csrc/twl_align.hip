@@ -118,11 +118,13 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.n_items = n_items;
     HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
     int32_t *hb = nullptr;
+#ifdef TWL_KERNEL_DEBUG
     if (dbg_on()) {
         HIP_TRY(hipHostMalloc((void **)&hb, 16 * sizeof(int32_t), hipHostMallocMapped));
         for (int i = 0; i < 16; ++i) hb[i] = -777;
         a.hb = hb;
     }
+#endif
     TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
     hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -221,3 +221,30 @@ def path_consumes(aln: np.ndarray, n: int) -> tuple[int, int]:
     """(#ref columns, #query columns) an alignment path consumes: 0 both, 1 query only, 2 ref only."""
     a = aln[:n]
     return int(np.count_nonzero(a != 1)), int(np.count_nonzero(a != 2))
+
+
+def make_family(n_leaves: int, length: int, *, P: int = NUC_P, seed: int = 1, sub: float = 0.04, indel: float = 0.004):
+    """A synthetic sequence family for end-to-end runs: (newick, [(name, sequence), ...]).
+
+    A root sequence is evolved down a random binary tree (Yule-like splits); branch lengths are the per-branch
+    substitution rates.  Leaves are named s0..s{n-1} in file order."""
+    rng = np.random.default_rng(seed)
+    n_letters = 4 if P == NUC_P else 20
+    bg = None if P == NUC_P else _AA_BG
+    alphabet = "ACGT" if P == NUC_P else "ACDEFGHIKLMNPQRSTVWY"
+    root = (rng.integers(0, 4, size=length) if P == NUC_P else rng.choice(20, size=length, p=bg)).astype(np.int8)
+    leaves = []
+
+    def grow(seq, n):
+        if n == 1:
+            name = f"s{len(leaves)}"
+            leaves.append((name, "".join(alphabet[c] for c in seq)))
+            return name
+        left = int(rng.integers(1, n))
+        parts = []
+        for k in (left, n - left):
+            b = float(rng.uniform(0.5, 1.5) * sub)
+            parts.append(f"{grow(_mutate(seq, rng, n_letters, b, indel, bg), k)}:{b:.6f}")
+        return "(" + ",".join(parts) + ")"
+
+    return grow(root, n_leaves) + ";", leaves
