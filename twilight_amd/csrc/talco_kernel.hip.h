@@ -101,6 +101,7 @@ __device__ __forceinline__ float wave_max_f32(float x)
 __device__ __forceinline__ int f2key(float f)
 {
     int b = __float_as_int(f);
+    if (b == (int)0x80000000) b = 0;          // -0.0 == +0.0
     return b >= 0 ? b : (b ^ 0x7fffffff);
 }
 __device__ __forceinline__ float key2f(int k)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                     for (int t = 0; t < F4; ++t) {
                         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (col < refLen) c = colsR[F4 * (size_t)(ref_idx + col) + t];
-                        s_ring[F4 * slot + t] = c;
+                        s_ring[t * CAP + slot] = c;
                     }
                 }
             };
@@ -254,7 +255,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
 
             // ---- Tile, TALCO-XDrop.cpp:233-689 ----
             int Lk = 0, Uk = 0, L1 = 2, U1 = -2, L2 = 1, U2 = -1;      // :296-297 (rows k, k-1, k-2)
-            float msp = -inf, max_score = 0.0f, conv_score = 0.0f;      // :259-260
+            // running maximum / X-drop reference / score at convergence, kept as order-preserving integer keys so that
+            // their bookkeeping is scalar integer work (:259-260,:501-503,:607-612)
+            int mspKey = f2key(-inf), msKey = 0, convKey = 0;
             bool converged = false, conv_logic = false;
             int conv_value = 0, prev_conv_s = -1, last_k = 0;
             const int kEnd = refLen + qLen - 1;
@@ -272,9 +275,16 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 tile_cells += (unsigned)(Uk - Lk + 1);
                 const int par = k & 1;
                 const int rs3 = k % 3;
-                const float thr = max_score - xdropf;                      // :495
+                const float msp = key2f(mspKey);
+                const float thr = key2f(msKey) - xdropf;                   // :495
                 const bool pb = (k >= marker - 1);
                 const bool edgeStep = (tile == 0) && (Lk == 0 || Uk == k);
+                // bands as (low, width) with an empty band mapped to an unreachable low: one unsigned compare per test
+                const unsigned wk = (unsigned)(Uk - Lk);
+                const int L1e = (U1 >= L1) ? L1 : 0x3fffffff;
+                const unsigned w1 = (U1 >= L1) ? (unsigned)(U1 - L1) : 0u;
+                const int L2p = (U2 >= L2) ? L2 + 1 : 0x3fffffff;
+                const unsigned w2 = (U2 >= L2) ? (unsigned)(U2 - L2) : 0u;
 
                 if constexpr (REFLDS) {
                     const int need_hi = ((k - Lk) >> 6) + 1;
@@ -305,14 +315,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                     if (fetchActive && active) {
                         const int i = b + lane;
                         const int j = k - i;
-                        const bool inband = (i >= Lk) && (i <= Uk);
+                        const bool inband = (unsigned)(i - Lk) <= wk;
                         // reference column r[j] (and, when it is not register-resident, the query column q[i])
                         float rc[CW];
                         if constexpr (REFLDS) {
                             int rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
 #pragma unroll
                             for (int t = 0; t < F4; ++t) {
-                                const float4 c = s_ring[F4 * rs + t];
+                                const float4 c = s_ring[t * CAP + rs];
                                 rc[4 * t] = c.x; rc[4 * t + 1] = c.y; rc[4 * t + 2] = c.z; rc[4 * t + 3] = c.w;
                             }
                         } else {
@@ -375,9 +385,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         }
                         const float sim = denomOne ? numer : numer / denom;                     // :444
 
-                        const bool diag_ok = (i - 1 >= L2) && (i - 1 <= U2);
-                        const bool up_ok = (i >= L1) && (i <= U1);
-                        const bool left_ok = (i - 1 >= L1) && (i - 1 <= U1);
+                        const unsigned t1 = (unsigned)(i - L1e);
+                        const bool up_ok = t1 <= w1;                      // i   in band(k-1)
+                        const bool left_ok = (t1 - 1u) <= w1;             // i-1 in band(k-1)
+                        const bool diag_ok = (unsigned)(i - L2p) <= w2;   // i-1 in band(k-2)
                         float match;                                                            // :445-450
                         if (k == 0) match = sim;
                         else match = diag_ok ? LS2[r] + sim : -inf;
@@ -395,33 +406,33 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const bool Dptr = delExt >= delOp;
                         const float Iv = Iptr ? insExt : insOp;
                         const float Dv = Dptr ? delExt : delOp;
-                        float Sv; int ptr;                                                      // :477-494
-                        if (match >= Iv) {
-                            if (match >= Dv) { Sv = match; ptr = 0; } else { Sv = Dv; ptr = 2; }
-                        } else if (Iv > Dv) { Sv = Iv; ptr = 1; }
-                        else { Sv = Dv; ptr = 2; }
-                        if (Sv < thr) Sv = -inf;                                                // :495-497
+                        // :477-494 as three compares: M wins ties, then D beats I on equality
+                        const bool c1 = match >= Iv, c2 = match >= Dv, c3 = Iv > Dv;
+                        const bool isM = c1 && c2, isI = !c1 && c3;
+                        float Sv = isM ? match : (isI ? Iv : Dv);
+                        Sv = (Sv < thr) ? -inf : Sv;                                            // :495-497
 
+                        // Out-of-band lanes compute too; their registers are never consumed (every reader tests the stored
+                        // band of the producing diagonal first), so only LDS/HBM side effects are guarded.
                         if (pb) {                                                               // :520-547
                             int CSn, CIn = CI1[r], CDn = CD1[r];
                             if (k == marker - 1) CSn = (3 << 16) | (i & 0xFFFF);
                             else if (k == marker) {
                                 CSn = i & 0xFFFF; CIn = (1 << 16) | (i & 0xFFFF); CDn = (2 << 16) | (i & 0xFFFF);
                             } else {
-                                CIn = Iptr ? (left_ok ? LCI1 : kIB) : ((left_ok && LCS1 != -1) ? LCS1 : kIB);
+                                const int viaS = (LCS1 != -1) ? LCS1 : kIB;
+                                CIn = left_ok ? (Iptr ? LCI1 : viaS) : kIB;
                                 // :534-538; offsetUp >= 0 always holds; above the stored band it reads the stale slot
                                 const int cdUp = up_ok ? CD1[r] : s_cd[par ^ 1][U1 - L1 + 1];
                                 CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
-                                CSn = (ptr == 0) ? LCS2[r] : ((ptr == 1) ? CIn : CDn);
+                                CSn = isM ? LCS2[r] : (isI ? CIn : CDn);
                             }
-                            if (inband) {
-                                CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn;
-                                if (k >= marker) s_cd[par][i - Lk] = CDn;
-                            }
+                            CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn;
+                            if (inband && k >= marker) s_cd[par][i - Lk] = CDn;
                         }
-                        if (inband) { S1[r] = Sv; I1[r] = Iv; D1[r] = Dv; }
+                        S1[r] = Sv; I1[r] = Iv; D1[r] = Dv;
                         if (k <= marker) {                                                      // :548-557
-                            const uint32_t nib = (uint32_t)ptr | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
+                            const uint32_t nib = (isM ? 0u : (isI ? 1u : 2u)) | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
                             tbacc[r] |= nib << (4 * (k & 7));
                             tbdirty[r] = true;
                         }
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 lds_max_i32(&s_red[rs3][2], b + 63 - (int)__builtin_clzll(vm));
                             }
                         }
-                        if (lane == 63) s_exch[par][vw] = make_int4(__float_as_int(S1[r]), __float_as_int(I1[r]), CS1[r], CI1[r]);
+                        if (lane == 63) s_exch[par][vw] = make_int4(__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]);
                     }
                     if (fetchActive) { LS2[r] = LS1; LCS2[r] = LCS1; }
                     if (tbdirty[r] && (((k & 7) == 7) || k == marker)) {
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 const bool anyValid = glast >= 0;
                 const int newL = anyValid ? gfirst : Uk + 1;                  // :563-583
                 const int newU = anyValid ? glast : Lk - 1;
-                msp = fmaxf(msp, key2f(gkey));                                // :501-503
+                mspKey = max(mspKey, gkey);                                   // :501-503
 
                 if (!converged && k < kEnd - 1) {                             // :585-595
                     int conv_S = -1;
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         if (newU >= newL && vmin == vmax && !(fl & 1)) { conv_S = vmin; all3 = !(fl & 2); }
                     }
                     if (all3 && prev_conv_s == conv_S && conv_S != -1) {
-                        converged = true; conv_value = prev_conv_s; conv_score = msp;
+                        converged = true; conv_value = prev_conv_s; convKey = mspKey;
                     }
                     prev_conv_s = conv_S;
                 }
@@ -506,9 +517,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                     const int nU = (qLen - 1) < (newU + 1) ? (qLen - 1) : (newU + 1);
                     L2 = L1; U2 = U1; L1 = Lk; U1 = Uk; Lk = nL; Uk = nU;
                 }
-                max_score = (msp < 0.0f) ? 0.0f : msp;                        // :607
+                msKey = max(mspKey, 0);                                       // :607  max(0, max_score_prime)
                 last_k = k;
-                if (converged && max_score > conv_score) { conv_logic = true; break; }   // :609-612
+                if (converged && msKey > convKey) { conv_logic = true; break; }          // :609-612
             }
 
             cells += tile_cells;
