@@ -123,7 +123,13 @@ struct Cfg {
     static constexpr int THREADS = 64 * W;
 };
 
-template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1>
+// MM = matrix mode of the nucleotide path (chosen by the host from the matrix values; every mode computes the same sums):
+//   0  general 5x5;
+//   1  N row and column all zero (scoring-matrix.cpp:104 without -w): their 9 products are +-0 and adding +-0 never changes a
+//      non-zero partial sum, so the 4x4 core is enough (this can only flip the sign of a zero);
+//   2  mode 1 and M[l][m] = A (l==m), B (|l-m|==2, transitions), C (otherwise): q[m]*M[l][m] takes 3 values per m -> 12 first
+//      products instead of 16 and 3 live scalars instead of 16.
+template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1, int MM = 0>
 __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
 {
     using C = Cfg<P, W, RPL, PRE, REFLDS, QREG>;
@@ -149,13 +155,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
     const int marker = a.marker;
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
-    // Default nucleotide matrix: the N row and column are all zero (scoring-matrix.cpp:104).  Their 9 products are +-0
-    // and adding +-0 never changes a non-zero partial sum, so they are skipped (can only flip the sign of a zero).
-    bool nZero = (P == 6);
-    if constexpr (P == 6) {
-#pragma unroll
-        for (int t = 0; t < 5; ++t) nZero = nZero && (a.M[20 + t] == 0.0f) && (a.M[5 * t + 4] == 0.0f);
-    }
 
     heartbeat(a, 0, 1);
     for (;;) {
@@ -334,8 +333,20 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const float rg = rc[P - 1], gopr = rc[P], gexr = rc[P + 1];
                         const bool rgAny = __builtin_amdgcn_ballot_w64(inband && rg != 0.0f) != 0ull;
                         float numer = 0.0f;
-                        if constexpr (P == 6) {
-                          if (nZero) {
+                        if constexpr (P == 6 && MM == 2 && !PRE) {
+                            const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
+                            float pa[4], pb[4], pc[4];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) { pa[m] = q[m] * mA; pb[m] = q[m] * mB; pc[m] = q[m] * mC; }
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) {
+                                float t[4];
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) t[m] = ((l == m) ? pa[m] : (((l ^ m) == 2) ? pb[m] : pc[m])) * rc[l];
+                                const float sl = ((t[0] + t[1]) + t[2]) + t[3];
+                                numer = (l == 0) ? sl : numer + sl;
+                            }
+                        } else if constexpr (P == 6 && MM >= 1) {
 #pragma unroll
                             for (int l = 0; l < 4; ++l) {
                                 float t[4];
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 const float sl = ((t[0] + t[1]) + t[2]) + t[3];
                                 numer = (l == 0) ? sl : numer + sl;
                             }
-                          } else {
+                        } else if constexpr (P == 6) {
                             // column score, :378-395 (order: (((t0+t1)+t2)+t3)+t4 per l, accumulated over l)
 #pragma unroll
                             for (int l = 0; l < 5; ++l) {
@@ -360,7 +371,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
                                 numer = (l == 0) ? sl : numer + sl;
                             }
-                          }
                         } else {
                             // protein column score, :409-430: per l the scalar tail m=16..20 first, then the two 8-lane
                             // blocks v[t] = (q[t]*M[l][t])*r[l] + (q[8+t]*M[l][8+t])*r[l] summed left to right

@@ -91,7 +91,7 @@ int check_params(const twl_params *p)
 template <class CfgT>
 size_t tb_words_for(int marker) { return ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW; }
 
-template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1>
+template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1, int MM = 0>
 int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int blocks_per_cu, int *grid_out,
               int *window_out = nullptr)
 {
@@ -100,7 +100,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         static int cached = 0;      // one value per template instantiation
         if (cached == 0) {
             int nb = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW>), CfgT::THREADS, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), CfgT::THREADS, 0));
             cached = std::max(1, nb);
         }
         blocks_per_cu = cached;
@@ -126,7 +126,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     }
 #endif
     TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
-    hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
         for (int t = 0; t < 200; ++t) {
@@ -220,7 +220,22 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     };
     if (force_wide) rc = launch_wide(items, n_pairs, &grid, &window);
     else if (prot) rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8r2") rc = launch_dp<6, 8, 2, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2") {
+        // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
+        const float *M = a.M;
+        bool nz = true, st3 = true;
+        for (int t = 0; t < 5; ++t) nz = nz && M[20 + t] == 0.0f && M[5 * t + 4] == 0.0f;
+        for (int l = 0; l < 4; ++l)
+            for (int m = 0; m < 4; ++m) st3 = st3 && M[5 * l + m] == ((l == m) ? M[0] : (((l ^ m) == 2) ? M[2] : M[1]));
+        const char *mmEnv = getenv("TWL_MATRIX_MODE");
+        int mm = nz ? (st3 ? 2 : 1) : 0;
+        if (mmEnv) mm = std::min(mm, atoi(mmEnv));          // development knob: force a more general mode
+        if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 1, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 1, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else rc = launch_dp<6, 8, 2, false, true, true, 1, 0>(d, st, a, items, n_pairs, 0, &grid, &window);
+    }
+    else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w8") rc = launch_dp<6, 8, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w4r4") rc = launch_dp<6, 4, 4, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
