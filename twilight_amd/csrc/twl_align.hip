@@ -246,30 +246,33 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     d->stats.grid = grid;
     d->stats.window = window;
 
-    // pairs whose band outgrew the fast window are re-run (bit-identically) by the wide kernel
+    // Pairs whose band outgrew a window are re-run, bit-identically, by the next stage: 1024-row fast window ->
+    // 2048-row window (16 waves x 2 blocks, LDS ring) -> 4608-row window (covers flen = 4096; columns from L2/HBM).
     std::vector<int16_t> h_err((size_t)n_pairs);
-    HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    TRACE("dp kernel done");
-    std::vector<int32_t> redo;
-    for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
     float ms_redo = 0.f;
-    std::vector<unsigned long long> cells_first;
-    if (!redo.empty()) {
+    for (int stage = 1; stage <= 2; ++stage) {
+        HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stage == 1) TRACE("dp kernel done");
+        std::vector<int32_t> redo;
+        for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
+        if (redo.empty()) break;
         if (force_wide) { g_err = "band wider than the wide window"; return TWL_ERR_UNSUPPORTED; }
-        cells_first.resize((size_t)n_pairs);
-        HIP_TRY(hipMemcpyAsync(cells_first.data(), d->cells.p, cells_first.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        const bool mid = (stage == 1) && !prot;
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
-        int grid2 = 0;
-        int w2 = 0;
-        rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        int grid2 = 0, w2 = 0;
+        if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
+        else rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(d->ev[4], st));
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipEventElapsedTime(&ms_redo, d->ev[3], d->ev[4]));
-        d->stats.n_launches = 2;
-        d->stats.n_relaunched = (int32_t)redo.size();
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4]));
+        ms_redo += ms;
+        d->stats.n_launches += 1;
+        d->stats.n_relaunched += (int32_t)redo.size();
+        if (!mid) { stage = 2; }
     }
     std::vector<unsigned long long> cells((size_t)n_pairs);
     HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
