@@ -262,22 +262,25 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             const int kEnd = refLen + qLen - 1;
             int k = 0;
             int tile_err = 0;
+            int rs3 = 0;                                 // k % 3, kept incrementally
             unsigned tile_cells = 0;                     // < 2^32 per tile: at most (refLen+qLen) diagonals x 4096 cells
 
             heartbeat(a, 2, tile);
             for (; k < kEnd; ++k) {
                 heartbeat(a, 3, k);
-                if (--steps_left < 0) { tile_err = 3; break; }
-                if (Lk >= Uk + 1) { tile_err = 1; break; }                // :323-329
-                if (Uk - Lk + 1 > fLen) { tile_err = 2; break; }          // :331-338
-                if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; break; }
+                // one rarely-taken exit for all four stop conditions (decoded after the loop)
+                if (__builtin_expect((--steps_left < 0) | (Lk > Uk) | (Uk - Lk + 1 > fLen) | ((Uk >> 6) - (Lk >> 6) >= NV), 0)) {
+                    tile_err = (steps_left < 0) ? 3 : (Lk > Uk) ? 1                       // :323-329 band emptied by X-drop
+                             : (Uk - Lk + 1 > fLen) ? 2 : kErrOverflow;                    // :331-338 wider than fLen / than this window
+                    break;
+                }
                 tile_cells += (unsigned)(Uk - Lk + 1);
                 const int par = k & 1;
-                const int rs3 = k % 3;
                 const float msp = key2f(mspKey);
                 const float thr = key2f(msKey) - xdropf;                   // :495
                 const bool pb = (k >= marker - 1);
                 const bool edgeStep = (tile == 0) && (Lk == 0 || Uk == k);
+                const bool special = (k == 0) | edgeStep;                  // first diagonal of a tile / first row or column of tile 0
                 // bands as (low, width) with an empty band mapped to an unreachable low: one unsigned compare per test
                 const unsigned wk = (unsigned)(Uk - Lk);
                 const int L1e = (U1 >= L1) ? L1 : 0x3fffffff;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                     if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
                 }
                 if (threadIdx.x == 0) {   // reset the reduction slot of the next diagonal
-                    const int nx = (k + 1) % 3;
+                    const int nx = (rs3 == 2) ? 0 : rs3 + 1;
                     s_red[nx][0] = f2key(-inf); s_red[nx][1] = 0x7fffffff; s_red[nx][2] = -1;
                 }
 
@@ -302,16 +305,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         load_q(r);
                     }
                     const int b = 64 * blk[r];
-                    const bool fetchActive = (b <= Uk + 1) && (b + 63 >= Lk);
-                    const bool active = (b <= Uk);
-                    float LS1 = 0.f, LI1 = 0.f; int LCS1 = 0, LCI1 = 0;
-                    if (fetchActive) {
+                    // The block takes part when the band touches it or will reach it on the next diagonal (its lane 0 then needs
+                    // S[k-1][b-1] now, to have S[k-2][i-1] next time).  In that one extra step every lane is out of band.
+                    const bool act = (b <= Uk + 1) && (b + 63 >= Lk);
+                    if (act) {
                         const int4 e = s_exch[par ^ 1][(vw + NV - 1) % NV];
-                        LS1 = dpp_shr1_f(__int_as_float(e.x), S1[r]);
-                        LI1 = dpp_shr1_f(__int_as_float(e.y), I1[r]);
-                        if (pb) { LCS1 = dpp_shr1_i(e.z, CS1[r]); LCI1 = dpp_shr1_i(e.w, CI1[r]); }
-                    }
-                    if (fetchActive && active) {
+                        const float LS1 = dpp_shr1_f(__int_as_float(e.x), S1[r]);
+                        const float LI1 = dpp_shr1_f(__int_as_float(e.y), I1[r]);
+                        const int LCS1 = dpp_shr1_i(e.z, CS1[r]);
+                        const int LCI1 = dpp_shr1_i(e.w, CI1[r]);
                         const int i = b + lane;
                         const int j = k - i;
                         const bool inband = (unsigned)(i - Lk) <= wk;
@@ -399,11 +401,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const bool up_ok = t1 <= w1;                      // i   in band(k-1)
                         const bool left_ok = (t1 - 1u) <= w1;             // i-1 in band(k-1)
                         const bool diag_ok = (unsigned)(i - L2p) <= w2;   // i-1 in band(k-2)
-                        float match;                                                            // :445-450
-                        if (k == 0) match = sim;
-                        else match = diag_ok ? LS2[r] + sim : -inf;
-                        if (edgeStep && k > 0) {
-                            if (i == 0 || j == 0) {
+                        float match = diag_ok ? LS2[r] + sim : -inf;                            // :445-450
+                        if (special) {
+                            if (k == 0) match = sim;
+                            else if (i == 0 || j == 0) {
                                 int far = max(i, j) - 1; far = far < 0 ? 0 : far;
                                 match = (sim + gapOpen) + gapExtend * (float)far;
                             }
@@ -449,18 +450,18 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         // wave summaries -> LDS reduction slot of this diagonal
                         const unsigned long long vm = __builtin_amdgcn_ballot_w64(inband && Sv > -inf);
                         const bool raise = __builtin_amdgcn_ballot_w64(inband && Sv > msp) != 0ull;
-                        float wmax = 0.f;
-                        if (raise) wmax = wave_max_f32(inband ? Sv : -inf);
-                        if (lane == 0) {
-                            if (raise) lds_max_i32(&s_red[rs3][0], f2key(wmax));
-                            if (vm) {
-                                lds_min_i32(&s_red[rs3][1], b + (int)__builtin_ctzll(vm));
-                                lds_max_i32(&s_red[rs3][2], b + 63 - (int)__builtin_clzll(vm));
-                            }
+                        int wkey = (int)0x80000000;                      // neutral for max
+                        if (raise) wkey = f2key(wave_max_f32(inband ? Sv : -inf));
+                        const int firstRow = vm ? b + (int)__builtin_ctzll(vm) : 0x7fffffff;     // neutral for min
+                        const int lastRow = vm ? b + 63 - (int)__builtin_clzll(vm) : -1;          // neutral for max
+                        if (lane == 63) {        // the block's single-lane side effects: three reductions and the mailbox for block b+64
+                            lds_max_i32(&s_red[rs3][0], wkey);
+                            lds_min_i32(&s_red[rs3][1], firstRow);
+                            lds_max_i32(&s_red[rs3][2], lastRow);
+                            s_exch[par][vw] = make_int4(__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]);
                         }
-                        if (lane == 63) s_exch[par][vw] = make_int4(__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]);
+                        LS2[r] = LS1; LCS2[r] = LCS1;
                     }
-                    if (fetchActive) { LS2[r] = LS1; LCS2[r] = LCS1; }
                     if (tbdirty[r] && (((k & 7) == 7) || k == marker)) {
                         tb[(size_t)(k >> 3) * WINDOW + 64 * vw + lane] = tbacc[r];
                         tbacc[r] = 0; tbdirty[r] = false;
@@ -470,10 +471,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 heartbeat(a, 4, k);
                 __syncthreads();
                 heartbeat(a, 5, k);
+                const int rs3_now = rs3;
+                rs3 = (rs3 == 2) ? 0 : rs3 + 1;
 
-                const int gkey = __builtin_amdgcn_readfirstlane(s_red[rs3][0]);
-                const int gfirst = __builtin_amdgcn_readfirstlane(s_red[rs3][1]);
-                const int glast = __builtin_amdgcn_readfirstlane(s_red[rs3][2]);
+                const int gkey = __builtin_amdgcn_readfirstlane(s_red[rs3_now][0]);
+                const int gfirst = __builtin_amdgcn_readfirstlane(s_red[rs3_now][1]);
+                const int glast = __builtin_amdgcn_readfirstlane(s_red[rs3_now][2]);
                 const bool anyValid = glast >= 0;
                 const int newL = anyValid ? gfirst : Uk + 1;                  // :563-583
                 const int newU = anyValid ? glast : Lk - 1;

@@ -104,6 +104,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
             cached = std::max(1, nb);
         }
         blocks_per_cu = cached;
+        if (const char *cap = getenv("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));   // development knob
     }
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
