@@ -281,6 +281,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 const bool pb = (k >= marker - 1);
                 const bool edgeStep = (tile == 0) && (Lk == 0 || Uk == k);
                 const bool special = (k == 0) | edgeStep;                  // first diagonal of a tile / first row or column of tile 0
+                // the slot one past diagonal k-1 in the mirrored CD row (see s_cd): one broadcast read per diagonal
+                const int staleCD = pb ? s_cd[par ^ 1][(U1 >= L1) ? (U1 - L1 + 1) : 0] : kDB;
                 // bands as (low, width) with an empty band mapped to an unreachable low: one unsigned compare per test
                 const unsigned wk = (unsigned)(Uk - Lk);
                 const int L1e = (U1 >= L1) ? L1 : 0x3fffffff;
@@ -426,17 +428,17 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         // Out-of-band lanes compute too; their registers are never consumed (every reader tests the stored
                         // band of the producing diagonal first), so only LDS/HBM side effects are guarded.
                         if (pb) {                                                               // :520-547
-                            int CSn, CIn = CI1[r], CDn = CD1[r];
-                            if (k == marker - 1) CSn = (3 << 16) | (i & 0xFFFF);
-                            else if (k == marker) {
-                                CSn = i & 0xFFFF; CIn = (1 << 16) | (i & 0xFFFF); CDn = (2 << 16) | (i & 0xFFFF);
-                            } else {
-                                const int viaS = (LCS1 != -1) ? LCS1 : kIB;
-                                CIn = left_ok ? (Iptr ? LCI1 : viaS) : kIB;
-                                // :534-538; offsetUp >= 0 always holds; above the stored band it reads the stale slot
-                                const int cdUp = up_ok ? CD1[r] : s_cd[par ^ 1][U1 - L1 + 1];
-                                CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
-                                CSn = isM ? LCS2[r] : (isI ? CIn : CDn);
+                            // propagation along the chosen predecessors (k > marker) ...
+                            const int viaS = (LCS1 != -1) ? LCS1 : kIB;
+                            int CIn = left_ok ? (Iptr ? LCI1 : viaS) : kIB;
+                            // :534-538; offsetUp >= 0 always holds; above the stored band the reference reads the stale slot
+                            const int cdUp = up_ok ? CD1[r] : staleCD;
+                            int CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
+                            int CSn = isM ? LCS2[r] : (isI ? CIn : CDn);
+                            if (__builtin_expect(k <= marker, 0)) {          // ... and the two diagonals where the markers are planted
+                                const int i16 = i & 0xFFFF;
+                                if (k == marker) { CSn = i16; CIn = (1 << 16) | i16; CDn = (2 << 16) | i16; }
+                                else { CSn = (3 << 16) | i16; CIn = CI1[r]; CDn = CD1[r]; }
                             }
                             CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn;
                             if (inband && k >= marker) s_cd[par][i - Lk] = CDn;
