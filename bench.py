@@ -28,7 +28,7 @@ from twilight_amd import synth  # noqa: E402
 
 B_CELL_NUC = 64          # algorithmic operand bytes per band cell, P=6: 2*P*4 + 4*4
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "w8r2_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "final_pmc_summary.json")
 
 
 def measured_traffic_per_launch(cells_per_launch):
@@ -67,24 +67,31 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(batch, pool_idx, gpu_paths, gpu_lens):
-    """Oracle ("port" of the reference CPU path) timed on the host cores of this box, bounded sample."""
+def cpu_baseline(batch, idx, gpu_paths, gpu_lens, target_seconds=15.0):
+    """Oracle ("port" of the reference CPU path, OpenMP over pairs like tbb::parallel_for at alignment-cpu.cpp:46) timed on
+    the host cores this process may use.  A short calibration sizes the sample to about `target_seconds` of CPU work; the
+    sample is the first k pairs of the very batch the GPU aligned, and the paths are compared while we are at it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cores = effective_cpus()
-    threads = min(cores, len(pool_idx))
-    sub = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq[pool_idx], gap_open=batch.gap_open[pool_idx],
-                           gap_extend=batch.gap_extend[pool_idx], len=batch.len[pool_idx], num=batch.num[pool_idx])
+    def sub(ix):
+        return synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq[ix], gap_open=batch.gap_open[ix],
+                                gap_extend=batch.gap_extend[ix], len=batch.len[ix], num=batch.num[ix])
+
+    threads = effective_cpus()
     p = O.make_params(synth.nucleotide_matrix())
-    O.align_batch(p, synth.LevelBatch(P=sub.P, seq_len=sub.seq_len, freq=sub.freq[:1], gap_open=sub.gap_open[:1],
-                                      gap_extend=sub.gap_extend[:1], len=sub.len[:1], num=sub.num[:1]), threads=1)   # warm the library
+    cal = idx[: max(threads, 8)]
     t0 = time.perf_counter()
-    aln, n, err, st = O.align_batch(p, sub, threads=threads)
+    _, _, _, st = O.align_batch(p, sub(cal), threads=threads)
+    rate = st.cells / (time.perf_counter() - t0)
+    per_pair = st.cells / len(cal)
+    k = int(min(len(idx), max(len(cal), target_seconds * rate / per_pair)))
+    t0 = time.perf_counter()
+    aln, n, err, st = O.align_batch(p, sub(idx[:k]), threads=threads)
     dt = time.perf_counter() - t0
-    parity = bool(np.array_equal(n, gpu_lens) and all(np.array_equal(aln[i, : n[i]], gpu_paths[i][: n[i]]) for i in range(len(pool_idx))))
+    parity = bool(np.array_equal(n, gpu_lens[:k]) and all(np.array_equal(aln[i, : n[i]], gpu_paths[i][: n[i]]) for i in range(k)))
     return {"value": st.cells / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"{len(pool_idx)} pairs of the same workload ({st.cells} band cells) in {dt:.2f} s, OpenMP over pairs",
+            "sample": f"first {k} pairs of the same batch ({st.cells} band cells) in {dt:.1f} s, OpenMP over pairs, {threads} threads",
             "gpu_paths_equal_on_sample": parity}
 
 
@@ -188,7 +195,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic_per_launch(cells // max(1, launches)),
-                "traffic_source": "profiles/r01/w8r2_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per band cell x cells per launch)",
+                "traffic_source": "profiles/r01/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per band cell x cells per launch)",
                 "kernel": "twl::talco_nuc_kernel", "kernel_ms_per_launch": kernel_ms / max(1, launches),
                 "algorithmic_bytes_per_cell": B_CELL_NUC, "cells_per_launch": cells // max(1, launches),
                 "note": "achieved = band cells x 64 B / DP-kernel time (HIP events on the library stream); the path is "
@@ -196,12 +203,9 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            k = args.cpu_sample or min(pool_n, max(8, min(2 * effective_cpus(), 64)))
-            pool_idx = np.arange(k)
-            gpu_paths = aln[:k].cpu().numpy()
-            gpu_lens = alen[:k].cpu().numpy()
+            kmax = args.cpu_sample or min(args.pairs, 4096)
             try:
-                out["cpu_baseline"] = cpu_baseline(batch, pool_idx, gpu_paths, gpu_lens)
+                out["cpu_baseline"] = cpu_baseline(batch, idx[:kmax], aln[:kmax].cpu().numpy(), alen[:kmax].cpu().numpy())
             except Exception as e:  # the checker must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

@@ -231,9 +231,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const char *mmEnv = getenv("TWL_MATRIX_MODE");
         int mm = nz ? (st3 ? 2 : 1) : 0;
         if (mmEnv) mm = std::min(mm, atoi(mmEnv));          // development knob: force a more general mode
-        if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 1, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 1, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else rc = launch_dp<6, 8, 2, false, true, true, 1, 0>(d, st, a, items, n_pairs, 0, &grid, &window);
+        if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_pairs, 0, &grid, &window);
     }
     else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_pairs, 0, &grid, &window);
