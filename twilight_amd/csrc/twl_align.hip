@@ -220,7 +220,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                     : launch_dp<6, 8, 9, false, false, true>(d, st, a, it, n_it, 1, g, w);
     };
     if (force_wide) rc = launch_wide(items, n_pairs, &grid, &window);
-    else if (prot) rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (prot) {
+        const char *pc = getenv("TWL_PROT_CFG");
+        if (pc && std::string(pc) == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    }
     else if (c == "w8r2") {
         // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
         const float *M = a.M;
