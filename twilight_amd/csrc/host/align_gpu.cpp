@@ -6,6 +6,8 @@
 
 #include "../../../include/twl_align.h"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -92,7 +94,9 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
     const int n = (int)nodes.size();
     const int P = param.matrixSize + 1;
     std::vector<PairInputs> in(n);
-#pragma omp parallel for schedule(dynamic, 1)
+    // wide levels: one pair per thread; narrow levels (upper tree): pairs in turn, the helpers' own column/sequence loops fan out
+    const bool acrossPairs = n >= omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) if (acrossPairs)
     for (int i = 0; i < n; ++i) preparePair(nodes[i], database, option, param, in[i]);       // alignment-cpu.cpp:50-93
 
     std::vector<alnPath> paths(n);
@@ -131,7 +135,7 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
     }
 
     std::vector<char> deferred(n, 0);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (acrossPairs)
     for (int i = 0; i < n; ++i) {                                                              // alignment-cpu.cpp:136-175
         // low-quality singleton rule (:136-144): such a pair is deferred whatever the DP said
         deferred[i] = (database->currentTask == 0 && (in[i].refNum == 1 || in[i].qryNum == 1) && (in[i].lowQ_r || in[i].lowQ_q)) ? 1 : 0;

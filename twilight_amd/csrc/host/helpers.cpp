@@ -23,13 +23,27 @@ static void profileOfSide(float *dst, Node *node, SequenceDB *db, Option *option
             for (int v = 0; v < P; ++v) dst[P * t + v] = node->msaFreq[t][v] / groupWeight * num;
         return;
     }
-    for (int sIdx : node->seqsIncluded) {
-        const float w = db->sequences[sIdx]->weight / groupWeight * num;
-        const char *row = db->sequences[sIdx]->alnStorage[db->sequences[sIdx]->storage];
-#pragma omp parallel for schedule(static) if (len > 4096)
-        for (int t = 0; t < len; ++t) {
-            const int li = letterIdx(option->type, (char)toupper((unsigned char)row[t]));
-            dst[P * t + li] += 1.0 * w;
+    // Same per-column summation order as the reference (member by member, :23-34); columns are split into chunks so that a
+    // single wide pair (upper tree levels) still uses every core and each member row is read with unit stride.
+    const int nSeq = (int)node->seqsIncluded.size();
+    std::vector<float> wOf(nSeq);
+    std::vector<const char *> rowOf(nSeq);
+    for (int s = 0; s < nSeq; ++s) {
+        auto *q = db->sequences[node->seqsIncluded[s]];
+        wOf[s] = q->weight / groupWeight * num;
+        rowOf[s] = q->alnStorage[q->storage];
+    }
+    const int chunk = 512, nChunks = (len + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) if (nChunks > 3 && nSeq > 1)
+    for (int c = 0; c < nChunks; ++c) {
+        const int t0 = c * chunk, t1 = std::min(len, t0 + chunk);
+        for (int s = 0; s < nSeq; ++s) {
+            const float w = wOf[s];
+            const char *row = rowOf[s];
+            for (int t = t0; t < t1; ++t) {
+                const int li = letterIdx(option->type, (char)toupper((unsigned char)row[t]));
+                dst[P * t + li] += 1.0 * w;
+            }
         }
     }
     if (storeFreq) {

@@ -392,13 +392,25 @@ static int run_host_slice(Device *d, const twl_params *p, const std::vector<int3
     hipStream_t st = d->stream;
     std::vector<int32_t> hl((size_t)n * 2), hn((size_t)n * 2);
     HIP_TRY(hipEventRecord(d->ev[5], st));
+    bool contiguous = true;
+    for (int32_t t = 0; t < n; ++t) contiguous = contiguous && ids[t] == ids[0] + t;
     for (int32_t t = 0; t < n; ++t) {
         const size_t s = (size_t)ids[t];
         hl[2 * t] = len[2 * s]; hl[2 * t + 1] = len[2 * s + 1];
         hn[2 * t] = num[2 * s]; hn[2 * t + 1] = num[2 * s + 1];
-        HIP_TRY(hipMemcpyAsync((float *)d->h2d_freq.p + (size_t)t * 2 * sl * P, freq + s * 2 * sl * P, 2 * sl * P * sizeof(float), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync((float *)d->h2d_gop.p + (size_t)t * 2 * sl, gop + s * 2 * sl, 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync((float *)d->h2d_gex.p + (size_t)t * 2 * sl, gex + s * 2 * sl, 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    if (contiguous) {      // one transfer per array instead of three per pair
+        const size_t s0 = (size_t)ids[0];
+        HIP_TRY(hipMemcpyAsync(d->h2d_freq.p, freq + s0 * 2 * sl * P, (size_t)n * 2 * sl * P * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d->h2d_gop.p, gop + s0 * 2 * sl, (size_t)n * 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d->h2d_gex.p, gex + s0 * 2 * sl, (size_t)n * 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+    } else {
+        for (int32_t t = 0; t < n; ++t) {
+            const size_t s = (size_t)ids[t];
+            HIP_TRY(hipMemcpyAsync((float *)d->h2d_freq.p + (size_t)t * 2 * sl * P, freq + s * 2 * sl * P, 2 * sl * P * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((float *)d->h2d_gop.p + (size_t)t * 2 * sl, gop + s * 2 * sl, 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((float *)d->h2d_gex.p + (size_t)t * 2 * sl, gex + s * 2 * sl, 2 * sl * sizeof(float), hipMemcpyHostToDevice, st));
+        }
     }
     HIP_TRY(hipMemcpyAsync(d->h2d_len.p, hl.data(), hl.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d->h2d_num.p, hn.data(), hn.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -444,7 +456,8 @@ int twl_align_batch(const twl_params *p, int32_t n_pairs, int32_t seq_len, const
         return (int64_t)len[2 * x] + len[2 * x + 1] > (int64_t)len[2 * y] + len[2 * y + 1];
     });
     std::vector<std::vector<int32_t>> slices(nd);
-    for (size_t t = 0; t < order.size(); ++t) slices[t % nd].push_back(order[t]);
+    if (nd == 1) { slices[0].resize((size_t)n_pairs); std::iota(slices[0].begin(), slices[0].end(), 0); }   // bulk copies; the device orders by cost itself
+    else for (size_t t = 0; t < order.size(); ++t) slices[t % nd].push_back(order[t]);
     if (nd == 1) return run_host_slice(g_devs[0], p, slices[0], seq_len, freq, gap_open, gap_extend, len, num, aln_out, aln_len_out, err_out);
     std::vector<int> rcs(nd, 0);
     std::vector<std::string> errs(nd);
