@@ -1,0 +1,157 @@
+// tests/host_kats.cpp -- known-answer tests of the host mirror's helpers, written from the reference source
+// (/root/reference/src/alignment-helper.cpp, scoring-matrix.cpp, tree.cpp, progressive.cpp).  Prints "OK <name>" / "FAIL <name>".
+#include "../twilight_amd/csrc/host/twl_host.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+static int g_fail = 0;
+#define CHECK(name, cond) do { if (cond) printf("OK %s\n", name); else { printf("FAIL %s\n", name); ++g_fail; } } while (0)
+
+using namespace msa;
+
+static std::string pathStr(const alnPath &p) { std::string s; for (auto c : p) s += char('0' + c); return s; }
+
+int main(int argc, char **argv)
+{
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    Option opt;
+    // ---- letterIdx (scoring-matrix.cpp:26-79) ----
+    CHECK("letterIdx_nuc", letterIdx('n', 'A') == 0 && letterIdx('n', 'C') == 1 && letterIdx('n', 'G') == 2 && letterIdx('n', 'T') == 3 &&
+                               letterIdx('n', 'U') == 3 && letterIdx('n', 'N') == 4 && letterIdx('n', 'R') == 4 && letterIdx('n', '-') == 5 && letterIdx('n', '.') == 5);
+    CHECK("letterIdx_prot", letterIdx('p', 'A') == 0 && letterIdx('p', 'Y') == 19 && letterIdx('p', 'W') == 18 && letterIdx('p', 'X') == 20 &&
+                                letterIdx('p', 'B') == 20 && letterIdx('p', 'U') == 20 && letterIdx('p', '-') == 21);
+    // ---- msa::Params defaults (scoring-matrix.cpp:81-110; twilight-main.cpp:65-73) ----
+    {
+        Params p(opt, 'n');
+        bool ok = p.matrixSize == 5 && p.gapOpen == -50 && p.gapExtend == -5 && p.gapBoundary == -5 && p.xdrop == 3000;
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) {
+                float want = (i == 4 || j == 4) ? 0 : (i == j ? 18 : (std::abs(i - j) == 2 ? -4 : -8));
+                ok = ok && p.scoringMatrix[i][j] == want;
+            }
+        CHECK("params_nucleotide_default", ok);
+        Option w = opt; w.wildcard = true;
+        Params pw(w, 'n');
+        CHECK("params_wildcard_N_is_match", pw.scoringMatrix[4][0] == 18 && pw.scoringMatrix[2][4] == 18);
+        Params pp(opt, 'p');
+        CHECK("params_protein_5xblosum62", pp.matrixSize == 21 && pp.scoringMatrix[0][0] == 20 && pp.scoringMatrix[18][18] == 55 && pp.scoringMatrix[1][3] == -20 &&
+                                               pp.scoringMatrix[20][5] == 0 && pp.scoringMatrix[5][20] == 0);
+    }
+    // ---- getConsensus (alignment-helper.cpp:221-241): first strict maximum; all-zero -> N ----
+    {
+        float prof[3 * 6] = {0, 2, 2, 0, 0, 1, /*col1: C and G tie -> C*/ 0, 0, 0, 0, 0, 3, /*all zero -> N*/ 1, 0, 0, 0.5f, 9, 0 /*N count ignored: argmax over first 4 -> A*/};
+        std::string c;
+        alignment_helper::getConsensus(&opt, prof, c, 3);
+        CHECK("consensus_ties_and_empty", c == "CNA");
+    }
+    // ---- calculatePSGP (alignment-helper.cpp:168-219) ----
+    {
+        Params p(opt, 'n');
+        Node a("a", 0), b("b", 0);
+        a.alnNum = 4; b.alnNum = 1;
+        NodePair np{&a, &b};
+        SequenceDB db;
+        const int memLen = 3;
+        float freq[6 * 2 * 3] = {0};
+        freq[0 * 6 + 5] = 0;       // ref col0: no gaps
+        freq[1 * 6 + 5] = 1;       // ref col1: 1 of 4 gaps
+        freq[2 * 6 + 5] = 3.999f;  // ref col2: almost all gaps
+        float go[6], ge[6];
+        alignment_helper::calculatePSGP(freq, go, ge, np, &db, &opt, memLen, {0, 0}, {3, 2}, p);
+        bool ok = go[0] == -50 && ge[0] == -5;
+        ok = ok && go[1] == std::min(-5.0f, (float)(-50.0f * 0.5f * ((4 - 1.0f) * 1.0 / 4))) && ge[1] == std::min(-1.0f, (float)(-5.0f * ((4 - 1.0f) * 1.0 / 4)));
+        ok = ok && go[2] == -5.0f && ge[2] == -1.0f;                 // clamps: 0.1*gapOpen, 0.2*gapExtend
+        ok = ok && go[3] == -50 && go[4] == -50 && go[5] == 0 && ge[5] == 0;   // query: 2 columns, then padding
+        CHECK("psgp_formula_and_clamps", ok);
+    }
+    // ---- removeGappyColumns / addGappyColumnsBack round trip (alignment-helper.cpp:74-166,324-375) ----
+    {
+        Params p(opt, 'n');
+        Node a("a", 0), b("b", 0);
+        a.alnNum = 10; b.alnNum = 10; a.alnLen = 6; b.alnLen = 5;
+        NodePair np{&a, &b};
+        const int memLen = 6;
+        std::vector<float> f(6 * 2 * memLen, 0.0f);
+        auto set = [&](int side, int col, int letter, float gaps) { f[6 * (side * memLen + col) + letter] = 10 - gaps; f[6 * (side * memLen + col) + 5] = gaps; };
+        // ref: cols 2,3 gappy (>95%); query: col 0 gappy and col 4 gappy
+        for (int c = 0; c < 6; ++c) set(0, c, c % 4, (c == 2 || c == 3) ? 9.8f : 0.0f);
+        for (int c = 0; c < 5; ++c) set(1, c, (c + 1) % 4, (c == 0 || c == 4) ? 10.0f : 1.0f);
+        std::pair<IntPairVec, IntPairVec> g;
+        IntPair lens{6, 5};
+        alignment_helper::removeGappyColumns(f.data(), np, &opt, g, memLen, lens, 0);
+        bool ok = lens.first == 4 && lens.second == 3 && g.first.size() == 1 && g.first[0] == IntPair(2, 2) && g.second.size() == 2 &&
+                  g.second[0] == IntPair(0, 1) && g.second[1] == IntPair(4, 1);
+        ok = ok && f[6 * 2 + 0] == 10 && f[6 * 3 + 1] == 10 && f[6 * 4 + 0] == 0;      // ref cols 4,5 moved up, tail zeroed
+        CHECK("remove_gappy_columns", ok);
+        alnPath before = {0, 0, 0, 2}, after;                        // reduced path: 4 ref cols x 3 query cols
+        alignment_helper::addGappyColumnsBack(before, after, g, p, {4, 3}, {"ACGTAC", "CGTAC"});
+        // query col0 is gappy at the very start -> 1; two matches; ref gappy run (2,3) -> 22; match; ref col; query col4 gappy at the end -> 1
+        int r = 0, q = 0;
+        for (auto c : after) { r += (c != 1); q += (c != 2); }
+        CHECK("add_gappy_columns_back_consumes_original_lengths", r == 6 && q == 5 && pathStr(after) == "10022012");
+    }
+    // ---- pairwiseGlobal tie-breaks (alignment-helper.cpp:243-322) ----
+    {
+        Params p(opt, 'n');
+        alnPath a;
+        alignment_helper::pairwiseGlobal("ACGT", "ACGT", a, p);
+        bool ok = pathStr(a) == "0000";
+        alignment_helper::pairwiseGlobal("AC", "ACGT", a, p);        // leading gaps are free (row/column 0 are zero), trailing ones are not:
+        ok = ok && pathStr(a) == "1100";                             // two transitions (-8) beat two matches plus a trailing gap (36-55)
+        alignment_helper::pairwiseGlobal("", "ACG", a, p);
+        ok = ok && pathStr(a) == "111";
+        alignment_helper::pairwiseGlobal("AC", "", a, p);
+        ok = ok && pathStr(a) == "22";
+        CHECK("pairwise_global_paths", ok);
+    }
+    // ---- updateFrequency (alignment-helper.cpp:506-539) ----
+    {
+        Node a("a", 0), b("b", 0);
+        a.msaFreq = {{1, 0, 0, 0, 0, 0}, {0, 2, 0, 0, 0, 0}};
+        b.msaFreq = {{0, 0, 3, 0, 0, 0}, {0, 0, 0, 4, 0, 1}};
+        NodePair np{&a, &b};
+        alnPath path = {0, 1, 2};
+        SequenceDB db;
+        alignment_helper::updateFrequency(np, &db, path, {0.5f, 0.25f});
+        bool ok = a.msaFreq.size() == 3 && b.msaFreq.empty() && a.alnLen == 3;
+        ok = ok && a.msaFreq[0][0] == 1 && a.msaFreq[0][2] == 3;                        // column from both
+        ok = ok && a.msaFreq[1][3] == 4 && a.msaFreq[1][5] == 1.5f;                      // query column + refWeight in the gap bin
+        ok = ok && a.msaFreq[2][1] == 2 && a.msaFreq[2][5] == 0.25f;                     // ref column + qryWeight in the gap bin
+        CHECK("update_frequency", ok);
+    }
+    // ---- Newick quirks (tree.cpp:59-223) and the level schedule (progressive.cpp:10-124) ----
+    {
+        const std::string f = tmp + "/kat.nwk";
+        { std::ofstream o(f); o << "((A:0.1,B:0.2):0.05,(C,D:0.4),E:0.3);\n"; }
+        Tree T(f);
+        bool ok = T.allNodes.size() == 8 && T.root->identifier == "node_1" && T.root->children.size() == 3 && T.m_numLeaves == 5;
+        ok = ok && T.allNodes["node_2"]->branchLength == 0.05f && T.allNodes["A"]->branchLength == 0.1f;
+        ok = ok && T.allNodes["node_3"]->branchLength == 0.4f;      // ")" without ":" reuses the piece's previous number (D:0.4)
+        ok = ok && T.allNodes["C"]->branchLength == 0.05f;          // missing length followed by ',' -> 0 -> smallest positive length
+        ok = ok && T.allNodes["E"]->weight > 0 && T.root->branchLength == 0;
+        float maxw = 0; for (auto &kv : T.allNodes) if (kv.second->is_leaf()) maxw = std::max(maxw, kv.second->weight);
+        ok = ok && maxw == 1.0f;                                     // calSeqWeight normalises to max 1
+        CHECK("newick_parse_quirks", ok);
+        phylogeny::assignSinglePartition(T.root);
+        Tree *sub = new Tree(T.root, true);                          // binarise + reroot at the diameter centre
+        bool bin = true; size_t leaves = 0;
+        std::vector<Node *> st{sub->root};                           // (allNodes may keep spliced-out unary nodes; walk the tree itself)
+        while (!st.empty()) {
+            Node *n = st.back(); st.pop_back();
+            if (n->is_leaf()) ++leaves; else bin = bin && n->children.size() == 2;
+            for (Node *c : n->children) { bin = bin && c->parent == n; st.push_back(c); }
+        }
+        CHECK("reroot_gives_binary_tree_with_all_leaves", bin && leaves == 5);
+        std::vector<NodePairVec> levels;
+        progressive::scheduling(sub->root, levels, 0);
+        size_t pairs = 0; for (auto &l : levels) pairs += l.size();
+        CHECK("schedule_has_n_minus_1_pairs", pairs == 4 && !levels.empty() && !levels[0].empty());
+        delete sub;
+    }
+    return g_fail ? 1 : 0;
+}

@@ -113,3 +113,45 @@ def test_protein_multi_tile_and_wildcard(gpu):
 def test_protein_2k(gpu):
     batch = synth.make_level_batch(6, 2000, P=synth.PROT_P, members=((1, 6), (1, 6)), seed=29, sub=0.2)
     _compare(gpu, batch, matrix=MP)
+
+
+# ---- device-resident entry point (twl_align_batch_device: HBM in, HBM out; what bench.py times) ----
+def test_device_pointer_form_equals_host_form(gpu):
+    import torch
+
+    batch = synth.make_level_batch(20, 900, members=((1, 6), (1, 6)), seed=41, length_jitter=0.3)
+    p = gpu.make_params(M)
+    a_host, n_host, e_host = gpu.align_batch(p, batch)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(getattr(batch, k))).to(dev) for k in ("freq", "gap_open", "gap_extend", "len", "num")}
+    n, sl = batch.n_pairs, batch.seq_len
+    aln = torch.zeros((n, 2 * sl), dtype=torch.int8, device=dev)
+    alen = torch.zeros(n, dtype=torch.int32, device=dev)
+    err = torch.full((n,), 7, dtype=torch.int16, device=dev)
+    for _ in range(2):      # twice: buffers and the work queue are reused across calls
+        gpu.align_batch_device(p, n, sl, t["freq"].data_ptr(), t["gap_open"].data_ptr(), t["gap_extend"].data_ptr(), t["len"].data_ptr(),
+                               t["num"].data_ptr(), aln.data_ptr(), alen.data_ptr(), err.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(alen.cpu().numpy(), n_host) and np.array_equal(err.cpu().numpy(), e_host)
+        d_aln = aln.cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(d_aln[i, : n_host[i]], a_host[i, : n_host[i]])
+    st = gpu.get_stats(0)
+    cells = gpu.get_pair_cells(n)
+    assert int(cells.sum()) == st.band_cells and st.kernel_ms > 0
+    oa, on, oerr, ost = O.align_batch(O.make_params(M), batch, threads=8)
+    assert st.band_cells == ost.cells
+
+
+def test_many_small_pairs_more_than_workgroups(gpu):
+    # more work items than persistent workgroups: exercises the device-side work queue
+    batch = synth.make_level_batch(48, 120, members=((1, 3), (1, 3)), seed=43, length_jitter=0.5)
+    idx = np.arange(1500) % 48
+    big = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq[idx], gap_open=batch.gap_open[idx], gap_extend=batch.gap_extend[idx],
+                           len=batch.len[idx], num=batch.num[idx])
+    p = gpu.make_params(M)
+    aln, n, err = gpu.align_batch(p, big)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M), batch, threads=8)
+    assert np.array_equal(n, on[idx]) and np.array_equal(err, oerr[idx])
+    for i in range(big.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[idx[i], : on[idx[i]]])
