@@ -44,6 +44,12 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise TwlError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch-ROCm bundles its own libamdhip64.  Two HIP runtimes in one process each try to own the device and the second
+        # one sees "no GPUs", so when torch is installed it is imported first and our library binds to the runtime already loaded.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.twl_last_error.restype = C.c_char_p
         lib.twl_version.restype = C.c_char_p
