@@ -419,10 +419,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const bool Dptr = delExt >= delOp;
                         const float Iv = Iptr ? insExt : insOp;
                         const float Dv = Dptr ? delExt : delOp;
-                        // :477-494 as three compares: M wins ties, then D beats I on equality
-                        const bool c1 = match >= Iv, c2 = match >= Dv, c3 = Iv > Dv;
-                        const bool isM = c1 && c2, isI = !c1 && c3;
-                        float Sv = isM ? match : (isI ? Iv : Dv);
+                        // :477-494 without combining lane masks: G = (I > D ? I : D) is the better gap state (D wins ties),
+                        // M wins when match >= G (match >= I and match >= D); otherwise the state is I iff I > D
+                        const bool gapIsI = Iv > Dv;
+                        const float Gv = gapIsI ? Iv : Dv;
+                        const bool isM = match >= Gv;
+                        float Sv = isM ? match : Gv;
                         Sv = (Sv < thr) ? -inf : Sv;                                            // :495-497
 
                         // Out-of-band lanes compute too; their registers are never consumed (every reader tests the stored
@@ -434,7 +436,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                             // :534-538; offsetUp >= 0 always holds; above the stored band the reference reads the stale slot
                             const int cdUp = up_ok ? CD1[r] : staleCD;
                             int CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
-                            int CSn = isM ? LCS2[r] : (isI ? CIn : CDn);
+                            const int viaGap = gapIsI ? CIn : CDn;
+                            int CSn = isM ? LCS2[r] : viaGap;
                             if (__builtin_expect(k <= marker, 0)) {          // ... and the two diagonals where the markers are planted
                                 const int i16 = i & 0xFFFF;
                                 if (k == marker) { CSn = i16; CIn = (1 << 16) | i16; CDn = (2 << 16) | i16; }
@@ -445,15 +448,17 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         }
                         S1[r] = Sv; I1[r] = Iv; D1[r] = Dv;
                         if (k <= marker) {                                                      // :548-557
-                            const uint32_t nib = (isM ? 0u : (isI ? 1u : 2u)) | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
+                            const uint32_t gapState = gapIsI ? 1u : 2u;
+                            const uint32_t nib = (isM ? 0u : gapState) | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
                             tbacc[r] |= nib << (4 * (k & 7));
                             tbdirty[r] = true;
                         }
                         // wave summaries -> LDS reduction slot of this diagonal
-                        const unsigned long long vm = __builtin_amdgcn_ballot_w64(inband && Sv > -inf);
-                        const bool raise = __builtin_amdgcn_ballot_w64(inband && Sv > msp) != 0ull;
+                        const float Sin = inband ? Sv : -inf;             // out-of-band lanes take no part in the reductions
+                        const unsigned long long vm = __builtin_amdgcn_ballot_w64(Sin > -inf);
+                        const bool raise = __builtin_amdgcn_ballot_w64(Sin > msp) != 0ull;
                         int wkey = (int)0x80000000;                      // neutral for max
-                        if (raise) wkey = f2key(wave_max_f32(inband ? Sv : -inf));
+                        if (raise) wkey = f2key(wave_max_f32(Sin));
                         const int firstRow = vm ? b + (int)__builtin_ctzll(vm) : 0x7fffffff;     // neutral for min
                         const int lastRow = vm ? b + 63 - (int)__builtin_clzll(vm) : -1;          // neutral for max
                         if (lane == 63) {        // the block's single-lane side effects: three reductions and the mailbox for block b+64

@@ -242,6 +242,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w16m2") rc = launch_dp<6, 16, 1, false, true, true, 1, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w16prem1") rc = launch_dp<6, 16, 1, true, true, true, 1, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w8") rc = launch_dp<6, 8, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w4r4") rc = launch_dp<6, 4, 4, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
     else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
