@@ -166,7 +166,7 @@ static void tile_run(const ctx_t *c, int32_t *reference_idx, int32_t *query_idx,
     const float gapExtendAtEnds = p->gap_extend;
 
     if (reference_length < 0 || query_length < 0) {          /* :313-320 */
-        *err = 3; aln->n = 0; return;
+        *err = 3; aln->n = 0; if (c->st) { c->st->err3_reason = 1; c->st->err3_tile = tile; } return;
     }
 
     /* :277-311 rotating rows; one guard element so that the reference's read at
@@ -281,8 +281,12 @@ static void tile_run(const ctx_t *c, int32_t *reference_idx, int32_t *query_idx,
                 else CD[b0][offset] = (offsetUp >= 0 && CS[c1][offsetUp] != -1) ? CS[c1][offsetUp] : D_BOUNDARY;
                 if (ptr == 0) {
                     if (!diag_ok && c->st) c->st->oob_diag++;
-                    /* the reference reads this unguarded (:541); keep it inside our row */
-                    CS[c0][offset] = (offsetDiag >= 0 && (size_t)offsetDiag < rowlen) ? CS[c2][offsetDiag] : -1;
+                    /* The reference reads CS[(k+1)%3][offsetDiag] unguarded (:541).  Without a diagonal predecessor that offset is
+                       negative or past the stored band (memory outside the row, or a stale slot): undefined in the reference.
+                       Defined here, and identically in the HIP kernel, as "unset" (-1).  It arises for pruned edge cells (trimmed
+                       on the same diagonal, value never used) and for first-row/column cells of tile 0 that are still in the band
+                       at the marker (tiny markers, or one sequence far shorter than the other). */
+                    CS[c0][offset] = diag_ok ? CS[c2][offsetDiag] : -1;
                 } else if (ptr == 1) CS[c0][offset] = CI[b0][offset];
                 else CS[c0][offset] = CD[b0][offset];
             }
@@ -341,7 +345,7 @@ static void tile_run(const ctx_t *c, int32_t *reference_idx, int32_t *query_idx,
         /* :618-622 == :636-641.  A boundary sentinel (-2/-3) or an unset -1 here makes the
            reference index its traceback store far out of range (undefined behaviour); we
            report that as errorType 3 instead of reproducing the fault. */
-        if (tb_state > 3 || n_ftr < 2) bad_conv = 1;
+        if (tb_state > 3 || n_ftr < 2) bad_conv = 2;
         else {
             conv_ref_idx = marker - conv_query_idx - ((tb_state == 3) ? 1 : 0);
             tb_start_addr = ftr_addr - ftr_len[n_ftr - 1];
@@ -349,17 +353,18 @@ static void tile_run(const ctx_t *c, int32_t *reference_idx, int32_t *query_idx,
                 ? tb_start_addr - ftr_len[n_ftr - 2] + (conv_query_idx - ftr_low[n_ftr - 2])
                 : tb_start_addr + (conv_query_idx - ftr_low[n_ftr - 1]);
             tb_start_ftr = (tb_state == 3) ? n_ftr - 2 : n_ftr - 1;
-            if (tb_start_addr < 0 || (size_t)tb_start_addr >= tb.n || conv_ref_idx < 0) bad_conv = 1;
+            if (tb_start_addr < 0 || (size_t)tb_start_addr >= tb.n) bad_conv = 3;
+            else if (conv_ref_idx < 0) bad_conv = 4;
         }
     }
-    if (bad_conv) { *err = 3; *last_tile = 1; aln->n = 0; TILE_FREE(); return; }
+    if (bad_conv) { *err = 3; *last_tile = 1; aln->n = 0; if (c->st) { c->st->err3_reason = bad_conv; c->st->err3_tile = tile; } TILE_FREE(); return; }
 
     *reference_idx += conv_ref_idx;                           /* :654-655 */
     *query_idx += conv_query_idx;
     reference_length = c->R - *reference_idx;
     query_length = c->Q - *query_idx;
     if (reference_length < 0 || query_length < 0) {           /* :659-668 */
-        *err = 3; aln->n = 0; TILE_FREE(); return;
+        *err = 3; aln->n = 0; if (c->st) { c->st->err3_reason = 5; c->st->err3_tile = tile; } TILE_FREE(); return;
     }
     if (*reference_idx == c->R - 1 && *query_idx < c->Q - 1) {    /* :671-674 */
         for (int32_t q = 0; q < c->Q - *query_idx - 1; ++q) bytes_push(aln, 1);
@@ -398,7 +403,7 @@ int twlo_align_pair(const twlo_params *p, const float *ref, int32_t R, const flo
         if (tile_aln.n == 0) { free(tile_aln.d); *aln_len = 0; return 0; }      /* :94-97 */
         for (long i = (long)tile_aln.n - 1; i >= 0; --i) {                     /* :98-102 */
             if (i == (long)tile_aln.n - 1 && tile > 0) continue;
-            if (n >= R + Q) { free(tile_aln.d); *err = 3; *aln_len = 0; return 0; }
+            if (n >= R + Q) { free(tile_aln.d); *err = 3; *aln_len = 0; if (stats) stats->err3_reason = 6; return 0; }
             aln[n++] = tile_aln.d[i];
         }
         tile++;
@@ -438,6 +443,7 @@ int twlo_align_batch(const twlo_params *p, int32_t n_pairs, int32_t seq_len, con
             total.cells += st.cells; total.diags += st.diags; total.tiles += st.tiles;
             if (st.max_width > total.max_width) total.max_width = st.max_width;
             total.empty_reduce += st.empty_reduce; total.oob_diag += st.oob_diag;
+            if (st.err3_reason) { total.err3_reason = st.err3_reason; total.err3_tile = st.err3_tile; }
         }
     }
     if (stats) *stats = total;

@@ -46,6 +46,8 @@ typedef struct {
     int32_t  max_width;
     uint64_t empty_reduce; /* Reduction_tree called on an all-pruned diagonal (stale read, :586-588) */
     uint64_t oob_diag;     /* ptr==0 with no valid diagonal predecessor (unguarded read, :541) */
+    int32_t  err3_reason;  /* debug: which errorType-3 exit fired (1 entry lengths, 2 marker state, 3 start address, 4 negative ref step, 5 lengths after advance, 6 path overflow) */
+    int32_t  err3_tile;
 } twlo_stats;
 
 /* Optional per-diagonal trace hook (debug aid for the HIP kernel). */

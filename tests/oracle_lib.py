@@ -20,7 +20,7 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("cells", C.c_uint64), ("diags", C.c_uint64), ("tiles", C.c_int32), ("max_width", C.c_int32),
-                ("empty_reduce", C.c_uint64), ("oob_diag", C.c_uint64)]
+                ("empty_reduce", C.c_uint64), ("oob_diag", C.c_uint64), ("err3_reason", C.c_int32), ("err3_tile", C.c_int32)]
 
 
 TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float)

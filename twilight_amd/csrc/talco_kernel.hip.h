@@ -179,7 +179,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         int ref_idx = 0, qry_idx = 0, tile = 0, pos = 0, err = 0;
         bool last_tile = (R <= 0 || Q <= 0);
         unsigned long long cells = 0;
-        int steps_left = (int)min(32ll * (R + Q) + a.step_slack, 0x7fffffffll);   // watchdog: every loop below is bounded by it
+        // watchdog: every loop below is bounded by it.  A tile advances at least marker-1 cells and runs at most R+Q diagonals.
+        int steps_left = (int)min((long long)(R + Q + 2) * ((R + Q) / (max(a.marker, 2) - 1) + 4) + a.step_slack, 0x7fffffffll);
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
@@ -437,7 +438,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                             const int cdUp = up_ok ? CD1[r] : staleCD;
                             int CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
                             const int viaGap = gapIsI ? CIn : CDn;
-                            int CSn = isM ? LCS2[r] : viaGap;
+                            // M without a diagonal predecessor (pruned edge cells; first row/column of tile 0 at the marker): the reference
+                            // reads outside its row there (:541); defined as "unset", as in the oracle
+                            int CSn = isM ? (diag_ok ? LCS2[r] : -1) : viaGap;
                             if (__builtin_expect(k <= marker, 0)) {          // ... and the two diagonals where the markers are planted
                                 const int i16 = i & 0xFFFF;
                                 if (k == marker) { CSn = i16; CIn = (1 << 16) | i16; CDn = (2 << 16) | i16; }
