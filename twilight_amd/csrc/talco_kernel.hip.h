@@ -53,6 +53,12 @@ struct KArgs {
     float M[441];             // scoreMatrix[l][m] row-major, (P-1)x(P-1): 5x5 or 21x21
 };
 
+#ifdef TWL_KERNEL_STAMPS
+#define TWL_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define TWL_STAMP(var)
+#endif
+
 #ifdef TWL_KERNEL_DEBUG
 __device__ __forceinline__ void heartbeat(const KArgs &a, int slot, int v)
 {
@@ -182,6 +188,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         // watchdog: every loop below is bounded by it.  A tile advances at least marker-1 cells and runs at most R+Q diagonals.
         int steps_left = (int)min((long long)(R + Q + 2) * ((R + Q) / (max(a.marker, 2) - 1) + 4) + a.step_slack, 0x7fffffffll);
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
+#ifdef TWL_KERNEL_STAMPS
+        unsigned long long st_slots = 0, st_bar = 0, st_post = 0, st_n = 0, st_act = 0;
+        const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
             int refLen = R - ref_idx, qLen = Q - qry_idx;
@@ -269,6 +279,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             heartbeat(a, 2, tile);
             for (; k < kEnd; ++k) {
                 heartbeat(a, 3, k);
+                TWL_STAMP(t_head);
                 // one rarely-taken exit for all four stop conditions (decoded after the loop)
                 if (__builtin_expect((--steps_left < 0) | (Lk > Uk) | (Uk - Lk + 1 > fLen) | ((Uk >> 6) - (Lk >> 6) >= NV), 0)) {
                     tile_err = (steps_left < 0) ? 3 : (Lk > Uk) ? 1                       // :323-329 band emptied by X-drop
@@ -479,7 +490,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                     uph[r] += 1; if (uph[r] == CAP) uph[r] = 0;
                 }
                 heartbeat(a, 4, k);
+                TWL_STAMP(t_slots);
                 __syncthreads();
+                TWL_STAMP(t_bar);
                 heartbeat(a, 5, k);
                 const int rs3_now = rs3;
                 rs3 = (rs3 == 2) ? 0 : rs3 + 1;
@@ -492,7 +505,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 const int newU = anyValid ? glast : Lk - 1;
                 mspKey = max(mspKey, gkey);                                   // :501-503
 
-                if (!converged && k < kEnd - 1) {                             // :585-595
+                // Before diagonal marker-1 every CS entry is the initial -1, so conv_S = -1 and nothing can converge (:585-595
+                // reduce to prev_conv_s = -1, which it already is): the whole test is skipped with one branch.
+                if (__builtin_expect(pb && !converged && k < kEnd - 1, 0)) {   // :585-595
                     int conv_S = -1;
                     bool all3 = false;
                     if (k == marker - 1) conv_S = (newL == newU) ? ((3 << 16) | (newL & 0xFFFF)) : -1;
@@ -542,6 +557,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 }
                 msKey = max(mspKey, 0);                                       // :607  max(0, max_score_prime)
                 last_k = k;
+#ifdef TWL_KERNEL_STAMPS
+                {
+                    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+                    st_slots += t_slots - t_head; st_bar += t_bar - t_slots; st_post += t_end - t_bar; st_n += 1;
+                    st_act += (64 * blk[0] <= Uk + 1 && 64 * blk[0] + 63 >= Lk) ? 1 : 0;
+                }
+#endif
                 if (converged && msKey > convKey) { conv_logic = true; break; }          // :609-612
             }
 
@@ -640,6 +662,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         }
 
         heartbeat(a, 9, err);
+#ifdef TWL_KERNEL_STAMPS
+        if (a.dbg && lane == 0 && pair == 0) {      // per wave of the workgroup that aligned pair 0: cycle sums per segment
+            long long *g = reinterpret_cast<long long *>(a.dbg) + 8 + 8 * w;
+            g[0] = (long long)st_slots; g[1] = (long long)st_bar; g[2] = (long long)st_post; g[3] = (long long)st_n; g[4] = (long long)st_act;
+            g[5] = (long long)(__builtin_amdgcn_s_memtime() - st_t0);
+        }
+#endif
         __syncthreads();
         if (threadIdx.x == 0) {
             a.err[pair] = (int16_t)err;

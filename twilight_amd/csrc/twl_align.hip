@@ -204,7 +204,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     const bool want_dbg = getenv("TWL_DEBUG") != nullptr;
     a.dbg = nullptr;
     if (want_dbg) {
-        if ((rc = d->dbg.ensure((size_t)n_pairs * 16 * sizeof(int32_t)))) return rc;
+        if ((rc = d->dbg.ensure(std::max<size_t>((size_t)n_pairs * 16 * sizeof(int32_t), 1024)))) return rc;
         HIP_TRY(hipMemsetAsync(d->dbg.p, 0xff, (size_t)n_pairs * 16 * sizeof(int32_t), st));
         a.dbg = (int32_t *)d->dbg.p;
     }
@@ -483,6 +483,15 @@ int twl_get_stats(int device, twl_stats *out)
     if (rc) return rc;
     *out = d->stats;
     return TWL_OK;
+}
+
+// debug aid (not in the public header): first `n` 64-bit words of the last call's debug record (TWL_DEBUG=1)
+int twl_debug_read(int device, long long *out, int32_t n)
+{
+    Device *d = nullptr;
+    if (find_dev(device, &d)) return TWL_ERR_BAD_ARGUMENT;
+    if (!d->dbg.p || (size_t)n * 8 > d->dbg.cap) return TWL_ERR_BAD_ARGUMENT;
+    return hipMemcpy(out, d->dbg.p, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWL_OK : TWL_ERR_HIP;
 }
 
 int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)
