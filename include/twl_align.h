@@ -78,7 +78,8 @@ const char *twl_version(void);
  *   gap_extend  [n_pairs][2][seq_len]     position-specific gap extend
  *   len         [n_pairs][2]              R, Q (after gappy-column removal)
  *   num         [n_pairs][2]              member-sequence counts; denominator = float(R_num)*float(Q_num)
- *   aln_out     [n_pairs][2*seq_len]      path codes 0 (both) / 1 (gap in ref, consumes query) / 2 (gap in query), forward order
+ *   aln_out     [n_pairs][2*seq_len]      path codes 0 (both) / 1 (gap in ref, consumes query) / 2 (gap in query), forward order;
+ *                                         bytes past aln_len_out[i] in row i are unspecified
  *   aln_len_out [n_pairs]                 path length; 0 if an input side is empty (caller emits the all-gap path,
  *                                         alignment-cpu.cpp:89-90) or if err_out != 0
  *   err_out     [n_pairs]                 errorType 0 ok / 1 X-drop emptied the band / 2 band wider than flen / 3 inconsistency

@@ -44,9 +44,12 @@ def main():
         print(r.stderr[-3000:]); sys.exit(1)
     tail = [l for l in r.stderr.splitlines() if l.startswith("Wrote")][-1]
     levels = [l for l in r.stderr.splitlines() if l.startswith("Level ")]
-    res["gpu"] = {"wall_s": wall, "summary": tail, "levels": len(levels), "md5": hashlib.md5(open(gpu_out, "rb").read()).hexdigest()}
+    phases = [l for l in r.stderr.splitlines() if l.startswith("Host phases") or l.startswith("Driver phases")]
+    res["gpu"] = {"wall_s": wall, "summary": tail, "phases": phases, "levels": len(levels), "md5": hashlib.md5(open(gpu_out, "rb").read()).hexdigest()}
     first = open(gpu_out).readlines()[1].strip()
     res["aln_len"] = len(first)
+    if a.out:
+        open(a.out + ".stderr.txt", "w").write(r.stderr)
     if a.cpu:
         cpu_out = os.path.join(d, "cpu.aln")
         wall_c, rc = run([os.path.join(ROOT, "oracle", "e2e_oracle"), "-t", os.path.join(d, "t.nwk"), "-i", os.path.join(d, "s.fa"), "-o", cpu_out, "--type", a.type])

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtwl_align.so")
+LIB_PATH = os.environ.get("TWL_LIB") or os.path.join(_HERE, "libtwl_align.so")   # TWL_LIB: development override for A/B builds
 TWL_MAX_MATRIX = 21
 
 _lib = None

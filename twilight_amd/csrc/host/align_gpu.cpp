@@ -9,10 +9,13 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <iostream>
 #include <map>
+#include <string>
 #include <tuple>
 
 namespace msa {
@@ -20,15 +23,28 @@ namespace progressive {
 namespace gpu {
 
 LevelTotals g_totals;
+static inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static std::vector<int> g_devices;
+
+static std::future<std::pair<int, std::string>> g_initJob;   // (return code, twl_last_error() of the helper thread)
+
+// Starts twl_init on a helper thread so that HIP start-up overlaps tree and FASTA reading; ensureInit() joins it.
+void beginInit(Option *option)
+{
+    g_devices = option->gpuIdx.empty() ? std::vector<int>{0} : option->gpuIdx;
+    g_initJob = std::async(std::launch::async, [] {
+        const int rc = twl_init(g_devices.data(), (int)g_devices.size());
+        return std::make_pair(rc, std::string(rc == TWL_OK ? "" : twl_last_error()));
+    });
+}
 
 static void ensureInit(Option *option)
 {
     static bool done = false;
     if (done) return;
-    int rc = option->gpuIdx.empty() ? twl_init(nullptr, 0) : twl_init(option->gpuIdx.data(), (int)option->gpuIdx.size());
-    if (rc != TWL_OK) { std::cerr << "ERROR: twl_init failed: " << twl_last_error() << '\n'; exit(1); }
-    g_devices = option->gpuIdx.empty() ? std::vector<int>{0} : option->gpuIdx;
+    if (!g_initJob.valid()) beginInit(option);
+    const auto res = g_initJob.get();
+    if (res.first != TWL_OK) { std::cerr << "ERROR: twl_init failed: " << res.second << '\n'; exit(1); }
     done = true;
 }
 
@@ -48,42 +64,64 @@ static twl_params baseParams(Params &param)          // == Talco_xdrop::Params(m
     return tp;
 }
 
-// Align the pairs `ids` (indices into `in`) with one parameter set; results land in paths/errs.
-static void runBatch(const twl_params &tp, const std::vector<int> &ids, std::vector<PairInputs> &in, int P, std::vector<alnPath> &paths,
-                     std::vector<int16_t> &errs)
-{
-    const int n = (int)ids.size();
-    if (n == 0) return;
-    int seqLen = 1;
-    for (int id : ids) seqLen = std::max({seqLen, in[id].lens.first, in[id].lens.second});
-    std::vector<float> freq((size_t)n * 2 * seqLen * P, 0.0f), gop((size_t)n * 2 * seqLen, 0.0f), gex((size_t)n * 2 * seqLen, 0.0f);
-    std::vector<int32_t> len(2 * (size_t)n), num(2 * (size_t)n), alnLen(n);
-    std::vector<int16_t> err(n);
-    std::vector<int8_t> aln((size_t)n * 2 * seqLen);
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int t = 0; t < n; ++t) {
-        const PairInputs &pi = in[ids[t]];
-        for (int side = 0; side < 2; ++side) {
-            const int L = side ? pi.lens.second : pi.lens.first;
-            const float *src = pi.freq.data() + (size_t)side * P * pi.memLen;
-            float *dst = &freq[((size_t)t * 2 + side) * seqLen * P];
-            std::copy(src, src + (size_t)L * P, dst);
-            std::copy(pi.gapOp.data() + (size_t)side * pi.memLen, pi.gapOp.data() + (size_t)side * pi.memLen + L, &gop[((size_t)t * 2 + side) * seqLen]);
-            std::copy(pi.gapEx.data() + (size_t)side * pi.memLen, pi.gapEx.data() + (size_t)side * pi.memLen + L, &gex[((size_t)t * 2 + side) * seqLen]);
-        }
-        len[2 * t] = pi.lens.first; len[2 * t + 1] = pi.lens.second;
-        num[2 * t] = pi.refNum; num[2 * t + 1] = pi.qryNum;
+// Level staging: the flat arrays of the C ABI ([pair][2][stride][P] etc.), kept for the whole run and only ever grown.  Each
+// pair's profile and gap penalties are built in place in its slot (preparePair), so nothing is copied on the host and the pages
+// are faulted in once, by the threads that fill them.
+struct Staging {
+    float *freq = nullptr, *gop = nullptr, *gex = nullptr;
+    int8_t *aln = nullptr;
+    size_t capFreq = 0, capGop = 0, capGex = 0, capAln = 0;
+    template <class T> static void grow(T *&p, size_t &cap, size_t need)
+    {
+        if (need <= cap) return;
+        std::free(p);
+        cap = need + need / 8;
+        p = static_cast<T *>(std::malloc(cap * sizeof(T)));
+        if (!p) { std::cerr << "ERROR: out of host memory for the level staging (" << cap * sizeof(T) << " bytes)\n"; exit(1); }
     }
-    int rc = twl_align_batch(&tp, n, seqLen, freq.data(), gop.data(), gex.data(), len.data(), num.data(), aln.data(), alnLen.data(), err.data());
+    void ensure(size_t n, size_t stride, size_t P)
+    {
+        grow(freq, capFreq, n * 2 * stride * P);
+        grow(gop, capGop, n * 2 * stride);
+        grow(gex, capGex, n * 2 * stride);
+        grow(aln, capAln, n * 2 * stride);
+    }
+};
+static Staging g_stage;
+
+// Align the pairs `ids` (ascending indices into the level's slots) with one parameter set; results land in paths/errs.  The
+// call covers the slot span [ids.front(), ids.back()]; slots in the span that are not in `ids` are passed with length 0, which the
+// boundary answers with aln_len 0 without running them.
+static void runBatch(const twl_params &tp, const std::vector<int> &ids, const std::vector<PairInputs> &in, int P, int stride,
+                     std::vector<alnPath> &paths, std::vector<int16_t> &errs)
+{
+    if (ids.empty()) return;
+    const double tStage = nowMs();
+    const int first = ids.front(), n = ids.back() - first + 1;
+    std::vector<int32_t> len(2 * (size_t)n, 0), num(2 * (size_t)n, 1), alnLen(n, 0);
+    std::vector<int16_t> err(n, 0);
+    for (int id : ids) {
+        const PairInputs &pi = in[id];
+        len[2 * (id - first)] = pi.lens.first; len[2 * (id - first) + 1] = pi.lens.second;
+        num[2 * (id - first)] = pi.refNum; num[2 * (id - first) + 1] = pi.qryNum;
+    }
+    const size_t sl = (size_t)stride;
+    int8_t *aln = g_stage.aln + (size_t)first * 2 * sl;
+    const double tCall = nowMs();
+    g_totals.stage_ms += tCall - tStage;
+    int rc = twl_align_batch(&tp, n, stride, g_stage.freq + (size_t)first * 2 * sl * P, g_stage.gop + (size_t)first * 2 * sl,
+                             g_stage.gex + (size_t)first * 2 * sl, len.data(), num.data(), aln, alnLen.data(), err.data());
     if (rc != TWL_OK) { std::cerr << "ERROR: twl_align_batch failed (" << rc << "): " << twl_last_error() << '\n'; exit(1); }
+    g_totals.call_ms += nowMs() - tCall;
     for (int dev : g_devices) {
         twl_stats st{};
         if (twl_get_stats(dev, &st) == TWL_OK) { g_totals.band_cells += st.band_cells; g_totals.kernel_ms += st.kernel_ms; g_totals.total_ms += st.total_ms; }
     }
-    g_totals.pairs += n;
-    for (int t = 0; t < n; ++t) {
-        errs[ids[t]] = err[t];
-        paths[ids[t]].assign(&aln[(size_t)t * 2 * seqLen], &aln[(size_t)t * 2 * seqLen] + (err[t] == 0 ? alnLen[t] : 0));
+    g_totals.pairs += ids.size();
+    for (int id : ids) {
+        const int t = id - first;
+        errs[id] = err[t];
+        paths[id].assign(aln + (size_t)t * 2 * sl, aln + (size_t)t * 2 * sl + (err[t] == 0 ? alnLen[t] : 0));
     }
 }
 
@@ -94,10 +132,20 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
     const int n = (int)nodes.size();
     const int P = param.matrixSize + 1;
     std::vector<PairInputs> in(n);
+    const double tPrep = nowMs();
+    const LevelTotals before = g_totals;
     // wide levels: one pair per thread; narrow levels (upper tree): pairs in turn, the helpers' own column/sequence loops fan out
     const bool acrossPairs = n >= omp_get_max_threads();
+    int stride = 1;
+    for (auto &pr : nodes) stride = std::max({stride, pr.first->getAlnLen(database->currentTask), pr.second->getAlnLen(database->currentTask)});
+    g_stage.ensure((size_t)n, (size_t)stride, (size_t)P);
+    const size_t sl = (size_t)stride;
 #pragma omp parallel for schedule(dynamic, 1) if (acrossPairs)
-    for (int i = 0; i < n; ++i) preparePair(nodes[i], database, option, param, in[i]);       // alignment-cpu.cpp:50-93
+    for (int i = 0; i < n; ++i)                                                                 // alignment-cpu.cpp:50-93
+        preparePair(nodes[i], database, option, param, in[i], g_stage.freq + (size_t)i * 2 * sl * P, g_stage.gop + (size_t)i * 2 * sl,
+                    g_stage.gex + (size_t)i * 2 * sl, stride);
+
+    g_totals.prepare_ms += nowMs() - tPrep;
 
     std::vector<alnPath> paths(n);
     std::vector<int16_t> errs(n, 0);
@@ -111,10 +159,10 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
         (zg ? zeroGap : plain).push_back(i);
     }
     twl_params tp = baseParams(param);
-    runBatch(tp, plain, in, P, paths, errs);
+    runBatch(tp, plain, in, P, stride, paths, errs);
     twl_params tz = tp;
     tz.gap_char = 0;
-    runBatch(tz, zeroGap, in, P, paths, errs);
+    runBatch(tz, zeroGap, in, P, stride, paths, errs);
 
     // alignment-cpu.cpp:108-129: task 0 defers a failed pair; later tasks retry with a larger X-drop / band limit
     std::vector<int> fallbackPairs;
@@ -130,11 +178,12 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
             else { tr.xdrop = static_cast<int32_t>(tr.xdrop * 2); tr.flen = std::min(static_cast<int32_t>(tr.xdrop * 4) << 1, minLen); }
             if (option->printDetail) std::cout << "Retry pair No. " << i << "\txdrop " << tr.xdrop << " flen " << tr.flen << '\n';
             if (tr.flen > 4096) { std::cerr << "ERROR: retry needs an anti-diagonal limit of " << tr.flen << " > 4096, which this build's kernels do not cover.\n"; exit(1); }
-            runBatch(tr, std::vector<int>{i}, in, P, paths, errs);
+            runBatch(tr, std::vector<int>{i}, in, P, stride, paths, errs);
         }
     }
 
     std::vector<char> deferred(n, 0);
+    const double tFin = nowMs();
 #pragma omp parallel for schedule(dynamic, 1) if (acrossPairs)
     for (int i = 0; i < n; ++i) {                                                              // alignment-cpu.cpp:136-175
         // low-quality singleton rule (:136-144): such a pair is deferred whatever the DP said
@@ -142,9 +191,14 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
         finishPair(nodes[i], database, option, param, in[i], paths[i]);
         in[i] = PairInputs();                                                                   // release the profile buffers early
     }
+    g_totals.finish_ms += nowMs() - tFin;
     for (int i = 0; i < n; ++i)
         if (deferred[i]) fallbackPairs.push_back(i);
     if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
+    if (option->printDetail)
+        std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " stage " << g_totals.stage_ms - before.stage_ms << " call "
+                  << g_totals.call_ms - before.call_ms << " (kernel " << g_totals.kernel_ms - before.kernel_ms << ") finish " << g_totals.finish_ms - before.finish_ms
+                  << " whole " << nowMs() - tPrep << '\n';
 }
 
 }  // namespace gpu

@@ -79,16 +79,23 @@ bool parseCommandLine(int argc, char **argv, Option &o)
 
 int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput)
 {
+    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = clk();
     SequenceDB database;
     Params param(option, option.type);
     Tree *T = new Tree(option.treeFile);                                    // twilight-main.cpp:122
     phylogeny::assignSinglePartition(T->root);                              // :129-130 with maxSubtree = INT32_MAX
     Tree *subT = new Tree(T->root, option.reroot);                          // :145
+    const double t1 = clk();
     io::readSequences(option.seqFile, &database, &option, subT);           // :146
+    const double t2 = clk();
     progressive::msaOnSubtree(subT, &database, &option, param, kernel, deferredKernel);   // :148
+    const double t3 = clk();
     if (option.debug && !database.debug()) std::cerr << "WARNING: --check found an illegal alignment row.\n";
     const int alnLen = subT->root->getAlnLen(database.currentTask);
     if (writeOutput) io::writeFinalMSA(&database, &option, alnLen);        // :165
+    if (option.printDetail)
+        std::cerr << "Driver phases (s): tree " << t1 - t0 << ", read " << t2 - t1 << ", align " << t3 - t2 << ", write " << clk() - t3 << '\n';
     delete subT;
     delete T;
     return alnLen;

@@ -362,7 +362,8 @@ void fallback2cpu(std::vector<int> &fallbackPairs, NodePairVec &nodes, SequenceD
 namespace progressive {
 
 // alignment-cpu.cpp:50-66,72-93: everything a pair needs before the DP
-void preparePair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in)
+void preparePair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in, float *freqSlot, float *gapOpSlot,
+                 float *gapExSlot, int stride)
 {
     const int P = param.matrixSize + 1;
     in.refLen = nodes.first->getAlnLen(database->currentTask);
@@ -370,9 +371,17 @@ void preparePair(NodePair &nodes, SequenceDB *database, Option *option, Params &
     in.refNum = nodes.first->getAlnNum(database->currentTask);
     in.qryNum = nodes.second->getAlnNum(database->currentTask);
     in.memLen = std::max(in.refLen, in.qryLen);
-    in.freq.assign((size_t)P * 2 * in.memLen, 0.0f);
-    in.gapOp.assign((size_t)2 * in.memLen, 0.0f);
-    in.gapEx.assign((size_t)2 * in.memLen, 0.0f);
+    if (freqSlot) {
+        if (stride < in.memLen) { std::cerr << "ERROR: staging stride " << stride << " < profile length " << in.memLen << '\n'; exit(1); }
+        in.memLen = stride;
+        in.freq.bind(freqSlot, (size_t)P * 2 * stride);
+        in.gapOp.bind(gapOpSlot, (size_t)2 * stride);
+        in.gapEx.bind(gapExSlot, (size_t)2 * stride);
+    } else {
+        in.freq.assign((size_t)P * 2 * in.memLen, 0.0f);
+        in.gapOp.assign((size_t)2 * in.memLen, 0.0f);
+        in.gapEx.assign((size_t)2 * in.memLen, 0.0f);
+    }
     in.gappyColumns = {};
     in.consensus = {"", ""};
     in.lens = {in.refLen, in.qryLen};

@@ -14,11 +14,14 @@ int main(int argc, char **argv)
         return 1;
     }
     auto t0 = std::chrono::high_resolution_clock::now();
+    msa::progressive::gpu::beginInit(&option);
     // both passes run on the GPU level kernel (the reference hard-wires its CPU kernel for the deferred pass)
     const int alnLen = msa::runDefaultAlignment(option, msa::progressive::gpu::alignmentKernel_GPU, msa::progressive::gpu::alignmentKernel_GPU);
     const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     const auto &g = msa::progressive::gpu::g_totals;
     std::cerr << "Wrote " << option.outFile << " (length " << alnLen << ") in " << secs << " s; level kernel: " << g.pairs << " pairs, " << g.band_cells
               << " band cells, " << g.kernel_ms << " ms DP kernel, " << g.total_ms << " ms incl. transfers\n";
+    if (option.printDetail)
+        std::cerr << "Host phases (ms): prepare " << g.prepare_ms << ", stage " << g.stage_ms << ", boundary call " << g.call_ms << ", finish " << g.finish_ms << '\n';
     return 0;
 }

@@ -201,21 +201,34 @@ void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, 
 void updateAlignment(Node *node, SequenceDB *database);
 
 // What one pair needs before / after the DP (alignment-cpu.cpp:50-93 and :136-175), shared by every level kernel.
+// A float buffer that is either owned (per-pair vector) or a slot of the level's flat staging arrays (align_gpu.cpp).
+struct FloatBuf {
+    std::vector<float> own;
+    float *ext = nullptr;
+    float *data() { return ext ? ext : own.data(); }
+    const float *data() const { return ext ? ext : own.data(); }
+    void assign(size_t n, float v) { ext = nullptr; own.assign(n, v); }
+    void bind(float *slot, size_t n) { ext = slot; std::fill(slot, slot + n, 0.0f); }
+};
 struct PairInputs {
-    std::vector<float> freq, gapOp, gapEx;          // freq[2][memLen][P], gapOp/gapEx[2][memLen]
+    FloatBuf freq, gapOp, gapEx;                     // freq[2][memLen][P], gapOp/gapEx[2][memLen]
     std::pair<IntPairVec, IntPairVec> gappyColumns;
     stringPair consensus;
     IntPair lens;                                    // after gappy-column removal
     int32_t refLen, qryLen, refNum, qryNum, memLen;
     bool lowQ_r, lowQ_q;
 };
-void preparePair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in);
+// With slots given, the pair's buffers are built in place there with row stride `stride` (>= max(refLen, qryLen)); the stride
+// is only an address stride (alignment-cpu.cpp:13-30 uses max(refLen, qryLen)), it does not enter any value.
+void preparePair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in, float *freqSlot = nullptr,
+                 float *gapOpSlot = nullptr, float *gapExSlot = nullptr, int stride = 0);
 // Returns false when the pair must be deferred (fallbackPairs), true when it was written back.
 bool finishPair(NodePair &nodes, SequenceDB *database, Option *option, Params &param, PairInputs &in, alnPath &aln_wo_gc);
 
 namespace gpu {
 void alignmentKernel_GPU(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
-struct LevelTotals { uint64_t band_cells = 0, pairs = 0; double kernel_ms = 0, total_ms = 0; };
+void beginInit(Option *option);   // optional: start device initialisation early, on a helper thread
+struct LevelTotals { uint64_t band_cells = 0, pairs = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0; };
 extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
 }
 

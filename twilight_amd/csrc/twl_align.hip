@@ -425,11 +425,16 @@ static int run_host_slice(Device *d, const twl_params *p, const std::vector<int3
     HIP_TRY(hipMemcpyAsync(alen.data(), d->d_alnlen.p, alen.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(aerr.data(), d->d_err.p, aerr.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    size_t path_bytes = 0;
+    for (int32_t t = 0; t < n; ++t) path_bytes += (size_t)std::max(alen[t], 0);
+    // paths: one transfer of the whole [n][2*seq_len] block when the slice is contiguous and reasonably full, else one per pair
+    const bool bulk = contiguous && path_bytes * 8 >= (size_t)n * 2 * sl;
+    if (bulk) HIP_TRY(hipMemcpyAsync(aln_out + (size_t)ids[0] * 2 * sl, d->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
     for (int32_t t = 0; t < n; ++t) {
         const size_t s = (size_t)ids[t];
         aln_len_out[s] = alen[t];
         err_out[s] = aerr[t];
-        if (alen[t] > 0)
+        if (!bulk && alen[t] > 0)
             HIP_TRY(hipMemcpyAsync(aln_out + s * 2 * sl, (int8_t *)d->d_aln.p + (size_t)t * 2 * sl, (size_t)alen[t], hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(d->ev[3], st));
