@@ -1,0 +1,96 @@
+/*
+ * include/twl_level.h -- C ABI of libtwl_align, part 2: device-resident level processing.
+ *
+ * twl_align.h replaces the per-pair Talco_xdrop::Align_freq calls of a level.  This header moves the work the
+ * reference does AROUND those calls for every pair (reference src/alignment-cpu.cpp:50-93 before, :136-175
+ * after) onto the device as well, with the sequences kept resident in HBM for the whole progressive pass, so
+ * that per level only paths and one byte per profile column cross PCIe:
+ *
+ *   twl_level_prepare  alignment_helper::calculateProfile      (src/alignment-helper.cpp:8-72)
+ *                      alignment_helper::getConsensus          (:221-241)
+ *                      alignment_helper::removeGappyColumns    (:74-166)
+ *                      alignment_helper::calculatePSGP         (:168-219)
+ *   twl_level_align    the Align_freq calls                    (src/alignment-cpu.cpp:95-130), on the prepared columns
+ *   twl_level_commit   alignment_helper::updateFrequency       (:506-539)
+ *                      alignment_helper::updateAlignment       (:377-503), row rewriting part
+ *
+ * What stays with the caller (small, serial, policy): the retry/defer policy, addGappyColumnsBack + pairwiseGlobal
+ * on the returned paths (:243-375), and the Node bookkeeping (alnNum/alnLen/alnWeight/seqsIncluded).
+ *
+ * A store lives on ONE device.  Same conventions as twl_align.h: plain C types, 0 or a negative twl_status,
+ * twl_last_error() for the text; algorithmic failures of a pair travel in err_out[].
+ */
+#ifndef TWL_LEVEL_H
+#define TWL_LEVEL_H
+
+#include "twl_align.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct twl_store twl_store;     /* opaque: the aligned rows of every sequence + cached node profiles, in HBM */
+
+/* One side (reference or query node) of one pair.  Mirrors what calculateProfile reads from a Node
+   (src/phylogeny.hpp:40-44): seqsIncluded, alnLen, alnNum, alnWeight, msaFreq. */
+typedef struct twl_side {
+    int32_t n_members;      /* sequences under this node */
+    int32_t member_off;     /* offset of its first entry in members[] / member_weight[] */
+    int32_t len;            /* aligned length of those rows (Node::alnLen) */
+    int32_t num;            /* Node::alnNum */
+    float   weight;         /* Node::alnWeight */
+    int32_t cache_id;       /* >= 0: this node has a cached profile (Node::msaFreq non-empty) under this id: use it (:16-21) */
+    int32_t store_id;       /* >= 0 (and cache_id < 0): also cache the un-normalised profile under this new id (:35-40) */
+    int32_t reserved;
+} twl_side;
+
+/* type 'n' or 'p'.  seqs[i] need not be NUL terminated; lens[i] >= 0.  Rows are stored as given (letter case kept, like
+   SequenceDB; the profile kernels upper-case on the fly exactly as alignment-helper.cpp:29 does). */
+int  twl_store_create(int device, char type, int32_t n_seqs, const char *const *seqs, const int32_t *lens, twl_store **out);
+void twl_store_destroy(twl_store *s);
+/* Current aligned row of every sequence: rows_out[i] must hold lens_out[i] bytes; call with rows_out == NULL to get the lengths. */
+int  twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out);
+/* Cached profile `id` as float[len][P]; len_out receives its length; out may be NULL to query the length. */
+int  twl_store_read_cache(twl_store *s, int32_t id, float *out, int32_t *len_out);
+int  twl_store_drop_cache(twl_store *s, int32_t id);
+
+/*
+ * Build the DP inputs of all pairs of a level on the device.
+ *   p               gap_open / gap_extend feed calculatePSGP; P selects nucleotide (6) or protein (22)
+ *   gappy_threshold option->gappyVertical; 1.0 disables the removal (:77)
+ *   sides           [n_pairs][2]   (0 = reference node, 1 = query node)
+ *   members         sequence ids, member_weight = seq.weight / groupWeight * num evaluated in fp32 (:27)
+ *   seq_len         column stride of the level, >= every side's len
+ *   len_out         [n_pairs][2]   lengths after gappy-column removal
+ *   colinfo_out     [n_pairs][2][seq_len]  per ORIGINAL column: consensus letter index (getConsensus) in the low 7 bits,
+ *                   0x80 set when the column was removed as gappy; the caller derives the (start,length) runs and the
+ *                   consensus strings addGappyColumnsBack needs.  May be NULL.
+ */
+int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, int32_t n_pairs, const twl_side *sides,
+                      const int32_t *members, const float *member_weight, int32_t seq_len, int32_t *len_out, uint8_t *colinfo_out);
+
+/*
+ * Run the DP on the prepared level.  run_mask[i] != 0 selects pair i (NULL = all); other pairs get aln_len 0, err 0.
+ * May be called repeatedly (other gap_char group, retries with a larger xdrop/flen).  Outputs as in twl_align_batch,
+ * aln_out is [n_pairs][2*seq_len].
+ */
+int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out);
+
+/*
+ * Apply the final paths (gappy columns restored) to the rows of both nodes of every pair and merge cached profiles.
+ *   paths     [n_pairs][path_stride]   codes 0/1/2;  path_len[i] == 0 leaves pair i untouched (deferred pair)
+ * After the call every member row of pair i has length path_len[i]; if both sides had a cache (cache_id or store_id) the
+ * merged profile replaces the reference side's cache and the query side's id is dropped (updateFrequency :506-539).
+ */
+int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride);
+
+/* Diagnostics: the packed DP columns [len][P+2] (P frequencies, gapOpen, gapExtend) of one side of the prepared level. */
+int twl_level_read_columns(twl_store *s, int32_t pair, int32_t side, float *out, int32_t max_cols);
+
+/* HIP-event time (ms) of the last prepare / commit kernels, for the per-level report. */
+int twl_level_timing(twl_store *s, double *prepare_ms, double *commit_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWL_LEVEL_H */

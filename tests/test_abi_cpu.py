@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "twl_align.h")).read()
+def _declared_symbols(header="twl_align.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(twl_[a-z_]+)\s*\(", text)))
 
@@ -22,6 +22,18 @@ def test_header_symbols_are_exported(built):
     assert set(declared) == set(twl.exported_symbols())
     for name in declared:
         assert getattr(lib, name) is not None, name
+
+
+def test_level_header_symbols_are_exported(built):
+    import twilight_amd as twl
+    from twilight_amd import level
+
+    lib = twl.load_library()
+    declared = _declared_symbols("twl_level.h")
+    assert set(declared) == set(level.exported_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    assert C.sizeof(level.TwlSide) == 8 * 4
 
 
 def test_struct_layouts_match_header(built):

@@ -1,0 +1,178 @@
+"""Device-resident level kernels (include/twl_level.h) against oracle/level_oracle.py and the DP oracle, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import level_cases as LC  # noqa: E402
+import level_oracle as LO  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _level(cases, store_all=False):
+    """Flatten cases into one store + one level description.  Returns (seqs, pairs, ids) with ids[i][sd] = sequence ids."""
+    from twilight_amd import level as L
+
+    seqs, pairs, ids = [], [], []
+    next_cache = 0
+    for c in cases:
+        pr, idp = [], []
+        for sd in range(2):
+            s = c.sides[sd]
+            k = len(s.rows)
+            members = list(range(len(seqs), len(seqs) + k))
+            seqs.extend(s.rows)
+            side = L.Side(members=members, member_weight=LO.member_weights(s.seq_weights, s.group_weight, k), len=len(s.rows[0]), num=k,
+                          weight=float(F(s.group_weight)))
+            if store_all:
+                side.store_id = next_cache
+                next_cache += 1
+            pr.append(side)
+            idp.append(members)
+        pairs.append(pr)
+        ids.append(idp)
+    return seqs, pairs, ids
+
+
+@pytest.mark.parametrize("seq_type", ["n", "p"])
+def test_prepare_align_commit_match_oracle(gpu, seq_type):
+    import twilight_amd as twl
+    from twilight_amd import level as L, synth
+
+    cases = [LC.make_case(seq_type, seed, cached=0, length=70 + 31 * seed) for seed in range(7)]
+    cases.append(LC.make_case(seq_type, 11, cached=0, length=1500, thr=0.6))       # spans many 256-column chunks
+    seqs, pairs, ids = _level(cases)
+    M = LC.matrix_of(seq_type)
+    p = twl.make_params(M)
+    st = L.Store(seqs, seq_type)
+    lens, info = st.prepare(p, pairs, gappy_threshold=0.95)
+    # gappy threshold is per level in the product; check the 0.6 case in its own level below
+    exps = [LC.expected(c) if c.thr == 0.95 else None for c in cases]
+    for i, (c, e) in enumerate(zip(cases, exps)):
+        if e is None:
+            continue
+        assert tuple(lens[i]) == e["lens"], f"pair {i}: lengths after gappy removal"
+        for sd in range(2):
+            assert np.array_equal(_bits(st.columns(i, sd)), _bits(e["cols"][sd])), f"pair {i} side {sd}: packed columns"
+            n0 = len(c.sides[sd].rows[0])
+            assert np.array_equal(info[i, sd, :n0], e["info"][sd]), f"pair {i} side {sd}: consensus / gappy flags"
+    # DP on the prepared columns == DP oracle on the oracle's columns
+    aln, n, err = st.align(p)
+    op = O.make_params(M)
+    for i, e in enumerate(exps):
+        if e is None:
+            continue
+        cr, cq = e["cols"]
+        P = st.P
+        k_r, k_q = len(cases[i].sides[0].rows), len(cases[i].sides[1].rows)
+        oa, oerr, _ = O.align_pair(op, cr[:, :P], cq[:, :P], cr[:, P], cr[:, P + 1], cq[:, P], cq[:, P + 1], k_r, k_q)
+        assert err[i] == oerr and n[i] == len(oa) and np.array_equal(aln[i, : n[i]], oa), f"pair {i}: DP path"
+    # write-back with the oracle's random paths (gappy columns restored); pair 2 is left out like a deferred pair
+    paths = []
+    for i, e in enumerate(exps):
+        paths.append(np.zeros(0, dtype=np.int8) if (e is None or i == 2) else e["path_full"])
+    st.commit(paths)
+    rows = st.rows()
+    for i, e in enumerate(exps):
+        flat = ids[i][0] + ids[i][1]
+        if e is None or i == 2:
+            for sid in flat:
+                assert rows[sid] == seqs[sid], f"pair {i}: untouched row {sid} changed"
+            continue
+        for sid, want in zip(flat, e["rows_after"]):
+            assert rows[sid] == want, f"pair {i}: row {sid} after write-back"
+    st.close()
+
+    # the 0.6-threshold, 1500-column case as its own level
+    c = cases[-1]
+    seqs2, pairs2, ids2 = _level([c])
+    st = L.Store(seqs2, seq_type)
+    lens, info = st.prepare(p, pairs2, gappy_threshold=0.6)
+    e = LC.expected(c)
+    assert tuple(lens[0]) == e["lens"]
+    for sd in range(2):
+        assert np.array_equal(_bits(st.columns(0, sd)), _bits(e["cols"][sd]))
+    st.commit([e["path_full"]])
+    rows = st.rows()
+    for sid, want in zip(ids2[0][0] + ids2[0][1], e["rows_after"]):
+        assert rows[sid] == want
+    st.close()
+
+
+@pytest.mark.parametrize("seq_type", ["n", "p"])
+def test_cached_profiles_two_levels(gpu, seq_type):
+    """Level 1 stores both nodes' profiles (as for >= 1000-sequence nodes) and merges them on commit; level 2 uses the merged cache."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    a = LC.make_case(seq_type, 21, cached=0, length=300)
+    seqs, pairs, ids = _level([a], store_all=True)
+    z_rows = LC.make_case(seq_type, 22, cached=0, length=340).sides[1]
+    z_ids = list(range(len(seqs), len(seqs) + len(z_rows.rows)))
+    seqs = seqs + z_rows.rows
+    p = twl.make_params(LC.matrix_of(seq_type))
+    st = L.Store(seqs, seq_type)
+    st.prepare(p, pairs)
+    P = st.P
+    profs = [LC.side_profile(a, sd) for sd in range(2)]
+    caches = [LO.cache_from_profile(profs[sd], a.sides[sd].group_weight, len(a.sides[sd].rows)) for sd in range(2)]
+    for sd in range(2):
+        assert np.array_equal(_bits(st.cache(sd)), _bits(caches[sd])), f"stored cache of side {sd}"
+    e = LC.expected(a)
+    st.commit([e["path_full"]])
+    merged = LO.update_frequency(caches[0], caches[1], e["path_full"], a.sides[0].group_weight, a.sides[1].group_weight)
+    assert np.array_equal(_bits(st.cache(0)), _bits(merged)), "merged cache"
+    with pytest.raises(twl.TwlError):
+        st.cache(1)                                  # the query node's cache is dropped by the merge
+    # level 2: (merged node, Z).  The merged node's profile comes from its cache; Z's is stored.
+    k = len(a.sides[0].rows) + len(a.sides[1].rows)
+    gw = float(F(F(a.sides[0].group_weight) + F(a.sides[1].group_weight)))
+    total = len(e["path_full"])
+    w_all = np.concatenate([a.sides[0].seq_weights, a.sides[1].seq_weights])
+    ref = L.Side(members=ids[0][0] + ids[0][1], member_weight=LO.member_weights(w_all, gw, k), len=total, num=k, weight=gw, cache_id=0)
+    kz = len(z_rows.rows)
+    qry = L.Side(members=z_ids, member_weight=LO.member_weights(z_rows.seq_weights, z_rows.group_weight, kz), len=len(z_rows.rows[0]), num=kz,
+                 weight=float(F(z_rows.group_weight)), store_id=7)
+    lens, info = st.prepare(p, [[ref, qry]])
+    prof_ref = LO.profile_from_cache(merged, gw, k)
+    cols, _, _ = LO.prepare_side(prof_ref, k, 0.95, LC.GAP_OPEN, LC.GAP_EXTEND, seq_type)
+    assert lens[0, 0] == cols.shape[0]
+    assert np.array_equal(_bits(st.columns(0, 0)), _bits(cols)), "columns from the merged cache"
+    prof_z = LO.calculate_profile(z_rows.rows, LO.member_weights(z_rows.seq_weights, z_rows.group_weight, kz), P, seq_type)
+    assert np.array_equal(_bits(st.cache(7)), _bits(LO.cache_from_profile(prof_z, z_rows.group_weight, kz)))
+    st.close()
+
+
+def test_rows_grow_past_initial_capacity(gpu):
+    """A commit whose paths are longer than the store's row pitch re-pitches the planes without losing rows."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    rng = np.random.default_rng(5)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=400).astype(np.uint8)) for _ in range(4)] + [b"ACGTAC"]
+    st = L.Store(seqs, "n")                      # initial pitch 1280 columns for 400-letter sequences
+    p = twl.make_params(LC.matrix_of("n"))
+    members, total = [0], 400
+    for nxt in (1, 2, 3):                        # end-to-end concatenation: 800, 1200, 1600 columns
+        k = len(members)
+        st.prepare(p, [[L.Side(list(members), np.full(k, 1.0, dtype=F), total, k, float(k)), L.Side([nxt], np.asarray([1.0], dtype=F), 400, 1, 1.0)]],
+                   gappy_threshold=1.0)
+        st.commit([np.concatenate([np.full(total, 2, np.int8), np.full(400, 1, np.int8)])])
+        members.append(nxt)
+        total += 400
+    rows = st.rows()
+    for i in range(4):
+        assert rows[i] == b"-" * (400 * i) + seqs[i] + b"-" * (400 * (3 - i)), f"row {i}"
+    assert rows[4] == seqs[4]
+    st.close()

@@ -2,9 +2,7 @@
 // for cpu::alignmentKernel_CPU (/root/reference/src/alignment-cpu.cpp:32-183).  Same phases, same policy; the per-pair
 // Talco_xdrop::Align_freq calls of a level (alignment-cpu.cpp:95-130) become twl_align_batch calls (include/twl_align.h).
 // There is no CPU alignment path in this file: if the GPU library fails the run stops.
-#include "twl_host.hpp"
-
-#include "../../../include/twl_align.h"
+#include "align_gpu.hpp"
 
 #include <omp.h>
 
@@ -23,8 +21,8 @@ namespace progressive {
 namespace gpu {
 
 LevelTotals g_totals;
-static inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static std::vector<int> g_devices;
+const std::vector<int> &selectedDevices() { return g_devices; }
 
 static std::future<std::pair<int, std::string>> g_initJob;   // (return code, twl_last_error() of the helper thread)
 
@@ -38,7 +36,7 @@ void beginInit(Option *option)
     });
 }
 
-static void ensureInit(Option *option)
+void ensureInit(Option *option)
 {
     static bool done = false;
     if (done) return;
@@ -48,7 +46,7 @@ static void ensureInit(Option *option)
     done = true;
 }
 
-static twl_params baseParams(Params &param)          // == Talco_xdrop::Params(msa::Params&), TALCO-XDrop.cpp:36-53
+twl_params baseParams(Params &param)          // == Talco_xdrop::Params(msa::Params&), TALCO-XDrop.cpp:36-53
 {
     twl_params tp{};
     tp.P = param.matrixSize + 1;

@@ -1,0 +1,297 @@
+// twilight_amd/csrc/host/align_resident.cpp -- msa::progressive::gpu::alignmentKernel_Resident: the level kernel with the
+// sequences resident in HBM (include/twl_level.h).  Same phases and policy as cpu::alignmentKernel_CPU
+// (/root/reference/src/alignment-cpu.cpp:32-183); what moves to the device besides the DP is calculateProfile,
+// getConsensus, removeGappyColumns, calculatePSGP (before) and updateFrequency + the row rewriting of updateAlignment (after).
+// The host keeps the policy: empty sides, low-quality singletons, retry/defer, addGappyColumnsBack, Node bookkeeping.
+//
+// Differences from the host-staged kernel that do not change the result:
+//  * groups of > 1000 sequences are not compressed into one negative id (alignment-helper.cpp:479-500): that device only saves the
+//    reference per-level row rewriting, which here is a sub-millisecond kernel; every row is simply kept up to date.
+//  * the pass covers currentTask == 0; before the deferred pass (currentTask 1) rows and cached profiles are brought back to the
+//    host and alignmentKernel_GPU takes over.
+#include "align_gpu.hpp"
+
+#include "../../../include/twl_level.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+namespace msa {
+namespace progressive {
+namespace gpu {
+
+namespace {
+
+twl_store *g_store = nullptr;
+bool g_finished = false;        // the main pass is over: rows are back on the host
+int g_nextCacheId = 0;
+
+void die(const char *what, int rc)
+{
+    std::cerr << "ERROR: " << what << " failed (" << rc << "): " << twl_last_error() << '\n';
+    exit(1);
+}
+
+void createStore(SequenceDB *db, Option *option)
+{
+    const int n = (int)db->sequences.size();
+    std::vector<const char *> rows(n);
+    std::vector<int32_t> lens(n);
+    for (int i = 0; i < n; ++i) {
+        auto *s = db->sequences[i];
+        if (s->id != i) { std::cerr << "ERROR: sequence ids are not dense.\n"; exit(1); }
+        rows[i] = s->alnStorage[s->storage];
+        lens[i] = s->len;
+    }
+    const int rc = twl_store_create(selectedDevices()[0], option->type, n, rows.data(), lens.data(), &g_store);
+    if (rc != TWL_OK) die("twl_store_create", rc);
+}
+
+// End of the main pass: current rows back into SequenceInfo::alnStorage, cached profiles of the nodes that go on (the root and the
+// deferred nodes) back into Node::msaFreq, store released.
+void materialise(Tree *T, SequenceDB *db, Option *option)
+{
+    if (!g_store) return;
+    const double t0 = nowMs();
+    const int n = (int)db->sequences.size();
+    std::vector<int32_t> lens(n);
+    int rc = twl_store_read_rows(g_store, nullptr, lens.data());
+    if (rc != TWL_OK) die("twl_store_read_rows", rc);
+    std::vector<char *> rows(n);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {               // exact-size host rows (memCheck would double and zero-fill both buffers serially)
+        auto *s = db->sequences[i];
+        if (s->memLen < lens[i]) {
+            for (int b = 0; b < 2; ++b) { delete[] s->alnStorage[b]; s->alnStorage[b] = new char[lens[i]]; }
+            s->memLen = lens[i];
+        }
+        rows[i] = s->alnStorage[s->storage];
+    }
+    rc = twl_store_read_rows(g_store, rows.data(), lens.data());
+    if (rc != TWL_OK) die("twl_store_read_rows", rc);
+    for (int i = 0; i < n; ++i) db->sequences[i]->len = lens[i];
+    const int P = (option->type == 'n') ? 6 : 22;
+    std::vector<Node *> keep{T->root};
+    keep.insert(keep.end(), db->fallback_nodes.begin(), db->fallback_nodes.end());
+    for (Node *nd : keep) {
+        if (nd->cacheId < 0) continue;
+        int32_t len = 0;
+        if ((rc = twl_store_read_cache(g_store, nd->cacheId, nullptr, &len)) != TWL_OK) die("twl_store_read_cache", rc);
+        std::vector<float> flat((size_t)len * P);
+        if ((rc = twl_store_read_cache(g_store, nd->cacheId, flat.data(), &len)) != TWL_OK) die("twl_store_read_cache", rc);
+        nd->msaFreq.assign(len, std::vector<float>(P));
+        for (int t = 0; t < len; ++t) std::copy(&flat[(size_t)t * P], &flat[(size_t)t * P] + P, nd->msaFreq[t].begin());
+        nd->cacheId = -1;
+    }
+    twl_store_destroy(g_store);
+    g_store = nullptr;
+    g_finished = true;
+    if (option->printDetail) std::cerr << "Rows back on the host in " << nowMs() - t0 << " ms\n";
+}
+
+struct PairState {
+    int32_t refLen, qryLen, refNum, qryNum;
+    IntPair lens;
+    bool lowQ_r, lowQ_q;
+    std::pair<IntPairVec, IntPairVec> gappy;
+    stringPair consensus;
+};
+
+void runsAndConsensus(const uint8_t *info, int len, bool removal, const char *letters, IntPairVec &runs, std::string &cons)
+{
+    cons.resize(len);
+    int start = -1;
+    for (int t = 0; t < len; ++t) {
+        cons[t] = letters[info[t] & 0x7f];
+        if (!removal) continue;
+        if (info[t] & 0x80) { if (start < 0) start = t; }
+        else if (start >= 0) { runs.push_back({start, t - start}); start = -1; }
+    }
+    if (removal && start >= 0) runs.push_back({start, len - start});
+}
+
+}  // namespace
+
+void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database, Option *option, Params &param)
+{
+    if (database->currentTask != 0 || g_finished || selectedDevices().size() > 1) {      // deferred pass / several devices: host-staged kernel
+        if (g_store) materialise(T, database, option);
+        alignmentKernel_GPU(T, nodes, database, option, param);
+        return;
+    }
+    if (option->cpuOnly) { std::cerr << "ERROR: --cpu-only is not available: this build has no CPU alignment path.\n"; exit(1); }
+    ensureInit(option);
+    if (selectedDevices().size() > 1) { alignmentKernel_GPU(T, nodes, database, option, param); return; }
+    if (!g_store) {
+        const double t0 = nowMs();
+        createStore(database, option);
+        if (option->printDetail) std::cerr << "Sequences resident on the device in " << nowMs() - t0 << " ms\n";
+        database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
+    }
+    const LevelTotals before = g_totals;
+    const double tPrep = nowMs();
+    const int n = (int)nodes.size();
+    static const char bases[] = {'A', 'C', 'G', 'T', 'N'};
+    static const char acids[] = {'A', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'K', 'L', 'M', 'N', 'P', 'Q', 'R', 'S', 'T', 'V', 'W', 'Y', 'X'};
+    const char *letters = (option->type == 'n') ? bases : acids;
+
+    // ---- side descriptors (what calculateProfile reads from the two nodes, alignment-helper.cpp:8-40) ----
+    std::vector<twl_side> sides(2 * (size_t)n);
+    std::vector<PairState> ps(n);
+    size_t nMembers = 0;
+    int stride = 1;
+    for (int i = 0; i < n; ++i) {
+        Node *nd[2] = {nodes[i].first, nodes[i].second};
+        PairState &s = ps[i];
+        s.refLen = nd[0]->getAlnLen(0); s.qryLen = nd[1]->getAlnLen(0);
+        s.refNum = nd[0]->getAlnNum(0); s.qryNum = nd[1]->getAlnNum(0);
+        const bool storeFreq = (s.refNum >= alignment_helper::_CAL_PROFILE_TH || s.qryNum >= alignment_helper::_CAL_PROFILE_TH) || (nd[0]->cacheId >= 0 || nd[1]->cacheId >= 0);
+        for (int sd = 0; sd < 2; ++sd) {
+            twl_side &x = sides[2 * (size_t)i + sd];
+            x.n_members = (int32_t)nd[sd]->seqsIncluded.size();
+            x.member_off = (int32_t)nMembers;
+            x.len = sd ? s.qryLen : s.refLen;
+            x.num = sd ? s.qryNum : s.refNum;
+            x.weight = nd[sd]->alnWeight;
+            x.cache_id = nd[sd]->cacheId;
+            x.store_id = -1;
+            x.reserved = 0;
+            if (storeFreq && nd[sd]->cacheId < 0) x.store_id = nd[sd]->cacheId = g_nextCacheId++;
+            nMembers += (size_t)x.n_members;
+            stride = std::max(stride, x.len);
+        }
+        s.lowQ_r = (option->alnMode == MERGE_MSA) ? false : ((s.refNum > 1) ? false : database->sequences[nd[0]->seqsIncluded[0]]->lowQuality);
+        s.lowQ_q = (option->alnMode == MERGE_MSA) ? false : ((s.qryNum > 1) ? false : database->sequences[nd[1]->seqsIncluded[0]]->lowQuality);
+    }
+    std::vector<int32_t> members(nMembers);
+    std::vector<float> weights(nMembers);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n; ++i) {
+        Node *nd[2] = {nodes[i].first, nodes[i].second};
+        for (int sd = 0; sd < 2; ++sd) {
+            const twl_side &x = sides[2 * (size_t)i + sd];
+            const float groupWeight = nd[sd]->alnWeight;
+            for (int m = 0; m < x.n_members; ++m) {
+                const int sIdx = nd[sd]->seqsIncluded[m];
+                if (sIdx < 0) { std::cerr << "ERROR: compressed sequence group in device-resident mode.\n"; exit(1); }
+                members[x.member_off + m] = sIdx;
+                weights[x.member_off + m] = database->sequences[sIdx]->weight / groupWeight * x.num;     // alignment-helper.cpp:27
+            }
+        }
+    }
+
+    // ---- device: profiles, consensus, gappy-column removal, gap penalties ----
+    twl_params tp = baseParams(param);
+    std::vector<int32_t> lens(2 * (size_t)n);
+    std::vector<uint8_t> colinfo((size_t)2 * n * stride);
+    int rc = twl_level_prepare(g_store, &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride, lens.data(), colinfo.data());
+    if (rc != TWL_OK) die("twl_level_prepare", rc);
+    const bool removal = !(option->gappyVertical == 1.0);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; ++i) {
+        PairState &s = ps[i];
+        s.lens = {lens[2 * i], lens[2 * i + 1]};
+        runsAndConsensus(&colinfo[((size_t)2 * i) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
+        runsAndConsensus(&colinfo[((size_t)2 * i + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
+    }
+    g_totals.prepare_ms += nowMs() - tPrep;
+
+    // ---- DP with the reference's grouping and retry/defer policy (alignment-cpu.cpp:88-130) ----
+    std::vector<alnPath> paths(n);
+    std::vector<int16_t> errs(n, 0);
+    std::vector<uint8_t> maskPlain(n, 0), maskZero(n, 0);
+    int nPlain = 0, nZero = 0;
+    for (int i = 0; i < n; ++i) {
+        if (ps[i].refLen == 0) paths[i].assign(ps[i].qryLen, 1);
+        if (ps[i].qryLen == 0) paths[i].insert(paths[i].end(), ps[i].refLen, 2);
+        if (!paths[i].empty() || ps[i].lowQ_r || ps[i].lowQ_q) continue;
+        const bool zg = (ps[i].refNum > 10000 || ps[i].qryNum > 10000);
+        if (zg) { maskZero[i] = 1; ++nZero; } else { maskPlain[i] = 1; ++nPlain; }
+    }
+    std::vector<int8_t> aln((size_t)n * 2 * stride);
+    std::vector<int32_t> alnLen(n);
+    std::vector<int16_t> err(n);
+    auto runMasked = [&](const twl_params &prm, const std::vector<uint8_t> &mask) {
+        const double tCall = nowMs();
+        const int r = twl_level_align(g_store, &prm, mask.data(), aln.data(), alnLen.data(), err.data());
+        if (r != TWL_OK) die("twl_level_align", r);
+        g_totals.call_ms += nowMs() - tCall;
+        twl_stats st{};
+        if (twl_get_stats(selectedDevices()[0], &st) == TWL_OK) { g_totals.band_cells += st.band_cells; g_totals.kernel_ms += st.kernel_ms; g_totals.total_ms += st.total_ms; }
+        for (int i = 0; i < n; ++i) {
+            if (!mask[i]) continue;
+            ++g_totals.pairs;
+            errs[i] = err[i];
+            paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + (err[i] == 0 ? alnLen[i] : 0));
+        }
+    };
+    twl_params tz = tp;
+    tz.gap_char = 0;
+    if (nPlain) runMasked(tp, maskPlain);
+    if (nZero) runMasked(tz, maskZero);
+    std::vector<int> fallbackPairs;
+    for (int i = 0; i < n; ++i) {
+        if (errs[i] == 0) continue;
+        if (errs[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
+        paths[i].clear();                       // currentTask == 0: a failed pair is deferred (alignment-cpu.cpp:108-115)
+        fallbackPairs.push_back(i);
+    }
+
+    // ---- gappy columns back, then the write-back on the device ----
+    const double tFin = nowMs();
+    int pathStride = 1;
+    for (int i = 0; i < n; ++i) pathStride = std::max(pathStride, ps[i].refLen + ps[i].qryLen);
+    std::vector<int8_t> finalPaths((size_t)n * pathStride);
+    std::vector<int32_t> finalLen(n, 0);
+    std::vector<char> deferred(n, 0);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; ++i) {
+        PairState &s = ps[i];
+        deferred[i] = ((s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144
+        if (deferred[i]) paths[i].clear();
+        if (paths[i].empty()) continue;
+        alnPath full;
+        int alnRef = 0, alnQry = 0;
+        for (auto a : paths[i]) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
+        alignment_helper::addGappyColumnsBack(paths[i], full, s.gappy, param, {alnRef, alnQry}, s.consensus);
+        alnRef = alnQry = 0;
+        for (auto a : full) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
+        if (alnRef != s.refLen) std::cout << "R: Post " << nodes[i].first->identifier << "(" << alnRef << "/" << s.refLen << ")\n";
+        if (alnQry != s.qryLen) std::cout << "Q: Post " << nodes[i].second->identifier << "(" << alnQry << "/" << s.qryLen << ")\n";
+        if ((int)full.size() > pathStride) { std::cerr << "ERROR: path longer than both profiles together.\n"; exit(1); }
+        std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
+        finalLen[i] = (int32_t)full.size();
+    }
+    rc = twl_level_commit(g_store, finalPaths.data(), finalLen.data(), pathStride);
+    if (rc != TWL_OK) die("twl_level_commit", rc);
+    for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
+        if (finalLen[i] == 0) continue;
+        Node *a = nodes[i].first, *b = nodes[i].second;
+        if (a->cacheId >= 0 && b->cacheId >= 0) b->cacheId = -1;       // merged into a's cache by the commit
+        a->alnNum += b->alnNum;
+        a->alnLen = finalLen[i];
+        a->alnWeight += b->alnWeight;
+        a->seqsIncluded.insert(a->seqsIncluded.end(), b->seqsIncluded.begin(), b->seqsIncluded.end());
+        b->seqsIncluded.clear();
+    }
+    g_totals.finish_ms += nowMs() - tFin;
+    double devPrep = 0, devCommit = 0;
+    twl_level_timing(g_store, &devPrep, &devCommit);
+    g_totals.dev_prepare_ms += devPrep;
+    g_totals.dev_commit_ms += devCommit;
+    for (int i = 0; i < n; ++i)
+        if (deferred[i]) fallbackPairs.push_back(i);
+    if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
+    if (option->printDetail)
+        std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << g_totals.call_ms - before.call_ms
+                  << " (kernel " << g_totals.kernel_ms - before.kernel_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
+                  << ") whole " << nowMs() - tPrep << '\n';
+}
+
+}  // namespace gpu
+}  // namespace progressive
+}  // namespace msa

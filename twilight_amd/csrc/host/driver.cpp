@@ -63,6 +63,7 @@ bool parseCommandLine(int argc, char **argv, Option &o)
         else if (flag(a, nullptr, "--filter")) o.noFilter = false;
         else if (flag(a, nullptr, "--check")) o.debug = true;
         else if (flag(a, "-v", "--verbose")) o.printDetail = true;
+        else if (flag(a, "--host-staged", "--host-staged")) o.hostStaged = true;
         else if (flag(a, nullptr, "--overwrite")) {}
         else if (flag(a, "-h", "--help")) return false;
         else { std::cerr << "ERROR: unsupported option " << a << " (this build covers the tree+sequences alignment mode only)\n"; exit(1); }

@@ -345,6 +345,7 @@ void fallback2cpu(std::vector<int> &fallbackPairs, NodePairVec &nodes, SequenceD
             std::swap(a->alnWeight, b->alnWeight);
             std::swap(a->seqsIncluded, b->seqsIncluded);
             std::swap(a->msaFreq, b->msaFreq);
+            std::swap(a->cacheId, b->cacheId);
             totalSeqs += refNum;
         } else {
             if (!filtering || !lowQ_q) {

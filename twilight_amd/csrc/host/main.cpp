@@ -10,18 +10,21 @@ int main(int argc, char **argv)
     msa::Option option;
     if (!msa::parseCommandLine(argc, argv, option)) {
         std::cerr << "usage: twilight-mi355x -t <tree.nwk> -i <sequences.fa[.gz]> -o <out.aln> [-r 0.95] [--type n|p] [--match 18 --mismatch -8 --transition -4\n"
-                     "        --gap-open -50 --gap-extend -5 --gap-ends X --xdrop 600] [-w] [--rooted] [--filter] [--check] [-v] [--gpu-index 0,1]\n";
+                     "        --gap-open -50 --gap-extend -5 --gap-ends X --xdrop 600] [-w] [--rooted] [--filter] [--check] [-v] [--gpu-index 0,1] [--host-staged]\n";
         return 1;
     }
     auto t0 = std::chrono::high_resolution_clock::now();
     msa::progressive::gpu::beginInit(&option);
     // both passes run on the GPU level kernel (the reference hard-wires its CPU kernel for the deferred pass)
-    const int alnLen = msa::runDefaultAlignment(option, msa::progressive::gpu::alignmentKernel_GPU, msa::progressive::gpu::alignmentKernel_GPU);
+    msa::alnFunction kernel = msa::progressive::gpu::alignmentKernel_Resident;
+    if (option.hostStaged) kernel = msa::progressive::gpu::alignmentKernel_GPU;
+    const int alnLen = msa::runDefaultAlignment(option, kernel, kernel);
     const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     const auto &g = msa::progressive::gpu::g_totals;
     std::cerr << "Wrote " << option.outFile << " (length " << alnLen << ") in " << secs << " s; level kernel: " << g.pairs << " pairs, " << g.band_cells
               << " band cells, " << g.kernel_ms << " ms DP kernel, " << g.total_ms << " ms incl. transfers\n";
     if (option.printDetail)
-        std::cerr << "Host phases (ms): prepare " << g.prepare_ms << ", stage " << g.stage_ms << ", boundary call " << g.call_ms << ", finish " << g.finish_ms << '\n';
+        std::cerr << "Host phases (ms): prepare " << g.prepare_ms << ", stage " << g.stage_ms << ", boundary call " << g.call_ms << ", finish " << g.finish_ms
+                  << "; device prepare kernels " << g.dev_prepare_ms << ", device write-back kernels " << g.dev_commit_ms << '\n';
     return 0;
 }

@@ -102,6 +102,8 @@ static void materialise(Node *n, Node *partner, SequenceDB *db)
             if ((c->grpID == -1 || c->grpID == grp) && c->identifier != partner->identifier) {
                 n->msaFreq = c->msaFreq;
                 c->msaFreq.clear();
+                n->cacheId = c->cacheId;
+                c->cacheId = -1;
                 n->seqsIncluded = c->seqsIncluded;
                 n->alnLen = c->alnLen;
                 n->alnNum = c->alnNum;
@@ -172,11 +174,13 @@ void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, 
         Node *last = levels.back()[0].first;
         T->root->seqsIncluded = last->seqsIncluded;
         if (!last->msaFreq.empty()) T->root->msaFreq = last->msaFreq;
+        if (last->cacheId >= 0) { T->root->cacheId = last->cacheId; last->cacheId = -1; }
         T->root->alnLen = last->alnLen;
         T->root->alnNum = last->alnNum;
         T->root->alnWeight = last->alnWeight;
         last->seqsIncluded.clear();
         last->msaFreq.clear();
+        if (database->afterMainPass) { database->afterMainPass(T); database->afterMainPass = nullptr; }
     }
     if (database->fallback_nodes.empty()) updateAlignment(T->root, database);
     auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::high_resolution_clock::now() - t0).count();

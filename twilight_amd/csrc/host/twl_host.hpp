@@ -40,6 +40,7 @@ struct Node {
 
     std::vector<int> seqsIncluded;
     Profile msaFreq;
+    int cacheId = -1;          // device-resident mode: handle of the profile cached in the store (plays msaFreq; -1 = none)
     int alnLen = 0;
     int alnNum = 0;
     float alnWeight = 0;
@@ -117,6 +118,7 @@ struct Option {
     bool alignGappy = true;
     std::string treeFile, seqFile, outFile;
     bool printDetail = false;    // -v
+    bool hostStaged = false;     // --host-staged: build profiles on the host and stage them per level (default: device-resident rows)
     // scoring flags (consumed by Params)
     float match = 18, mismatch = -8, transition = -4, gapOpen = -50, gapExtend = -5, xdrop = 600;
     bool hasGapEnds = false;
@@ -159,6 +161,7 @@ struct SequenceDB {
     std::vector<Node *> fallback_nodes;
     std::unordered_map<std::string, SequenceInfo *> name_map;
     std::unordered_map<int, alnPath> subtreeAln;
+    std::function<void(Tree *)> afterMainPass;    // set by the device-resident level kernel: bring rows/caches back to the host
     void addSequence(int id, const std::string &name, std::string &seq, int subtreeIdx, float weight, bool debug);
     bool debug();      // --check: true when every aligned row reproduces its input sequence and all rows are equally long
     ~SequenceDB();
@@ -228,7 +231,11 @@ bool finishPair(NodePair &nodes, SequenceDB *database, Option *option, Params &p
 namespace gpu {
 void alignmentKernel_GPU(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
 void beginInit(Option *option);   // optional: start device initialisation early, on a helper thread
-struct LevelTotals { uint64_t band_cells = 0, pairs = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0; };
+// Device-resident variant (include/twl_level.h): rows and cached profiles stay in HBM during the main progressive pass; profile
+// building, gappy-column removal, gap penalties and the row write-back run as kernels.  Falls through to alignmentKernel_GPU
+// for the deferred pass (currentTask != 0), after bringing the rows back.
+void alignmentKernel_Resident(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
+struct LevelTotals { uint64_t band_cells = 0, pairs = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0; };
 extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
 }
 

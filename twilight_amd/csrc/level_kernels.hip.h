@@ -1,0 +1,264 @@
+// twilight_amd/csrc/level_kernels.hip.h -- device-side pre/post-processing of one guide-tree level.
+//
+// The rows of every sequence stay in HBM for the whole run (two planes, ping-pong per sequence like
+// SequenceDB::SequenceInfo::alnStorage[2], /root/reference/src/msa.hpp:126); these kernels replace the host work
+// the reference does around the DP for every pair of a level:
+//   profile_kernel   alignment_helper::calculateProfile   /root/reference/src/alignment-helper.cpp:8-72
+//                    + getConsensus (:221-241) + the gappy-column test of removeGappyColumns (:84,105)
+//   compact_kernel   removeGappyColumns compaction (:74-166) fused with calculatePSGP (:168-219); writes the packed
+//                    [P freq | gapOpen | gapExtend] columns the DP kernel reads (talco_kernel.hip.h), so the level's
+//                    profiles never cross PCIe
+//   path_scan_kernel / apply_path_kernel   alignment_helper::updateAlignment row rewriting (:389-400,436-447)
+//   merge_cache_kernel                      alignment_helper::updateFrequency (:506-539)
+// All are HBM-bound byte/float streams: one thread per column, members visited in the reference's order so the
+// fp32 sums round identically.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace twl {
+
+// One side (ref or query) of one pair of the level.
+struct SideDesc {
+    int32_t n_members;       // rows of this side
+    int32_t member_off;      // offset into the member tables
+    int32_t len;             // aligned length of those rows before gappy-column removal
+    int32_t num;             // alnNum
+    float weight;            // alnWeight (groupWeight)
+    int32_t cache_slot;      // >= 0: index into the cache pointer table; the cached profile is used instead of the rows
+    int32_t store_slot;      // >= 0: store the un-normalised profile there (alignment-helper.cpp:35-40)
+    int32_t pad;
+};
+
+struct LevelArgs {
+    const SideDesc *sides;            // [2 * n_pairs]
+    const int32_t *member_seq;        // sequence id per member
+    const float *member_w;            // seq.weight / groupWeight * num  (alignment-helper.cpp:27), computed by the caller in fp32
+    const uint8_t *member_plane;      // current plane per member
+    const char *rows0, *rows1;        // planes [n_seqs][cap]
+    int64_t cap;
+    float *const *cache;              // cache pointer table
+    const uint8_t *lut;               // char -> letter index (letterIdx(type, toupper(c)), scoring-matrix.cpp:26-79)
+    float *raw;                       // [2*n_pairs][stride][P] un-compacted profiles
+    uint8_t *colinfo;                 // [2*n_pairs][stride]  consensus letter index | 0x80 when the column is gappy
+    float *cols;                      // [2*n_pairs][stride][P+2] packed DP columns
+    int32_t *len_out;                 // [2*n_pairs] lengths after removal
+    int32_t stride;
+    float gappy_thr;                  // option->gappyVertical
+    int32_t remove;                   // 0 when gappy_thr == 1 (removeGappyColumns returns early, :77)
+    float gap_open, gap_extend, scale, min_gap_open, min_gap_extend;   // calculatePSGP constants (:171-176)
+};
+
+// grid: (2 * n_pairs, ceil(stride / 256)), 256 threads; thread = one column of one side.
+template <int P>
+__global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
+{
+    const int side = blockIdx.x;
+    const SideDesc sd = a.sides[side];
+    const int t = blockIdx.y * 256 + threadIdx.x;
+    if (t >= sd.len) return;
+    float acc[P];
+#pragma unroll
+    for (int v = 0; v < P; ++v) acc[v] = 0.0f;
+    const float fnum = (float)sd.num;
+    if (sd.cache_slot >= 0) {                                            // :16-21  msaFreq / weight * num
+        const float *c = a.cache[sd.cache_slot] + (size_t)t * P;
+#pragma unroll
+        for (int v = 0; v < P; ++v) acc[v] = c[v] / sd.weight * fnum;
+    } else {                                                             // :23-34  member by member
+        for (int m = 0; m < sd.n_members; ++m) {
+            const int mi = sd.member_off + m;
+            const char *row = (a.member_plane[mi] ? a.rows1 : a.rows0) + (size_t)a.member_seq[mi] * a.cap;
+            const int li = a.lut[(uint8_t)row[t]];
+            const float w = a.member_w[mi];
+#pragma unroll
+            for (int v = 0; v < P; ++v) acc[v] += (li == v) ? w : 0.0f;    // x + 0 is exact (accumulators are never -0)
+        }
+        if (sd.store_slot >= 0) {                                        // :35-40  cache = profile / num * weight
+            float *c = a.cache[sd.store_slot] + (size_t)t * P;
+#pragma unroll
+            for (int v = 0; v < P; ++v) c[v] = acc[v] / fnum * sd.weight;
+        }
+    }
+    float *dst = a.raw + ((size_t)side * a.stride + t) * P;
+#pragma unroll
+    for (int v = 0; v < P; ++v) dst[v] = acc[v];
+    int best = P - 2;                                                    // getConsensus: first strict maximum, all-zero -> N / X
+    float bestCount = 0.0f;
+#pragma unroll
+    for (int v = 0; v < P - 2; ++v)
+        if (acc[v] > bestCount) { bestCount = acc[v]; best = v; }
+    const bool gappy = (acc[P - 1] / fnum > a.gappy_thr);                // :84,105
+    a.colinfo[(size_t)side * a.stride + t] = (uint8_t)(best | (gappy ? 0x80 : 0));
+}
+
+// Workgroup-wide exclusive scan of one flag per thread (256 threads = 4 waves); returns the thread's offset, *total = sum.
+__device__ inline int block_scan_256(bool flag, int *total, int *s_wave /*[4]*/)
+{
+    const unsigned long long b = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();                               // s_wave may still be read from the previous round
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; if (w < wave) base += c; sum += c; }
+    *total = sum;
+    return base + before;
+}
+
+// grid: 2 * n_pairs workgroups of 256 threads; a workgroup walks its side in 256-column chunks with a running output index.
+template <int P>
+__global__ void __launch_bounds__(256) compact_kernel(LevelArgs a)
+{
+    constexpr int CW = P + 2;
+    __shared__ int s_wave[4];
+    const int side = blockIdx.x;
+    const SideDesc sd = a.sides[side];
+    const float fnum = (float)sd.num;
+    const double dnum = (double)sd.num;
+    int base = 0;
+    for (int c0 = 0; c0 < sd.len; c0 += 256) {
+        const int t = c0 + threadIdx.x;
+        const bool in = t < sd.len;
+        const bool keep = in && !(a.remove && (a.colinfo[(size_t)side * a.stride + t] & 0x80));
+        int total;
+        const int dst = base + block_scan_256(keep, &total, s_wave);
+        if (keep) {
+            const float *src = a.raw + ((size_t)side * a.stride + t) * P;
+            float v[CW];
+#pragma unroll
+            for (int k = 0; k < P; ++k) v[k] = src[k];
+            const float g = v[P - 1];
+            if (g > 0) {                                                 // calculatePSGP :186-190 (double arithmetic, narrowed once)
+                const double frac = ((double)(fnum - g) * 1.0) / dnum;
+                v[P] = fminf(a.min_gap_open, (float)((double)(a.gap_open * a.scale) * frac));
+                v[P + 1] = fminf(a.min_gap_extend, (float)((double)a.gap_extend * frac));
+            } else {
+                v[P] = a.gap_open;
+                v[P + 1] = a.gap_extend;
+            }
+            float4 *out = reinterpret_cast<float4 *>(a.cols + ((size_t)side * a.stride + dst) * CW);
+#pragma unroll
+            for (int k = 0; k < CW / 4; ++k) out[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) a.len_out[side] = base;
+}
+
+// ---- write-back ----
+struct CommitArgs {
+    const int8_t *paths;          // [n_pairs][path_stride]  final paths (gappy columns restored), codes 0/1/2
+    const int32_t *path_len;      // [n_pairs]  0 = pair not committed
+    int32_t path_stride;
+    int32_t *chunk_base;          // [n_pairs][n_chunks][2]  rows consumed before each 256-code chunk (ref, query)
+    int32_t n_chunks;
+    const SideDesc *sides;
+    const int32_t *member_seq;
+    const uint8_t *member_plane;
+    char *rows0, *rows1;
+    int64_t cap;
+    const int32_t *work;          // [n_work][3]  side, first member, member count
+    float *const *cache;
+    const int32_t *merge;         // [n_merge][4]  pair, ref slot, query slot, destination slot
+    const float *merge_w;         // [n_merge][2]  refWeight, qryWeight
+};
+
+// grid: n_pairs workgroups of 256 threads.
+__global__ void __launch_bounds__(256) path_scan_kernel(CommitArgs a)
+{
+    __shared__ int s_wave[4];
+    const int pair = blockIdx.x;
+    const int n = a.path_len[pair];
+    const int8_t *path = a.paths + (size_t)pair * a.path_stride;
+    int baseR = 0, baseQ = 0;
+    for (int c0 = 0, ch = 0; c0 < n; c0 += 256, ++ch) {
+        const int c = c0 + threadIdx.x;
+        const int code = (c < n) ? path[c] : 3;
+        if (threadIdx.x == 0) {
+            a.chunk_base[((size_t)pair * a.n_chunks + ch) * 2] = baseR;
+            a.chunk_base[((size_t)pair * a.n_chunks + ch) * 2 + 1] = baseQ;
+        }
+        int totR, totQ;
+        (void)block_scan_256(code == 0 || code == 2, &totR, s_wave);
+        (void)block_scan_256(code == 0 || code == 1, &totQ, s_wave);
+        baseR += totR;
+        baseQ += totQ;
+    }
+}
+
+// grid: (n_work, n_chunks), 256 threads: one 256-column chunk of the new rows for a group of members of one side.
+// New row: letter of the old row where the path keeps this side (code 0 or the side's own code), '-' elsewhere
+// (alignment-helper.cpp:389-400, 436-447).
+__global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
+{
+    __shared__ int s_wave[4];
+    const int32_t *w = a.work + (size_t)blockIdx.x * 3;
+    const int side = w[0], pair = side >> 1, isQ = side & 1;
+    const int n = a.path_len[pair];
+    const int c0 = blockIdx.y * 256;
+    if (c0 >= n) return;
+    const int c = c0 + threadIdx.x;
+    const int code = (c < n) ? a.paths[(size_t)pair * a.path_stride + c] : 3;
+    const bool keep = (code == 0) || (code == (isQ ? 1 : 2));
+    int tot;
+    const int src = a.chunk_base[((size_t)pair * a.n_chunks + blockIdx.y) * 2 + isQ] + block_scan_256(keep, &tot, s_wave);
+    if (c >= n) return;
+    const SideDesc sd = a.sides[side];
+    for (int m = w[1]; m < w[1] + w[2]; ++m) {
+        const int mi = sd.member_off + m;
+        const size_t off = (size_t)a.member_seq[mi] * a.cap;
+        const bool pl = a.member_plane[mi];
+        const char *from = (pl ? a.rows1 : a.rows0) + off;
+        char *to = (pl ? a.rows0 : a.rows1) + off;
+        to[c] = keep ? from[src] : '-';
+    }
+}
+
+// grid: (n_merge, n_chunks), 256 threads: merged cache column j (alignment-helper.cpp:506-539).
+template <int P>
+__global__ void __launch_bounds__(256) merge_cache_kernel(CommitArgs a)
+{
+    __shared__ int s_wave[4];
+    const int32_t *mg = a.merge + (size_t)blockIdx.x * 4;
+    const int pair = mg[0];
+    const int n = a.path_len[pair];
+    const int c0 = blockIdx.y * 256;
+    if (c0 >= n) return;
+    const int j = c0 + threadIdx.x;
+    const int code = (j < n) ? a.paths[(size_t)pair * a.path_stride + j] : 3;
+    int tot;
+    const int r = a.chunk_base[((size_t)pair * a.n_chunks + blockIdx.y) * 2] + block_scan_256(code == 0 || code == 2, &tot, s_wave);
+    const int q = a.chunk_base[((size_t)pair * a.n_chunks + blockIdx.y) * 2 + 1] + block_scan_256(code == 0 || code == 1, &tot, s_wave);
+    if (j >= n) return;
+    const float *fr = a.cache[mg[1]] + (size_t)r * P;
+    const float *fq = a.cache[mg[2]] + (size_t)q * P;
+    float *out = a.cache[mg[3]] + (size_t)j * P;
+    const float refWeight = a.merge_w[2 * blockIdx.x], qryWeight = a.merge_w[2 * blockIdx.x + 1];
+    if (code == 0) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) out[k] = fr[k] + fq[k];
+    } else if (code == 1) {
+#pragma unroll
+        for (int k = 0; k < P - 1; ++k) out[k] = fq[k];
+        out[P - 1] = (float)((double)fq[P - 1] + 1.0 * (double)refWeight);
+    } else {
+#pragma unroll
+        for (int k = 0; k < P - 1; ++k) out[k] = fr[k];
+        out[P - 1] = (float)((double)fr[P - 1] + 1.0 * (double)qryWeight);
+    }
+}
+
+// grid: (n_seqs, n_chunks), 256 threads: current row of every sequence, packed back to back (for the final download).
+__global__ void __launch_bounds__(256) gather_rows_kernel(const char *rows0, const char *rows1, int64_t cap, const uint8_t *plane,
+                                                          const int32_t *len, const int64_t *off, char *out)
+{
+    const int s = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= len[s]) return;
+    out[off[s] + c] = (plane[s] ? rows1 : rows0)[(size_t)s * cap + c];
+}
+
+}  // namespace twl

@@ -3,6 +3,8 @@
 // Owns device buffers, streams and the launch policy.  There is no CPU fallback: without a HIP
 // device every entry point fails with TWL_ERR_HIP / TWL_ERR_NOT_INITIALIZED.
 #include "../../include/twl_align.h"
+#include "../../include/twl_level.h"
+#include "level_kernels.hip.h"
 #include "talco_kernel.hip.h"
 
 #include <hip/hip_runtime.h>
@@ -11,10 +13,12 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -147,8 +151,9 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
-               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len)
+               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len, const float *d_packed = nullptr)
 {
+    // d_packed: the level's columns already in the packed [P+2] layout (device-resident level path); no packing pass then
     HIP_TRY(hipSetDevice(d->id));
     d->stats = twl_stats{};
     d->pair_cells.assign((size_t)n_pairs, 0);
@@ -157,7 +162,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int rc;
     const size_t n_cols = (size_t)n_pairs * 2 * (size_t)seq_len;
     const bool prot = (p->P == 22);
-    if ((rc = d->cols.ensure(n_cols * (size_t)(p->P + 2) * sizeof(float)))) return rc;
+    if (!d_packed && (rc = d->cols.ensure(n_cols * (size_t)(p->P + 2) * sizeof(float)))) return rc;
     if ((rc = d->cells.ensure((size_t)n_pairs * sizeof(unsigned long long)))) return rc;
     if ((rc = d->queue.ensure(64))) return rc;
     if ((rc = d->items.ensure((size_t)n_pairs * sizeof(int32_t)))) return rc;
@@ -181,7 +186,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 
     TRACE("run_device n_pairs=%d seq_len=%d", n_pairs, seq_len);
     HIP_TRY(hipEventRecord(d->ev[0], st));
-    {
+    if (!d_packed) {
         const int threads = 256;
         const int blocks = (int)std::min<size_t>((n_cols + threads - 1) / threads, (size_t)d->num_cu * 8);
         if (prot) hipLaunchKernelGGL(twl::pack_kernel<22>, dim3(std::max(blocks, 1)), dim3(threads), 0, st, d_freq, d_gop, d_gex, (float *)d->cols.p, n_cols);
@@ -192,7 +197,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     if (dbg_on()) { HIP_TRY(hipStreamSynchronize(st)); TRACE("pack done"); }
 
     twl::KArgs a{};
-    a.cols = (const float *)d->cols.p;
+    a.cols = d_packed ? d_packed : (const float *)d->cols.p;
     a.len = d_len; a.num = d_num;
     a.aln = d_aln; a.aln_len = d_alnlen; a.err = d_err;
     a.cells = (unsigned long long *)d->cells.p;
@@ -511,3 +516,5 @@ int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)
 }
 
 }  // extern "C"
+
+#include "twl_level.inc.hip"

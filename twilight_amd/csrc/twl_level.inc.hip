@@ -1,0 +1,509 @@
+// twilight_amd/csrc/twl_level.inc.hip -- host side of the device-resident level API (include/twl_level.h).
+// Included at the end of twl_align.hip: it shares that file's Device bookkeeping and run_device().
+//
+// HBM layout of a store (one device):
+//   rows[2]    two planes of [n_seqs][cap] bytes; plane[i] says which one holds sequence i's current row.  A commit writes the new
+//              row of every touched sequence into its other plane and flips the flag (SequenceInfo::changeStorage, sequencedb.cpp:51-55).
+//   caches     one float[len][P] buffer per cached node profile (Node::msaFreq), addressed by the caller's ids.
+//   level      raw[2n][stride][P] -> cols[2n][stride][P+2] (what the DP kernel reads), colinfo[2n][stride], lens, paths.
+
+namespace {
+
+struct CacheEntry {
+    Buf buf;
+    int32_t len = 0;
+};
+
+}  // namespace
+
+struct twl_store {
+    Device *d = nullptr;
+    int P = 6;
+    char type = 'n';
+    int32_t n_seqs = 0;
+    int64_t cap = 0;
+    Buf rows[2];
+    std::vector<uint8_t> plane;
+    std::vector<int32_t> len;
+    std::unordered_map<int32_t, CacheEntry *> cache;
+    Buf lut;
+    // state of the level between prepare / align / commit
+    int32_t n_pairs = 0, seq_len = 0;
+    bool prepared = false;
+    std::vector<twl_side> sides;
+    std::vector<int32_t> members;
+    std::vector<int32_t> h_len, h_num;
+    Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
+    Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew, d_gather, d_off, d_plane, d_rowlen;
+    double prepare_ms = 0, commit_ms = 0;
+};
+
+namespace {
+
+// letterIdx(type, toupper(c)) -- reference src/scoring-matrix.cpp:26-79
+void build_lut(char type, uint8_t *lut)
+{
+    for (int c = 0; c < 256; ++c) {
+        const int u = (c >= 'a' && c <= 'z') ? c - 32 : c;
+        int v;
+        if (type == 'n') {
+            switch (u) {
+            case 'A': v = 0; break;
+            case 'C': v = 1; break;
+            case 'G': v = 2; break;
+            case 'T': case 'U': v = 3; break;
+            case '-': case '.': v = 5; break;
+            default: v = 4; break;
+            }
+        } else {
+            static const char acids[] = "ACDEFGHIKLMNPQRSTVWY";
+            v = 20;
+            for (int k = 0; k < 20; ++k) if (u == acids[k]) v = k;
+            if (u == '-' || u == '.') v = 21;
+        }
+        lut[c] = (uint8_t)v;
+    }
+}
+
+int grow_rows(twl_store *s, int64_t need)
+{
+    if (need <= s->cap) return TWL_OK;
+    Device *d = s->d;
+    int64_t ncap = (need + need / 4 + 255) & ~(int64_t)255;
+    for (int pl = 0; pl < 2; ++pl) {
+        Buf nb;
+        int rc = nb.ensure((size_t)s->n_seqs * (size_t)ncap);
+        if (rc) return rc;
+        if (s->rows[pl].p)
+            HIP_TRY(hipMemcpy2DAsync(nb.p, (size_t)ncap, s->rows[pl].p, (size_t)s->cap, (size_t)s->cap, (size_t)s->n_seqs, hipMemcpyDeviceToDevice, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        s->rows[pl].release();
+        s->rows[pl] = nb;
+    }
+    s->cap = ncap;
+    return TWL_OK;
+}
+
+template <class T>
+int upload(Buf &b, const std::vector<T> &v, hipStream_t st)
+{
+    int rc = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return TWL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int twl_store_create(int device, char type, int32_t n_seqs, const char *const *seqs, const int32_t *lens, twl_store **out)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    if (!out || n_seqs < 0 || (n_seqs > 0 && (!seqs || !lens)) || (type != 'n' && type != 'p')) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    auto *s = new twl_store();
+    s->d = d;
+    s->type = type;
+    s->P = (type == 'n') ? 6 : 22;
+    s->n_seqs = n_seqs;
+    s->plane.assign((size_t)n_seqs, 0);
+    s->len.assign(lens, lens + n_seqs);
+    int64_t maxLen = 1;
+    for (int32_t i = 0; i < n_seqs; ++i) {
+        if (lens[i] < 0) { delete s; g_err = "negative sequence length"; return TWL_ERR_BAD_ARGUMENT; }
+        maxLen = std::max<int64_t>(maxLen, lens[i]);
+    }
+    // room for the alignment to grow before the first re-allocation (rows are re-pitched when a commit outgrows them)
+    if ((rc = grow_rows(s, maxLen + maxLen / 2 + 256))) { twl_store_destroy(s); return rc; }
+    // upload plane 0 through one pitched host image
+    std::vector<char> img((size_t)n_seqs * (size_t)s->cap, '-');
+    for (int32_t i = 0; i < n_seqs; ++i) memcpy(&img[(size_t)i * (size_t)s->cap], seqs[i], (size_t)lens[i]);
+    if (!img.empty()) HIP_TRY(hipMemcpy(s->rows[0].p, img.data(), img.size(), hipMemcpyHostToDevice));
+    uint8_t lut[256];
+    build_lut(type, lut);
+    if ((rc = s->lut.ensure(256))) { twl_store_destroy(s); return rc; }
+    HIP_TRY(hipMemcpy(s->lut.p, lut, 256, hipMemcpyHostToDevice));
+    *out = s;
+    return TWL_OK;
+}
+
+void twl_store_destroy(twl_store *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->d->id);
+    for (auto &kv : s->cache) { kv.second->buf.release(); delete kv.second; }
+    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_sides, &s->d_mseq, &s->d_mw, &s->d_mplane, &s->d_tab, &s->d_raw, &s->d_colinfo, &s->d_cols,
+                   &s->d_len, &s->d_lenmask, &s->d_num, &s->d_aln, &s->d_alnlen, &s->d_err, &s->d_paths, &s->d_pathlen, &s->d_chunk, &s->d_work,
+                   &s->d_merge, &s->d_mergew, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
+        b->release();
+    delete s;
+}
+
+int twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out)
+{
+    if (!s || !lens_out) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    for (int32_t i = 0; i < s->n_seqs; ++i) lens_out[i] = s->len[i];
+    if (!rows_out || s->n_seqs == 0) return TWL_OK;
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    std::vector<int64_t> off((size_t)s->n_seqs);
+    int64_t total = 0;
+    int32_t maxLen = 1;
+    for (int32_t i = 0; i < s->n_seqs; ++i) { off[i] = total; total += s->len[i]; maxLen = std::max(maxLen, s->len[i]); }
+    int rc;
+    if ((rc = s->d_gather.ensure((size_t)std::max<int64_t>(total, 16)))) return rc;
+    if ((rc = upload(s->d_off, off, d->stream))) return rc;
+    if ((rc = upload(s->d_plane, s->plane, d->stream))) return rc;
+    if ((rc = upload(s->d_rowlen, s->len, d->stream))) return rc;
+    hipLaunchKernelGGL(twl::gather_rows_kernel, dim3((unsigned)s->n_seqs, (unsigned)((maxLen + 255) / 256)), dim3(256), 0, d->stream,
+                       (const char *)s->rows[0].p, (const char *)s->rows[1].p, s->cap, (const uint8_t *)s->d_plane.p, (const int32_t *)s->d_rowlen.p,
+                       (const int64_t *)s->d_off.p, (char *)s->d_gather.p);
+    HIP_TRY(hipGetLastError());
+    std::unique_ptr<char[]> host(new char[(size_t)std::max<int64_t>(total, 1)]);      // uninitialised on purpose
+    if (total) HIP_TRY(hipMemcpyAsync(host.get(), s->d_gather.p, (size_t)total, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    // scatter into the caller's rows on a few threads (hundreds of MB at the end of a large run)
+    const int nt = (int)std::min<size_t>(8, std::max<size_t>(1, (size_t)total >> 24));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (int32_t i = t; i < s->n_seqs; i += nt)
+                if (rows_out[i] && s->len[i] > 0) memcpy(rows_out[i], &host[(size_t)off[i]], (size_t)s->len[i]);
+        });
+    for (auto &x : th) x.join();
+    return TWL_OK;
+}
+
+int twl_store_read_cache(twl_store *s, int32_t id, float *out, int32_t *len_out)
+{
+    if (!s) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    auto it = s->cache.find(id);
+    if (it == s->cache.end()) { g_err = "unknown cache id"; return TWL_ERR_BAD_ARGUMENT; }
+    if (len_out) *len_out = it->second->len;
+    if (!out) return TWL_OK;
+    std::lock_guard<std::mutex> lk(s->d->mu);
+    HIP_TRY(hipSetDevice(s->d->id));
+    HIP_TRY(hipMemcpy(out, it->second->buf.p, (size_t)it->second->len * s->P * sizeof(float), hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
+int twl_store_drop_cache(twl_store *s, int32_t id)
+{
+    if (!s) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    auto it = s->cache.find(id);
+    if (it == s->cache.end()) return TWL_OK;
+    std::lock_guard<std::mutex> lk(s->d->mu);
+    (void)hipSetDevice(s->d->id);
+    (void)hipStreamSynchronize(s->d->stream);
+    it->second->buf.release();
+    delete it->second;
+    s->cache.erase(it);
+    return TWL_OK;
+}
+
+int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, int32_t n_pairs, const twl_side *sides, const int32_t *members,
+                      const float *member_weight, int32_t seq_len, int32_t *len_out, uint8_t *colinfo_out)
+{
+    if (!s) { g_err = "store is null"; return TWL_ERR_BAD_ARGUMENT; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (p->P != s->P) { g_err = "params.P does not match the store's sequence type"; return TWL_ERR_BAD_ARGUMENT; }
+    if (n_pairs < 0 || seq_len < 1 || (n_pairs > 0 && (!sides || !len_out))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    s->prepared = false;
+    s->n_pairs = n_pairs;
+    s->seq_len = seq_len;
+    if (n_pairs == 0) { s->prepared = true; return TWL_OK; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    const size_t ns = (size_t)n_pairs * 2, P = (size_t)s->P, sl = (size_t)seq_len;
+
+    s->sides.assign(sides, sides + ns);
+    size_t nm = 0;
+    for (size_t i = 0; i < ns; ++i) {
+        const twl_side &sd = sides[i];
+        if (sd.n_members < 0 || sd.member_off < 0 || sd.len < 0 || sd.len > seq_len || sd.num < 1) { g_err = "bad side descriptor"; return TWL_ERR_BAD_ARGUMENT; }
+        nm = std::max(nm, (size_t)sd.member_off + (size_t)sd.n_members);
+    }
+    if (nm > 0 && (!members || !member_weight)) { g_err = "member tables missing"; return TWL_ERR_BAD_ARGUMENT; }
+    s->members.assign(members, members + nm);
+    std::vector<uint8_t> mplane(nm, 0);
+    std::vector<twl::SideDesc> dsides(ns);
+    std::vector<float *> tab;
+    std::unordered_map<int32_t, int32_t> slotOf;
+    auto slot = [&](int32_t id) {
+        auto it = slotOf.find(id);
+        if (it != slotOf.end()) return it->second;
+        tab.push_back((float *)s->cache[id]->buf.p);
+        return slotOf[id] = (int32_t)tab.size() - 1;
+    };
+    for (size_t i = 0; i < ns; ++i) {
+        const twl_side &sd = sides[i];
+        for (int32_t m = 0; m < sd.n_members; ++m) {
+            const int32_t q = members[sd.member_off + m];
+            if (q < 0 || q >= s->n_seqs) { g_err = "member sequence id out of range"; return TWL_ERR_BAD_ARGUMENT; }
+            if (s->len[q] != sd.len) { g_err = "member row length differs from the side's len"; return TWL_ERR_BAD_ARGUMENT; }
+            mplane[sd.member_off + m] = s->plane[q];
+        }
+        twl::SideDesc &ds = dsides[i];
+        ds.n_members = sd.n_members; ds.member_off = sd.member_off; ds.len = sd.len; ds.num = sd.num; ds.weight = sd.weight;
+        ds.cache_slot = ds.store_slot = -1; ds.pad = 0;
+        if (sd.cache_id >= 0) {
+            auto it = s->cache.find(sd.cache_id);
+            if (it == s->cache.end() || it->second->len != sd.len) { g_err = "cache id unknown or of another length"; return TWL_ERR_BAD_ARGUMENT; }
+            ds.cache_slot = slot(sd.cache_id);
+        } else if (sd.store_id >= 0) {
+            if (s->cache.count(sd.store_id)) { g_err = "store_id already in use"; return TWL_ERR_BAD_ARGUMENT; }
+            auto *ce = new CacheEntry();
+            ce->len = sd.len;
+            if ((rc = ce->buf.ensure(std::max<size_t>((size_t)sd.len * P * sizeof(float), 16)))) { delete ce; return rc; }
+            s->cache[sd.store_id] = ce;
+            ds.store_slot = slot(sd.store_id);
+        }
+    }
+    s->h_num.resize(ns);
+    for (size_t i = 0; i < ns; ++i) s->h_num[i] = sides[i].num;
+
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    if ((rc = upload(s->d_sides, dsides, st))) return rc;
+    if ((rc = upload(s->d_mseq, s->members, st))) return rc;
+    { std::vector<float> w(member_weight, member_weight + nm); if ((rc = upload(s->d_mw, w, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    if ((rc = upload(s->d_mplane, mplane, st))) return rc;
+    if ((rc = upload(s->d_tab, tab, st))) return rc;
+    if ((rc = upload(s->d_num, s->h_num, st))) return rc;
+    if ((rc = s->d_raw.ensure(ns * sl * P * sizeof(float)))) return rc;
+    if ((rc = s->d_colinfo.ensure(ns * sl))) return rc;
+    if ((rc = s->d_cols.ensure(ns * sl * (P + 2) * sizeof(float)))) return rc;
+    if ((rc = s->d_len.ensure(ns * sizeof(int32_t)))) return rc;
+
+    twl::LevelArgs a{};
+    a.sides = (const twl::SideDesc *)s->d_sides.p;
+    a.member_seq = (const int32_t *)s->d_mseq.p;
+    a.member_w = (const float *)s->d_mw.p;
+    a.member_plane = (const uint8_t *)s->d_mplane.p;
+    a.rows0 = (const char *)s->rows[0].p; a.rows1 = (const char *)s->rows[1].p;
+    a.cap = s->cap;
+    a.cache = (float *const *)s->d_tab.p;
+    a.lut = (const uint8_t *)s->lut.p;
+    a.raw = (float *)s->d_raw.p;
+    a.colinfo = (uint8_t *)s->d_colinfo.p;
+    a.cols = (float *)s->d_cols.p;
+    a.len_out = (int32_t *)s->d_len.p;
+    a.stride = seq_len;
+    a.gappy_thr = gappy_threshold;
+    a.remove = (gappy_threshold == 1.0) ? 0 : 1;                         // alignment-helper.cpp:77
+    a.gap_open = p->gap_open; a.gap_extend = p->gap_extend;
+    a.scale = (s->type == 'n') ? 0.5f : 1.0f;                            // :171
+    a.min_gap_extend = p->gap_extend * 0.2;                              // :174  (double product narrowed to float)
+    a.min_gap_open = p->gap_open * 0.1;                                  // :175
+    int32_t maxLen = 1;
+    for (size_t i = 0; i < ns; ++i) maxLen = std::max(maxLen, sides[i].len);
+    const dim3 gridP((unsigned)ns, (unsigned)((maxLen + 255) / 256));
+    if (s->P == 6) {
+        hipLaunchKernelGGL(twl::profile_kernel<6>, gridP, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(twl::compact_kernel<6>, dim3((unsigned)ns), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(twl::profile_kernel<22>, gridP, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(twl::compact_kernel<22>, dim3((unsigned)ns), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(d->ev[1], st));
+    s->h_len.resize(ns);
+    HIP_TRY(hipMemcpyAsync(s->h_len.data(), s->d_len.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (colinfo_out) HIP_TRY(hipMemcpyAsync(colinfo_out, s->d_colinfo.p, ns * sl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
+    s->prepare_ms = ms;
+    for (size_t i = 0; i < ns; ++i) len_out[i] = s->h_len[i];
+    s->prepared = true;
+    return TWL_OK;
+}
+
+int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out)
+{
+    if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (p->P != s->P) { g_err = "params.P does not match the store's sequence type"; return TWL_ERR_BAD_ARGUMENT; }
+    const int32_t n = s->n_pairs;
+    if (n == 0) return TWL_OK;
+    if (!aln_out || !aln_len_out || !err_out) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    const size_t sl = (size_t)s->seq_len;
+    std::vector<int32_t> lm(s->h_len);
+    if (run_mask)
+        for (int32_t i = 0; i < n; ++i) if (!run_mask[i]) lm[2 * i] = lm[2 * i + 1] = 0;
+    if ((rc = upload(s->d_lenmask, lm, st))) return rc;
+    if ((rc = s->d_aln.ensure((size_t)n * 2 * sl))) return rc;
+    if ((rc = s->d_alnlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = s->d_err.ensure((size_t)n * sizeof(int16_t)))) return rc;
+    HIP_TRY(hipEventRecord(d->ev[5], st));
+    rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->d_lenmask.p, (const int32_t *)s->d_num.p, (int8_t *)s->d_aln.p,
+                    (int32_t *)s->d_alnlen.p, (int16_t *)s->d_err.p, lm.data(), (const float *)s->d_cols.p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(aln_len_out, s->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(err_out, s->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // paths: bulk when most pairs ran, else one copy per pair that has a path
+    int32_t ran = 0;
+    for (int32_t i = 0; i < n; ++i) ran += aln_len_out[i] > 0;
+    if (ran * 2 >= n) HIP_TRY(hipMemcpyAsync(aln_out, s->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
+    else
+        for (int32_t i = 0; i < n; ++i)
+            if (aln_len_out[i] > 0)
+                HIP_TRY(hipMemcpyAsync(aln_out + (size_t)i * 2 * sl, (int8_t *)s->d_aln.p + (size_t)i * 2 * sl, (size_t)aln_len_out[i], hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(d->ev[3], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[5], d->ev[3]));
+    d->stats.total_ms = ms;
+    return TWL_OK;
+}
+
+int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride)
+{
+    if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
+    const int32_t n = s->n_pairs;
+    s->prepared = false;
+    if (n == 0) return TWL_OK;
+    if (!paths || !path_len || path_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    const size_t P = (size_t)s->P;
+    int32_t maxPath = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (path_len[i] < 0 || path_len[i] > path_stride) { g_err = "path_len outside [0, path_stride]"; return TWL_ERR_BAD_ARGUMENT; }
+        maxPath = std::max(maxPath, path_len[i]);
+    }
+    if (maxPath == 0) return TWL_OK;
+    int rc;
+    if ((rc = grow_rows(s, maxPath))) return rc;
+    const int32_t nChunks = (maxPath + 255) / 256;
+
+    constexpr int MG = 16;                      // members per workgroup of the row rewrite
+    std::vector<int32_t> work, merge;
+    std::vector<float> mergew;
+    std::vector<float *> tab;
+    struct Pending { int32_t refId, qryId; CacheEntry *dst; };
+    std::vector<Pending> pend;
+    for (int32_t i = 0; i < n; ++i) {
+        if (path_len[i] == 0) continue;
+        for (int sd = 0; sd < 2; ++sd) {
+            const twl_side &x = s->sides[2 * (size_t)i + sd];
+            for (int32_t m = 0; m < x.n_members; m += MG) { work.push_back(2 * i + sd); work.push_back(m); work.push_back(std::min(MG, x.n_members - m)); }
+        }
+        const twl_side &r = s->sides[2 * (size_t)i], &q = s->sides[2 * (size_t)i + 1];
+        const int32_t rid = r.cache_id >= 0 ? r.cache_id : r.store_id, qid = q.cache_id >= 0 ? q.cache_id : q.store_id;
+        if (rid >= 0 && qid >= 0) {             // updateFrequency: both nodes carry a cached profile
+            auto *ce = new CacheEntry();
+            ce->len = path_len[i];
+            if ((rc = ce->buf.ensure((size_t)path_len[i] * P * sizeof(float)))) { delete ce; return rc; }
+            merge.push_back(i);
+            merge.push_back((int32_t)tab.size()); tab.push_back((float *)s->cache[rid]->buf.p);
+            merge.push_back((int32_t)tab.size()); tab.push_back((float *)s->cache[qid]->buf.p);
+            merge.push_back((int32_t)tab.size()); tab.push_back((float *)ce->buf.p);
+            mergew.push_back(r.weight); mergew.push_back(q.weight);
+            pend.push_back({rid, qid, ce});
+        }
+    }
+    // current planes of the members (prepare's table may be stale if a sequence took part in an earlier commit of this level: it cannot,
+    // a sequence belongs to one node of one pair per level)
+    std::vector<uint8_t> mplane(s->members.size(), 0);
+    for (size_t k = 0; k < s->members.size(); ++k) mplane[k] = s->plane[s->members[k]];
+
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    if ((rc = s->d_paths.ensure((size_t)n * (size_t)path_stride))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
+    { std::vector<int32_t> pl(path_len, path_len + n); if ((rc = upload(s->d_pathlen, pl, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    if ((rc = s->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = upload(s->d_work, work, st))) return rc;
+    if ((rc = upload(s->d_merge, merge, st))) return rc;
+    if ((rc = upload(s->d_mergew, mergew, st))) return rc;
+    if ((rc = upload(s->d_tab, tab, st))) return rc;
+    if ((rc = upload(s->d_mplane, mplane, st))) return rc;
+
+    twl::CommitArgs a{};
+    a.paths = (const int8_t *)s->d_paths.p;
+    a.path_len = (const int32_t *)s->d_pathlen.p;
+    a.path_stride = path_stride;
+    a.chunk_base = (int32_t *)s->d_chunk.p;
+    a.n_chunks = nChunks;
+    a.sides = (const twl::SideDesc *)s->d_sides.p;
+    a.member_seq = (const int32_t *)s->d_mseq.p;
+    a.member_plane = (const uint8_t *)s->d_mplane.p;
+    a.rows0 = (char *)s->rows[0].p; a.rows1 = (char *)s->rows[1].p;
+    a.cap = s->cap;
+    a.work = (const int32_t *)s->d_work.p;
+    a.cache = (float *const *)s->d_tab.p;
+    a.merge = (const int32_t *)s->d_merge.p;
+    a.merge_w = (const float *)s->d_mergew.p;
+    hipLaunchKernelGGL(twl::path_scan_kernel, dim3((unsigned)n), dim3(256), 0, st, a);
+    const unsigned nWork = (unsigned)(work.size() / 3), nMerge = (unsigned)(merge.size() / 4);
+    if (nWork) hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)nChunks), dim3(256), 0, st, a);
+    if (nMerge) {
+        if (s->P == 6) hipLaunchKernelGGL(twl::merge_cache_kernel<6>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(twl::merge_cache_kernel<22>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(d->ev[1], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
+    s->commit_ms = ms;
+
+    // bookkeeping: every member of a committed pair now lives in its other plane with the path's length
+    for (int32_t i = 0; i < n; ++i) {
+        if (path_len[i] == 0) continue;
+        for (int sd = 0; sd < 2; ++sd) {
+            const twl_side &x = s->sides[2 * (size_t)i + sd];
+            for (int32_t m = 0; m < x.n_members; ++m) {
+                const int32_t q = s->members[x.member_off + m];
+                s->plane[q] ^= 1;
+                s->len[q] = path_len[i];
+            }
+        }
+    }
+    for (const Pending &pe : pend) {            // merged profile replaces the reference node's cache, the query node's is dropped
+        CacheEntry *oldR = s->cache[pe.refId], *oldQ = s->cache[pe.qryId];
+        oldR->buf.release(); delete oldR;
+        oldQ->buf.release(); delete oldQ;
+        s->cache.erase(pe.qryId);
+        s->cache[pe.refId] = pe.dst;
+    }
+    return TWL_OK;
+}
+
+int twl_level_read_columns(twl_store *s, int32_t pair, int32_t side, float *out, int32_t max_cols)
+{
+    if (!s || !s->prepared || pair < 0 || pair >= s->n_pairs || side < 0 || side > 1 || !out) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    const size_t CW = (size_t)s->P + 2;
+    const int32_t n = std::min(max_cols, s->h_len[2 * (size_t)pair + side]);
+    std::lock_guard<std::mutex> lk(s->d->mu);
+    HIP_TRY(hipSetDevice(s->d->id));
+    if (n > 0)
+        HIP_TRY(hipMemcpy(out, (const float *)s->d_cols.p + ((size_t)pair * 2 + side) * (size_t)s->seq_len * CW, (size_t)n * CW * sizeof(float), hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
+int twl_level_timing(twl_store *s, double *prepare_ms, double *commit_ms)
+{
+    if (!s) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (prepare_ms) *prepare_ms = s->prepare_ms;
+    if (commit_ms) *commit_ms = s->commit_ms;
+    return TWL_OK;
+}
+
+}  // extern "C"
