@@ -25,18 +25,23 @@ def main():
     ap.add_argument("--indel", type=float, default=0.001)
     ap.add_argument("--seed", type=int, default=20260501)
     ap.add_argument("--out", default="")
+    ap.add_argument("--keep", default="", help="write the generated tree/sequences into this directory (t.nwk, s.fa) and keep them")
+    ap.add_argument("--generate-only", action="store_true")
     a = ap.parse_args()
     P = 6 if a.type == "n" else 22
     sys.setrecursionlimit(100000)
     t0 = time.perf_counter()
     nwk, seqs = synth.make_family(a.leaves, a.length, P=P, seed=a.seed, sub=a.sub, indel=a.indel)
-    d = tempfile.mkdtemp(prefix="twl_e2e_")
+    d = a.keep or tempfile.mkdtemp(prefix="twl_e2e_")
+    os.makedirs(d, exist_ok=True)
     open(os.path.join(d, "t.nwk"), "w").write(nwk + "\n")
     with open(os.path.join(d, "s.fa"), "w") as f:
         for name, s in seqs:
             f.write(f">{name}\n{s}\n")
     gen = time.perf_counter() - t0
     res = {"leaves": a.leaves, "length": a.length, "type": a.type, "generate_s": gen}
+    if a.generate_only:
+        print(json.dumps(res)); return
     gpu_out = os.path.join(d, "gpu.aln")
     wall, r = run([os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), "-t", os.path.join(d, "t.nwk"), "-i", os.path.join(d, "s.fa"), "-o", gpu_out,
                    "--type", a.type, "-v"])
