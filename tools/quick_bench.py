@@ -8,11 +8,11 @@ from twilight_amd import synth
 def main():
     n = int(sys.argv[1]); length = int(sys.argv[2]); mem = sys.argv[3] if len(sys.argv) > 3 else "prof"
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-    members = (1, 1) if mem.startswith("leaf") else ((1, 8), (1, 8))
+    members = (1, 1) if mem.startswith("leaf") else (((32, 64), (32, 64)) if mem.startswith("deep") else ((1, 8), (1, 8)))
     prot = mem.endswith("_p")
     pool = min(n, 32)
     t0 = time.time()
-    b = synth.make_level_batch(pool, length, members=members, seed=5, P=(22 if prot else 6), sub=(0.15 if prot else 0.06))
+    b = synth.make_level_batch(pool, length, members=members, seed=5, P=(22 if prot else 6), sub=((0.4 if mem.startswith("deep") else 0.15) if prot else 0.06))
     print(f"gen {pool} pairs in {time.time()-t0:.1f}s", flush=True)
     import torch
     import twilight_amd as twl

@@ -142,7 +142,16 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
     constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP, CW = C::CW, F4 = C::F4;
     constexpr int MS = P - 1;                    // matrix side
 
+    // Protein sparse mode (MM == 3): the score loop runs over the NON-ZERO letters of the reference column only.  A skipped
+    // letter l has r[l] == 0, so each of its 21 products is +-0 and so is their block sum; adding +-0 to the running sum (which
+    // starts at +0 and therefore is never -0) changes nothing, so the result is bit-identical to the dense loop.  The letters are
+    // visited in ascending order, the reference's order.  s_rmask holds the non-zero-letter bitmask of every ring column (computed
+    // once when the column enters the ring), s_M the matrix rows padded to 24 floats.
+    constexpr bool SPARSE = (P == 22) && (MM == 3);
+    static_assert(!SPARSE || REFLDS, "sparse mode reads the reference column from the LDS ring");
     __shared__ float4 s_ring[C::RING_F4];
+    __shared__ uint32_t s_rmask[SPARSE ? CAP : 1];
+    __shared__ float4 s_M4[SPARSE ? 21 * 6 : 1];
     __shared__ int4 s_exch[2][NV];
     __shared__ int s_red[3][4];      // {max key, first unpruned row (min), last unpruned row (max), -}
     __shared__ int s_conv[2][4];     // {vmin, vmax, flags, -}
@@ -162,6 +171,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
 
+    if constexpr (SPARSE) {
+        float *sm = reinterpret_cast<float *>(s_M4);
+        for (int t = threadIdx.x; t < 21 * 24; t += C::THREADS) { const int l = t / 24, m = t % 24; sm[t] = (m < 21) ? a.M[21 * l + m] : 0.0f; }
+    }
     heartbeat(a, 0, 1);
     for (;;) {
         if (threadIdx.x == 0) s_misc[0] = atomicAdd(a.queue, 1);
@@ -233,12 +246,20 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 if constexpr (REFLDS) {
                     const int col = 64 * B + lane;
                     const int slot = (B % NB) * 64 + lane;
+                    uint32_t mk = 0;
 #pragma unroll
                     for (int t = 0; t < F4; ++t) {
                         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (col < refLen) c = colsR[F4 * (size_t)(ref_idx + col) + t];
                         s_ring[t * CAP + slot] = c;
+                        if constexpr (SPARSE) {
+                            if (4 * t + 0 < 21) mk |= (c.x != 0.0f) ? (1u << (4 * t + 0)) : 0u;
+                            if (4 * t + 1 < 21) mk |= (c.y != 0.0f) ? (1u << (4 * t + 1)) : 0u;
+                            if (4 * t + 2 < 21) mk |= (c.z != 0.0f) ? (1u << (4 * t + 2)) : 0u;
+                            if (4 * t + 3 < 21) mk |= (c.w != 0.0f) ? (1u << (4 * t + 3)) : 0u;
+                        }
                     }
+                    if constexpr (SPARSE) s_rmask[slot] = mk;
                 }
             };
 
@@ -333,8 +354,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const bool inband = (unsigned)(i - Lk) <= wk;
                         // reference column r[j] (and, when it is not register-resident, the query column q[i])
                         float rc[CW];
-                        if constexpr (REFLDS) {
-                            int rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
+                        int rs = 0;
+                        uint32_t rmask = 0;
+                        if constexpr (SPARSE) {
+                            rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
+                            const float4 c = s_ring[(F4 - 1) * CAP + rs];          // {X letter, gap, gapOpen, gapExtend}
+                            rc[CW - 4] = c.x; rc[CW - 3] = c.y; rc[CW - 2] = c.z; rc[CW - 1] = c.w;
+                            rmask = inband ? s_rmask[rs] : 0u;
+                        } else if constexpr (REFLDS) {
+                            rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
 #pragma unroll
                             for (int t = 0; t < F4; ++t) {
                                 const float4 c = s_ring[t * CAP + rs];
@@ -387,6 +415,29 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
                                 numer = (l == 0) ? sl : numer + sl;
                             }
+                        } else if constexpr (SPARSE) {
+                            // protein column score over the non-zero letters of r only (see SPARSE above); same per-letter order as below
+                            const float *ringf = reinterpret_cast<const float *>(s_ring);
+                            uint32_t mk = rmask;
+                            while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+                                if (mk != 0u) {
+                                    const int l = __builtin_ctz(mk);
+                                    mk &= mk - 1u;
+                                    const float rl = ringf[(size_t)((l >> 2) * CAP + rs) * 4 + (l & 3)];
+                                    float Mr[24];
+#pragma unroll
+                                    for (int t = 0; t < 6; ++t) {
+                                        const float4 c = s_M4[l * 6 + t];
+                                        Mr[4 * t] = c.x; Mr[4 * t + 1] = c.y; Mr[4 * t + 2] = c.z; Mr[4 * t + 3] = c.w;
+                                    }
+#pragma unroll
+                                    for (int m = 16; m < 21; ++m) numer += (rl * q[m]) * Mr[m];
+                                    float v[8];
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) v[t] = (q[t] * Mr[t]) * rl + (q[8 + t] * Mr[8 + t]) * rl;
+                                    numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
+                                }
+                            }
                         } else {
                             // protein column score, :409-430: per l the scalar tail m=16..20 first, then the two 8-lane
                             // blocks v[t] = (q[t]*M[l][t])*r[l] + (q[8+t]*M[l][8+t])*r[l] summed left to right
@@ -402,8 +453,20 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                             }
                         }
                         if (q5any[r]) {
+                            if constexpr (SPARSE) {      // (r[l]*q[gap])*gc is +-0 for the skipped letters
+                                const float *ringf = reinterpret_cast<const float *>(s_ring);
+                                uint32_t mk = rmask;
+                                while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+                                    if (mk != 0u) {
+                                        const int l = __builtin_ctz(mk);
+                                        mk &= mk - 1u;
+                                        numer += (ringf[(size_t)((l >> 2) * CAP + rs) * 4 + (l & 3)] * q[P - 1]) * gc;
+                                    }
+                                }
+                            } else {
 #pragma unroll
-                            for (int l = 0; l < MS; ++l) numer += (rc[l] * q[P - 1]) * gc;       // :394 / :432
+                                for (int l = 0; l < MS; ++l) numer += (rc[l] * q[P - 1]) * gc;   // :394 / :432
+                            }
                         }
                         if (rgAny) {
 #pragma unroll

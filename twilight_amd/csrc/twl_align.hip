@@ -226,9 +226,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     };
     if (force_wide) rc = launch_wide(items, n_pairs, &grid, &window);
     else if (prot) {
-        const char *pc = getenv("TWL_PROT_CFG");
-        if (pc && std::string(pc) == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+        // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
+        const char *pc = getenv("TWL_PROT_CFG");      // development knob
+        const std::string pcs = pc ? pc : "sparse";
+        if (pcs == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else if (pcs == "dense") rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else rc = launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, items, n_pairs, 0, &grid, &window);
     }
     else if (c == "w8r2") {
         // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
