@@ -155,3 +155,48 @@ def test_many_small_pairs_more_than_workgroups(gpu):
     assert np.array_equal(n, on[idx]) and np.array_equal(err, oerr[idx])
     for i in range(big.n_pairs):
         assert np.array_equal(aln[i, : n[i]], oa[idx[i], : on[idx[i]]])
+
+
+def _rnasim_leaf_batch(n_pairs):
+    """Leaf-vs-leaf pairs from the reference's own RNASim sample (tests/golden/RNASim.fa.gz): one-hot columns, plain gap penalties."""
+    import gzip
+    import os
+
+    seqs, cur = [], []
+    with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "RNASim.fa.gz"), "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if cur:
+                    seqs.append("".join(cur))
+                cur = []
+            else:
+                cur.append(line.strip())
+    if cur:
+        seqs.append("".join(cur))
+    idx = {"A": 0, "C": 1, "G": 2, "T": 3, "U": 3}
+    n = min(n_pairs, len(seqs) // 2)
+    sl = max(len(s) for s in seqs[: 2 * n])
+    freq = np.zeros((n, 2, sl, 6), dtype=np.float32)
+    gop = np.zeros((n, 2, sl), dtype=np.float32)
+    gex = np.zeros((n, 2, sl), dtype=np.float32)
+    ln = np.zeros((n, 2), dtype=np.int32)
+    for i in range(n):
+        for sd in range(2):
+            s = seqs[2 * i + sd].upper()
+            code = np.array([idx.get(c, 4) for c in s])
+            freq[i, sd, np.arange(len(s)), code] = 1.0
+            gop[i, sd, : len(s)] = -50.0
+            gex[i, sd, : len(s)] = -5.0
+            ln[i, sd] = len(s)
+    return synth.LevelBatch(P=6, seq_len=sl, freq=freq, gap_open=gop, gap_extend=gex, len=ln, num=np.ones((n, 2), dtype=np.int32))
+
+
+def test_config2_rnasim_leaf_level_band512(gpu):
+    """BASELINE configs[1]: RNASim leaf pairs as one level batch with fLen = 512, xdrop = 4000.  GPU and oracle must
+    agree on every path and on which pairs overflow the 512-wide band (errorType 2: deferred in the first pass)."""
+    batch = _rnasim_leaf_batch(289)
+    st, ost = _compare(gpu, batch, flen=512, xdrop=4000)
+    # and with the reference's default parameters (xdrop 5000, fLen 4096) nothing fails on this data
+    p = gpu.make_params(M)
+    aln, n, err = gpu.align_batch(p, batch)
+    assert not err.any() and (n > 0).all()

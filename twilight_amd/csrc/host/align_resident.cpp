@@ -66,7 +66,7 @@ void materialise(Tree *T, SequenceDB *db, Option *option)
     for (int i = 0; i < n; ++i) {               // exact-size host rows (memCheck would double and zero-fill both buffers serially)
         auto *s = db->sequences[i];
         if (s->memLen < lens[i]) {
-            for (int b = 0; b < 2; ++b) { delete[] s->alnStorage[b]; s->alnStorage[b] = new char[lens[i]]; }
+            for (int b = 0; b < 2; ++b) { free(s->alnStorage[b]); s->alnStorage[b] = static_cast<char *>(calloc(lens[i] > 0 ? lens[i] : 1, 1)); }
             s->memLen = lens[i];
         }
         rows[i] = s->alnStorage[s->storage];

@@ -113,19 +113,17 @@ SequenceDB::SequenceInfo::SequenceInfo(int id_, const std::string &name_, std::s
     : id(id_), name(name_), len((int)seq.length()), subtreeIdx(subtreeIdx_), weight(weight_)
 {
     memLen = len * timesBigger;
-    alnStorage[0] = new char[memLen > 0 ? memLen : 1];
-    alnStorage[1] = new char[memLen > 0 ? memLen : 1];
-    for (int i = 0; i < memLen; ++i) {
-        alnStorage[0][i] = (i < len) ? seq[i] : '\0';
-        alnStorage[1][i] = '\0';
-    }
+    // calloc: the spare capacity and the second buffer stay untouched (no page is faulted in) until a level writes there
+    alnStorage[0] = static_cast<char *>(calloc(memLen > 0 ? memLen : 1, 1));
+    alnStorage[1] = static_cast<char *>(calloc(memLen > 0 ? memLen : 1, 1));
+    if (len > 0) memcpy(alnStorage[0], seq.data(), (size_t)len);
     if (debug) unalignedSeq = seq;
 }
 
 SequenceDB::SequenceInfo::~SequenceInfo()
 {
-    delete[] alnStorage[0];
-    delete[] alnStorage[1];
+    free(alnStorage[0]);
+    free(alnStorage[1]);
 }
 
 void SequenceDB::SequenceInfo::memCheck(int need)
@@ -133,9 +131,9 @@ void SequenceDB::SequenceInfo::memCheck(int need)
     if (memLen >= need) return;
     const int grown = need * timesBigger;
     for (int b = 0; b < 2; ++b) {
-        char *t = new char[grown];
-        for (int j = 0; j < grown; ++j) t[j] = (j < memLen) ? alnStorage[b][j] : 0;
-        delete[] alnStorage[b];
+        char *t = static_cast<char *>(calloc(grown, 1));
+        if (memLen > 0) memcpy(t, alnStorage[b], (size_t)memLen);
+        free(alnStorage[b]);
         alnStorage[b] = t;
     }
     memLen = grown;
@@ -178,10 +176,41 @@ bool SequenceDB::debug()
 
 namespace io {
 
-// FASTA(.gz) records the way kseq.h delivers them: name = header up to the first blank, sequence = all lines joined
-static bool nextRecord(gzFile f, std::string &carry, std::string &name, std::string &seq)
+// FASTA(.gz) records the way kseq.h delivers them: name = header up to the first blank, sequence = all lines joined.
+// The file is pulled through zlib in 4 MB blocks (gzread handles plain files transparently) and split with memchr.
+struct ChunkReader {
+    gzFile f;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false;
+    explicit ChunkReader(gzFile f_) : f(f_), buf(1 << 22) {}
+    bool fill()
+    {
+        if (eof) return false;
+        const int n = gzread(f, buf.data(), (unsigned)buf.size());
+        pos = 0;
+        end = n > 0 ? (size_t)n : 0;
+        if (n <= 0) eof = true;
+        return n > 0;
+    }
+    // Appends the next physical line (without the newline) to `line`; false at end of file with nothing read.
+    bool getline(std::string &line)
+    {
+        bool any = false;
+        for (;;) {
+            if (pos == end && !fill()) return any;
+            const char *s = buf.data() + pos;
+            const char *nl = static_cast<const char *>(memchr(s, '\n', end - pos));
+            if (nl) { line.append(s, nl - s); pos += (size_t)(nl - s) + 1; return true; }
+            line.append(s, end - pos);
+            pos = end;
+            any = true;
+        }
+    }
+};
+
+static bool nextRecord(ChunkReader &in, std::string &carry, std::string &name, std::string &seq)
 {
-    char buf[1 << 16];
     name.clear();
     seq.clear();
     bool have = false;
@@ -194,20 +223,16 @@ static bool nextRecord(gzFile f, std::string &carry, std::string &name, std::str
     std::string line;
     while (true) {
         line.clear();
-        bool eof = true;
-        while (gzgets(f, buf, sizeof buf)) {            // a physical line can be longer than the buffer
-            eof = false;
-            line += buf;
-            if (!line.empty() && line.back() == '\n') break;
-        }
-        if (eof && line.empty()) return have;
+        if (!in.getline(line)) return have;
         while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
         if (!line.empty() && line[0] == '>') {
             if (have) { carry = line; return true; }
             header(line);
         } else if (have) {
-            for (char c : line)
-                if (!isspace((unsigned char)c)) seq += c;
+            const size_t at = seq.size();
+            seq += line;                               // whole line at once; blanks inside a sequence line are rare
+            if (line.find_first_of(" \t\v\f\r\n") != std::string::npos)
+                seq.erase(std::remove_if(seq.begin() + at, seq.end(), [](char c) { return isspace((unsigned char)c) != 0; }), seq.end());
         }
     }
 }
@@ -237,12 +262,14 @@ void readSequences(const std::string &fileName, SequenceDB *database, Option *op
 {
     gzFile f = gzopen(fileName.c_str(), "r");
     if (!f) { fprintf(stderr, "ERROR: cant open file: %s\n", fileName.c_str()); exit(1); }
+    gzbuffer(f, 1 << 22);
+    ChunkReader in(f);
     const int seqNum_init = (int)database->sequences.size();
     int seqNum = seqNum_init, maxLen = 0, minLen = INT_MAX;
     uint64_t totalLen = 0;
     std::vector<int> lens;
     std::string carry, name, seq;
-    while (nextRecord(f, carry, name, seq)) {
+    while (nextRecord(in, carry, name, seq)) {
         if (tree->allNodes.find(name) == tree->allNodes.end()) continue;
         if (database->name_map.count(name)) {
             printf("WARNING: duplicate leaf names found in the sequence file! Leaf name: %s. Only the first occurrence will be kept.\n", name.c_str());
@@ -278,15 +305,16 @@ void readSequences(const std::string &fileName, SequenceDB *database, Option *op
     const int minTh = (option->lenDev > 0) ? (int)(medLen * (1 - option->lenDev)) : option->minLen;
     const int maxTh = (option->lenDev > 0) ? (int)(medLen * (1 + option->lenDev)) : option->maxLen;
     std::atomic<int> numLowQ{0};
+    uint8_t isAmbig[256];                     // letterIdx(type, toupper(c)) == N / X, tabulated once
+    for (int c = 0; c < 256; ++c) isAmbig[c] = (letterIdx(option->type, (char)toupper(c)) == ((option->type == 'n') ? 4 : 20)) ? 1 : 0;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < seqNum; ++i) {                                                  // io.cpp:134-162
         auto *s = database->sequences[i];
-        const int ambig = (option->type == 'n') ? 4 : 20;
         s->lowQuality = (s->len > maxTh || s->len < minTh);
         if (!s->lowQuality) {
             int cnt = 0;
-            for (int j = 0; j < s->len; ++j)
-                if (letterIdx(option->type, (char)toupper((unsigned char)s->alnStorage[0][j])) == ambig) cnt++;
+            const unsigned char *row = reinterpret_cast<const unsigned char *>(s->alnStorage[0]);
+            for (int j = 0; j < s->len; ++j) cnt += isAmbig[row[j]];
             s->lowQuality = (cnt > (s->len * option->maxAmbig));
         }
         if (s->lowQuality) {
