@@ -200,3 +200,18 @@ def test_config2_rnasim_leaf_level_band512(gpu):
     p = gpu.make_params(M)
     aln, n, err = gpu.align_batch(p, batch)
     assert not err.any() and (n > 0).all()
+
+
+@pytest.mark.parametrize("mode", ["dense", "sparse", "presim"])
+def test_protein_score_modes_match_oracle(gpu, mode, monkeypatch):
+    """The three protein column-score paths (dense loop, loop over non-zero reference letters, scores precomputed by
+    score_matrix_kernel) are the same arithmetic in the same order: each must reproduce the oracle bit for bit."""
+    monkeypatch.setenv("TWL_PROT_CFG", mode)
+    PM = synth.protein_matrix()
+    for seed, members, length in ((3, (1, 1), 500), (4, ((2, 9), (1, 6)), 700), (5, ((20, 40), (20, 40)), 300)):
+        batch = synth.make_level_batch(6, length, members=members, seed=seed, P=22, sub=0.25)
+        _compare(gpu, batch, matrix=PM)
+    # multi-tile (small marker) and a zero gap-letter score (deferred-pass rule, alignment-cpu.cpp:88)
+    batch = synth.make_level_batch(5, 900, members=((1, 5), (1, 5)), seed=8, P=22, sub=0.2)
+    _compare(gpu, batch, matrix=PM, marker=128)
+    _compare(gpu, batch, matrix=PM, gap_char=0.0)

@@ -51,6 +51,10 @@ struct KArgs {
     float gap_open, gap_extend, gap_char;
     int32_t xdrop, flen, marker;
     float M[441];             // scoreMatrix[l][m] row-major, (P-1)x(P-1): 5x5 or 21x21
+    // matrix mode 4 (protein, few pairs): column scores precomputed by score_matrix_kernel, diagonal-major per pair:
+    // sim[sim_off[pair] + (i + j) * pitch + i] with i = query row, j = reference column, pitch = (Q + 63) & ~63
+    const float *sim;
+    const long long *sim_off;
 };
 
 #ifdef TWL_KERNEL_STAMPS
@@ -148,6 +152,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
     // visited in ascending order, the reference's order.  s_rmask holds the non-zero-letter bitmask of every ring column (computed
     // once when the column enters the ring), s_M the matrix rows padded to 24 floats.
     constexpr bool SPARSE = (P == 22) && (MM == 3);
+    constexpr bool PRESIM = (P == 22) && (MM == 4);      // scores come from score_matrix_kernel (same arithmetic, done ahead by the whole GPU)
+    static_assert(!PRESIM || REFLDS, "presim mode takes the gap penalties of the reference column from the LDS ring");
     static_assert(!SPARSE || REFLDS, "sparse mode reads the reference column from the LDS ring");
     __shared__ float4 s_ring[C::RING_F4];
     __shared__ uint32_t s_rmask[SPARSE ? CAP : 1];
@@ -189,6 +195,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * CW);
         const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * CW);
         int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
+        const float *simP = PRESIM ? a.sim + a.sim_off[pair] : nullptr;
+        const int simPitch = (Q + 63) & ~63;
 
         // An empty side produces no path (the caller emits the all-gap path, alignment-cpu.cpp:89-90).
         // NOTE on control flow: no `continue`, and every single-lane block is followed by a workgroup
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
             int refLen = R - ref_idx, qLen = Q - qry_idx;
+            const int simK0 = ref_idx + qry_idx;                                      // global anti-diagonal of the tile's first cell
             const int fLen = min(a.flen, min(refLen, qLen));                          // :258
             // ---- per-slot (virtual wave) state ----
             float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
@@ -356,7 +365,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         float rc[CW];
                         int rs = 0;
                         uint32_t rmask = 0;
-                        if constexpr (SPARSE) {
+                        float presim = 0.0f;
+                        if constexpr (PRESIM) {
+                            if (inband) presim = simP[(size_t)(k + simK0) * (size_t)simPitch + (size_t)(qry_idx + i)];
+                            rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
+                            const float4 c = s_ring[(F4 - 1) * CAP + rs];          // {X letter, gap, gapOpen, gapExtend}
+                            rc[CW - 4] = c.x; rc[CW - 3] = c.y; rc[CW - 2] = c.z; rc[CW - 1] = c.w;
+                        } else if constexpr (SPARSE) {
                             rs = uph[r] - lane; rs += (rs < 0) ? CAP : 0;
                             const float4 c = s_ring[(F4 - 1) * CAP + rs];          // {X letter, gap, gapOpen, gapExtend}
                             rc[CW - 4] = c.x; rc[CW - 3] = c.y; rc[CW - 2] = c.z; rc[CW - 1] = c.w;
@@ -377,7 +392,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                         const float rg = rc[P - 1], gopr = rc[P], gexr = rc[P + 1];
                         const bool rgAny = __builtin_amdgcn_ballot_w64(inband && rg != 0.0f) != 0ull;
                         float numer = 0.0f;
-                        if constexpr (P == 6 && MM == 2 && !PRE) {
+                        if constexpr (PRESIM) {
+                            // nothing to compute: see below
+                        } else if constexpr (P == 6 && MM == 2 && !PRE) {
                             const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
                             float pa[4], pb[4], pc[4];
 #pragma unroll
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
                             }
                         }
-                        if (q5any[r]) {
+                        if (!PRESIM && q5any[r]) {
                             if constexpr (SPARSE) {      // (r[l]*q[gap])*gc is +-0 for the skipped letters
                                 const float *ringf = reinterpret_cast<const float *>(s_ring);
                                 uint32_t mk = rmask;
@@ -468,11 +485,11 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                                 for (int l = 0; l < MS; ++l) numer += (rc[l] * q[P - 1]) * gc;   // :394 / :432
                             }
                         }
-                        if (rgAny) {
+                        if (!PRESIM && rgAny) {
 #pragma unroll
                             for (int m = 0; m < MS; ++m) numer += (rg * q[m]) * gc;              // :395 / :433
                         }
-                        const float sim = denomOne ? numer : numer / denom;                     // :444
+                        const float sim = PRESIM ? presim : (denomOne ? numer : numer / denom);  // :444
 
                         const unsigned t1 = (unsigned)(i - L1e);
                         const bool up_ok = t1 <= w1;                      // i   in band(k-1)
@@ -745,6 +762,116 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             }
         }
         __syncthreads();   // keeps the single-lane block above out of the loop latch (see NOTE on control flow)
+    }
+}
+
+// ---- precomputed protein column scores (matrix mode 4) ----
+// One workgroup = 64 query rows x 64 anti-diagonals of one pair; lane <-> query row, so the stores of one anti-diagonal are
+// consecutive floats, the order the DP kernel reads them in.  Arithmetic and summation order are those of the in-kernel sparse
+// path (and therefore of TALCO-XDrop.cpp:409-444): letters of the reference column in ascending order, per letter the tail
+// m = 16..20 first, then the eight pair sums left to right; then the two gap-letter loops (:432,:433); then the division (:444).
+struct ScoreArgs {
+    const float *cols;
+    const int32_t *len, *num;
+    const int32_t *items;          // pair ids
+    const int32_t *blk_off;        // [n_items + 1] first workgroup of each item
+    int32_t n_items, seq_len;
+    float gap_char;
+    const float *M24;              // [21][24] matrix rows padded to 24 floats (global memory)
+    float *sim;
+    const long long *sim_off;
+};
+
+__global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
+{
+    constexpr int P = 22, CW = 24, F4 = 6;
+    __shared__ float4 s_r[F4 * 128];           // plane-major: reference columns Jmin .. Jmin+126
+    __shared__ uint32_t s_mask[128];
+    __shared__ float4 s_M4[21 * 6];
+    int it = 0;
+    while (it + 1 < a.n_items && (int)blockIdx.x >= a.blk_off[it + 1]) ++it;
+    const int pair = a.items[it];
+    const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
+    const int nI = (Q + 63) >> 6;
+    const int local = (int)blockIdx.x - a.blk_off[it];
+    const int I0 = (local % nI) * 64, K0 = (local / nI) * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Jmin = K0 - I0 - 63;
+    const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * CW);
+    const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * CW);
+    for (int t = threadIdx.x; t < 21 * 6; t += 256) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
+    if (threadIdx.x < 127) {
+        const int J = Jmin + (int)threadIdx.x;
+        uint32_t mk = 0;
+#pragma unroll
+        for (int t = 0; t < F4; ++t) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (J >= 0 && J < R) c = colsR[F4 * (size_t)J + t];
+            s_r[t * 128 + threadIdx.x] = c;
+            if (4 * t + 0 < 21) mk |= (c.x != 0.0f) ? (1u << (4 * t + 0)) : 0u;
+            if (4 * t + 1 < 21) mk |= (c.y != 0.0f) ? (1u << (4 * t + 1)) : 0u;
+            if (4 * t + 2 < 21) mk |= (c.z != 0.0f) ? (1u << (4 * t + 2)) : 0u;
+            if (4 * t + 3 < 21) mk |= (c.w != 0.0f) ? (1u << (4 * t + 3)) : 0u;
+        }
+        s_mask[threadIdx.x] = mk;
+    }
+    const int I = I0 + lane;
+    float q[CW];
+#pragma unroll
+    for (int t = 0; t < F4; ++t) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (I < Q) c = colsQ[F4 * (size_t)I + t];
+        q[4 * t] = c.x; q[4 * t + 1] = c.y; q[4 * t + 2] = c.z; q[4 * t + 3] = c.w;
+    }
+    __syncthreads();
+    const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];
+    const bool denomOne = (denom == 1.0f);
+    const float gc = a.gap_char;
+    const int pitch = (Q + 63) & ~63;
+    float *out = a.sim + a.sim_off[pair];
+    const float *rf = reinterpret_cast<const float *>(s_r);
+    for (int kk = wave; kk < 64; kk += 4) {
+        const int K = K0 + kk;
+        const int J = K - I;
+        const bool ok = (I < Q) && (J >= 0) && (J < R);
+        const int jr = J - Jmin;                       // 0..126 when ok
+        float numer = 0.0f;
+        uint32_t mk = ok ? s_mask[jr] : 0u;
+        const uint32_t mk0 = mk;
+        while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+            if (mk != 0u) {
+                const int l = __builtin_ctz(mk);
+                mk &= mk - 1u;
+                const float rl = rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)];
+                float Mr[24];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const float4 c = s_M4[l * 6 + t];
+                    Mr[4 * t] = c.x; Mr[4 * t + 1] = c.y; Mr[4 * t + 2] = c.z; Mr[4 * t + 3] = c.w;
+                }
+#pragma unroll
+                for (int m = 16; m < 21; ++m) numer += (rl * q[m]) * Mr[m];
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = (q[t] * Mr[t]) * rl + (q[8 + t] * Mr[8 + t]) * rl;
+                numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
+            }
+        }
+        // gap-letter terms: (r[l]*q[gap])*gc over l (:432) and (r[gap]*q[m])*gc over m (:433); terms with a zero factor are +-0
+        mk = mk0;
+        while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+            if (mk != 0u) {
+                const int l = __builtin_ctz(mk);
+                mk &= mk - 1u;
+                numer += (rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)] * q[P - 1]) * gc;
+            }
+        }
+        if (ok) {
+            const float rg = rf[(size_t)(5 * 128 + jr) * 4 + 1];
+#pragma unroll
+            for (int m = 0; m < 21; ++m) numer += (rg * q[m]) * gc;
+            out[(size_t)K * (size_t)pitch + (size_t)I] = denomOne ? numer : numer / denom;
+        }
     }
 }
 

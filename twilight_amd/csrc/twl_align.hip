@@ -65,6 +65,7 @@ struct Device {
     int num_cu = 0;
     int fast_blocks_per_cu = 0, wide_blocks_per_cu = 0;
     Buf cols, tb, cells, queue, items, errs, dbg;
+    Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
     std::vector<int32_t> dbg_host;
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
@@ -231,7 +232,48 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const std::string pcs = pc ? pc : "sparse";
         if (pcs == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
         else if (pcs == "dense") rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else rc = launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else {
+            // Few pairs (upper tree levels): the serial diagonal chain of each pair is what costs, and most of its instructions are the
+            // column score.  Scores do not depend on the DP state, so the otherwise idle CUs compute them for the whole R x Q matrix
+            // first (score_matrix_kernel, same arithmetic) and the DP kernel only loads them (matrix mode 4).
+            size_t simFloats = 0;
+            std::vector<long long> off((size_t)n_pairs, 0);
+            std::vector<int32_t> blk((size_t)n_pairs + 1, 0);
+            for (int32_t t = 0; t < n_pairs; ++t) {
+                const int32_t pr = order[t];
+                const long long R = std::max(0, h_len[2 * pr]), Q = std::max(0, h_len[2 * pr + 1]);
+                off[pr] = (long long)simFloats;
+                const long long pitch = (Q + 63) & ~63ll;
+                const bool live = R > 0 && Q > 0;
+                simFloats += live ? (size_t)((R + Q) * pitch) : 0;
+                blk[t + 1] = blk[t] + (live ? (int32_t)(((R + Q - 1 + 63) / 64) * ((Q + 63) / 64)) : 0);
+            }
+            const bool few = n_pairs <= std::max(1, d->num_cu / 2);      // measured break-even vs the sparse in-kernel path: ~150 pairs of 2 kaa
+            const bool fits = simFloats * sizeof(float) <= ((size_t)16 << 30) && blk[n_pairs] > 0;
+            if ((pcs == "presim" || (pcs == "sparse" && few)) && fits) {
+                if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
+                if ((rc = d->sim_off.ensure(off.size() * sizeof(long long)))) return rc;
+                if ((rc = d->blk_off.ensure(blk.size() * sizeof(int32_t)))) return rc;
+                if ((rc = d->m24.ensure(21 * 24 * sizeof(float)))) return rc;
+                std::vector<float> m24(21 * 24, 0.0f);
+                for (int l = 0; l < 21; ++l) for (int m = 0; m < 21; ++m) m24[24 * l + m] = a.M[21 * l + m];
+                HIP_TRY(hipMemcpyAsync(d->sim_off.p, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(d->blk_off.p, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));      // the host vectors above go out of scope
+                twl::ScoreArgs sa{};
+                sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
+                sa.n_items = n_pairs; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p;
+                sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
+                hipLaunchKernelGGL(twl::score_matrix_kernel, dim3((unsigned)blk[n_pairs]), dim3(256), 0, st, sa);
+                HIP_TRY(hipGetLastError());
+                a.sim = (const float *)d->sim.p;
+                a.sim_off = (const long long *)d->sim_off.p;
+                rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
+            } else {
+                rc = launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, items, n_pairs, 0, &grid, &window);
+            }
+        }
     }
     else if (c == "w8r2") {
         // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
