@@ -176,3 +176,46 @@ def test_rows_grow_past_initial_capacity(gpu):
         assert rows[i] == b"-" * (400 * i) + seqs[i] + b"-" * (400 * (3 - i)), f"row {i}"
     assert rows[4] == seqs[4]
     st.close()
+
+
+def test_level_edge_cases(gpu):
+    """Empty side, run masks, a level that commits nothing, and argument errors of the level API."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    rng = np.random.default_rng(9)
+    mk = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8))
+    seqs = [mk(120), mk(130), mk(90), b"", mk(64), mk(64)]
+    one = np.asarray([1.0], dtype=F)
+    p = twl.make_params(LC.matrix_of("n"))
+    st = L.Store(seqs, "n")
+    pairs = [[L.Side([0], one, 120, 1, 1.0), L.Side([1], one, 130, 1, 1.0)],
+             [L.Side([2], one, 90, 1, 1.0), L.Side([3], one, 0, 1, 1.0)],          # empty query side (alignment-cpu.cpp:89-90)
+             [L.Side([4], one, 64, 1, 1.0), L.Side([5], one, 64, 1, 1.0)]]
+    lens, info = st.prepare(p, pairs)
+    assert lens.tolist() == [[120, 130], [90, 0], [64, 64]]
+    aln, n, err = st.align(p, run_mask=np.array([1, 1, 0], dtype=np.uint8))
+    assert n[0] > 0 and n[1] == 0 and n[2] == 0 and not err.any()                 # empty side and masked pair: no path, no error
+    aln2, n2, err2 = st.align(p, run_mask=np.array([0, 0, 1], dtype=np.uint8))    # second call on the same prepared level
+    assert n2[0] == 0 and n2[2] > 0
+    full = st.align(p)
+    assert np.array_equal(full[0][0, : n[0]], aln[0, : n[0]]) and np.array_equal(full[0][2, : n2[2]], aln2[2, : n2[2]])
+    # commit: pair 0 its path, pair 1 the all-gap path the caller builds for an empty side, pair 2 deferred
+    st.commit([aln[0, : n[0]], np.full(90, 2, np.int8), np.zeros(0, np.int8)])
+    rows = st.rows()
+    assert len(rows[0]) == n[0] == len(rows[1]) and rows[0].replace(b"-", b"") == seqs[0] and rows[1].replace(b"-", b"") == seqs[1]
+    assert rows[2] == seqs[2] and rows[3] == b"-" * 90 and rows[4] == seqs[4] and rows[5] == seqs[5]
+    # a level without any pair to commit, then errors
+    st.prepare(p, [[L.Side([4], one, 64, 1, 1.0), L.Side([5], one, 64, 1, 1.0)]])
+    st.commit([np.zeros(0, np.int8)])
+    with pytest.raises(twl.TwlError):
+        st.align(p)                                                               # nothing prepared any more
+    with pytest.raises(twl.TwlError):
+        st.prepare(p, [[L.Side([0], one, 120, 1, 1.0), L.Side([1], one, 130, 1, 1.0)]])   # rows 0/1 are n[0] long now
+    with pytest.raises(twl.TwlError):
+        st.prepare(p, [[L.Side([4], one, 64, 1, 1.0), L.Side([99], one, 64, 1, 1.0)]])
+    with pytest.raises(twl.TwlError):
+        st.prepare(p, [[L.Side([4], one, 64, 1, 1.0, cache_id=5), L.Side([5], one, 64, 1, 1.0)]])
+    with pytest.raises(twl.TwlError):
+        st.prepare(twl.make_params(LC.matrix_of("p")), [[L.Side([4], one, 64, 1, 1.0), L.Side([5], one, 64, 1, 1.0)]])
+    st.close()

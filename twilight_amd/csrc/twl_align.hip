@@ -229,7 +229,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else if (prot) {
         // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
         const char *pc = getenv("TWL_PROT_CFG");      // development knob
-        const std::string pcs = pc ? pc : "sparse";
+        const std::string pcs = pc ? pc : "auto";          // auto | dense | sparse | presim | r1
         if (pcs == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
         else if (pcs == "dense") rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
         else {
@@ -250,7 +250,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             }
             const bool few = n_pairs <= std::max(1, d->num_cu / 2);      // measured break-even vs the sparse in-kernel path: ~150 pairs of 2 kaa
             const bool fits = simFloats * sizeof(float) <= ((size_t)16 << 30) && blk[n_pairs] > 0;
-            if ((pcs == "presim" || (pcs == "sparse" && few)) && fits) {
+            if ((pcs == "presim" || (pcs == "auto" && few)) && fits) {
                 if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
                 if ((rc = d->sim_off.ensure(off.size() * sizeof(long long)))) return rc;
                 if ((rc = d->blk_off.ensure(blk.size() * sizeof(int32_t)))) return rc;
