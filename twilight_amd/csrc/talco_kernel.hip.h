@@ -210,11 +210,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         int steps_left = (int)min((long long)(R + Q + 2) * ((R + Q) / (max(a.marker, 2) - 1) + 4) + a.step_slack, 0x7fffffffll);
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
 #ifdef TWL_KERNEL_STAMPS
-        unsigned long long st_slots = 0, st_bar = 0, st_post = 0, st_n = 0, st_act = 0;
+        unsigned long long st_slots = 0, st_bar = 0, st_post = 0, st_n = 0, st_act = 0, st_exit = 0, st_setup = 0;
         const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
+            TWL_STAMP(t_tile0);
             int refLen = R - ref_idx, qLen = Q - qry_idx;
             const int simK0 = ref_idx + qry_idx;                                      // global anti-diagonal of the tile's first cell
             const int fLen = min(a.flen, min(refLen, qLen));                          // :258
@@ -307,6 +308,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             unsigned tile_cells = 0;                     // < 2^32 per tile: at most (refLen+qLen) diagonals x 4096 cells
 
             heartbeat(a, 2, tile);
+#ifdef TWL_KERNEL_STAMPS
+            st_setup += __builtin_amdgcn_s_memtime() - t_tile0;
+#endif
             for (; k < kEnd; ++k) {
                 heartbeat(a, 3, k);
                 TWL_STAMP(t_head);
@@ -647,6 +651,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
                 if (converged && msKey > convKey) { conv_logic = true; break; }          // :609-612
             }
 
+            TWL_STAMP(t_exit0);
             cells += tile_cells;
             dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
             if (tile_err != 0) { err = tile_err; break; }
@@ -737,6 +742,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             }
             __syncthreads();
             err = __builtin_amdgcn_readfirstlane(s_misc[2] == 3 ? 3 : err);
+#ifdef TWL_KERNEL_STAMPS
+            st_exit += __builtin_amdgcn_s_memtime() - t_exit0;
+#endif
             if (err != 0) break;
             ++tile;
         }
@@ -747,6 +755,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
             long long *g = reinterpret_cast<long long *>(a.dbg) + 8 + 8 * w;
             g[0] = (long long)st_slots; g[1] = (long long)st_bar; g[2] = (long long)st_post; g[3] = (long long)st_n; g[4] = (long long)st_act;
             g[5] = (long long)(__builtin_amdgcn_s_memtime() - st_t0);
+            g[6] = (long long)st_exit; g[7] = (long long)st_setup;
         }
 #endif
         __syncthreads();
