@@ -87,3 +87,37 @@ def test_product_equals_oracle_on_synthetic_family(built, tmp_path, kind, n, len
     assert _md5(outs["gpu"]) == _md5(outs["oracle"])
     names, rows = _rows(outs["gpu"])
     assert len(names) == n and len(set(len(x) for x in rows)) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,flags", [
+    ("n", ["-r", "0.7"]),                                   # more columns count as gappy: runs on both sides, pairwiseGlobal splices
+    ("n", ["-r", "1"]),                                     # gappy-column removal off (alignment-helper.cpp:77)
+    ("n", ["-w", "--gap-open", "-30", "--gap-extend", "-3"]),   # wildcard matrix (general 5x5 kernel mode), other gap penalties / X-drop
+    ("n", ["--length-deviation", "0.004"]),                 # some sequences are deferred: main pass on the device, deferred pass after the hand-over
+    ("p", ["-r", "0.8", "--gap-open", "-40"]),
+    ("p", ["--length-deviation", "0.01", "-w"]),
+])
+@pytest.mark.timeout(900)
+def test_product_equals_oracle_with_cli_variants(built, tmp_path, kind, flags):
+    """Device-resident CLI path vs the CPU checker under non-default options; plus resident == host-staged."""
+    from twilight_amd import synth
+
+    n, length = (48, 900) if kind == "n" else (28, 400)
+    nwk, seqs = synth.make_family(n, length, P=(6 if kind == "n" else 22), seed=77, sub=0.03, indel=0.006)
+    (tmp_path / "t.nwk").write_text(nwk + "\n")
+    (tmp_path / "s.fa").write_text("".join(f">{name}\n{seq}\n" for name, seq in seqs))
+    outs = {}
+    runs = (("oracle", os.path.join(ROOT, "oracle", "e2e_oracle"), []), ("gpu", os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), []),
+            ("staged", os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), ["--host-staged"]))
+    for tag, exe, extra in runs:
+        out = tmp_path / f"{tag}.aln"
+        r = subprocess.run([exe, "-t", str(tmp_path / "t.nwk"), "-i", str(tmp_path / "s.fa"), "-o", str(out), "--type", kind, "--check"] + flags + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "illegal alignment" not in r.stderr
+        outs[tag] = (out, r.stderr)
+    assert _md5(outs["gpu"][0]) == _md5(outs["oracle"][0]), flags
+    assert _md5(outs["staged"][0]) == _md5(outs["oracle"][0]), flags
+    if "--length-deviation" in flags:
+        assert "Realign profiles that have been deferred" in outs["gpu"][1], "the variant was meant to exercise the deferred pass"
