@@ -61,15 +61,24 @@ void materialise(Tree *T, SequenceDB *db, Option *option)
     std::vector<int32_t> lens(n);
     int rc = twl_store_read_rows(g_store, nullptr, lens.data());
     if (rc != TWL_OK) die("twl_store_read_rows", rc);
+    // One block for all rows, laid out like the device's gathered buffer (row i at the prefix sum of the lengths), so the library
+    // copies straight into it; the second half backs the sequences' other buffer (untouched until a later pass writes there).
     std::vector<char *> rows(n);
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {               // exact-size host rows (memCheck would double and zero-fill both buffers serially)
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)lens[i];
+    free(db->rowArena);
+    db->rowArena = static_cast<char *>(malloc(2 * total + 1));
+    if (!db->rowArena) { std::cerr << "ERROR: out of host memory for the final rows.\n"; exit(1); }
+    size_t at = 0;
+    for (int i = 0; i < n; ++i) {
         auto *s = db->sequences[i];
-        if (s->memLen < lens[i]) {
-            for (int b = 0; b < 2; ++b) { free(s->alnStorage[b]); s->alnStorage[b] = static_cast<char *>(calloc(lens[i] > 0 ? lens[i] : 1, 1)); }
-            s->memLen = lens[i];
-        }
+        if (!s->borrowed) { free(s->alnStorage[0]); free(s->alnStorage[1]); }
+        s->borrowed = true;
+        s->alnStorage[s->storage] = db->rowArena + at;
+        s->alnStorage[!s->storage] = db->rowArena + total + at;
+        s->memLen = lens[i];
         rows[i] = s->alnStorage[s->storage];
+        at += (size_t)lens[i];
     }
     rc = twl_store_read_rows(g_store, rows.data(), lens.data());
     if (rc != TWL_OK) die("twl_store_read_rows", rc);

@@ -122,8 +122,10 @@ SequenceDB::SequenceInfo::SequenceInfo(int id_, const std::string &name_, std::s
 
 SequenceDB::SequenceInfo::~SequenceInfo()
 {
-    free(alnStorage[0]);
-    free(alnStorage[1]);
+    if (!borrowed) {
+        free(alnStorage[0]);
+        free(alnStorage[1]);
+    }
 }
 
 void SequenceDB::SequenceInfo::memCheck(int need)
@@ -133,9 +135,10 @@ void SequenceDB::SequenceInfo::memCheck(int need)
     for (int b = 0; b < 2; ++b) {
         char *t = static_cast<char *>(calloc(grown, 1));
         if (memLen > 0) memcpy(t, alnStorage[b], (size_t)memLen);
-        free(alnStorage[b]);
+        if (!borrowed) free(alnStorage[b]);
         alnStorage[b] = t;
     }
+    borrowed = false;
     memLen = grown;
 }
 
@@ -149,6 +152,7 @@ void SequenceDB::addSequence(int id, const std::string &name, std::string &seq, 
 SequenceDB::~SequenceDB()
 {
     for (auto *s : sequences) delete s;
+    free(rowArena);
 }
 
 // sequencedb.cpp:87-120 (--check): legality of the MSA, not optimality

@@ -148,6 +148,7 @@ struct SequenceDB {
         int subtreeIdx;
         float weight;
         bool storage = false;
+        bool borrowed = false;      // alnStorage points into SequenceDB::rowArena (device-resident mode hands all rows back in one block)
         int memLen = 0;
         char *alnStorage[2] = {nullptr, nullptr};
         static constexpr int timesBigger = 2;
@@ -161,6 +162,7 @@ struct SequenceDB {
     std::vector<Node *> fallback_nodes;
     std::unordered_map<std::string, SequenceInfo *> name_map;
     std::unordered_map<int, alnPath> subtreeAln;
+    char *rowArena = nullptr;                      // owns the rows of sequences with `borrowed` set
     std::function<void(Tree *)> afterMainPass;    // set by the device-resident level kernel: bring rows/caches back to the host
     void addSequence(int id, const std::string &name, std::string &seq, int subtreeIdx, float weight, bool debug);
     bool debug();      // --check: true when every aligned row reproduces its input sequence and all rows are equally long

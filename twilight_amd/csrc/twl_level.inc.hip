@@ -165,6 +165,14 @@ int twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out)
                        (const char *)s->rows[0].p, (const char *)s->rows[1].p, s->cap, (const uint8_t *)s->d_plane.p, (const int32_t *)s->d_rowlen.p,
                        (const int64_t *)s->d_off.p, (char *)s->d_gather.p);
     HIP_TRY(hipGetLastError());
+    // rows laid out back to back by the caller (row i at the prefix sum of the lengths): one transfer, straight into them
+    bool packed = true;
+    for (int32_t i = 0; i < s->n_seqs && packed; ++i) packed = (s->len[i] == 0) || (rows_out[i] == rows_out[0] + (off[i] - off[0]) && rows_out[0] != nullptr);
+    if (packed && s->len[0] > 0) {
+        if (total) HIP_TRY(hipMemcpyAsync(rows_out[0], s->d_gather.p, (size_t)total, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        return TWL_OK;
+    }
     std::unique_ptr<char[]> host(new char[(size_t)std::max<int64_t>(total, 1)]);      // uninitialised on purpose
     if (total) HIP_TRY(hipMemcpyAsync(host.get(), s->d_gather.p, (size_t)total, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
