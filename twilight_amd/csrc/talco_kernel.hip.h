@@ -46,6 +46,7 @@ struct KArgs {
     int32_t seq_len;
     int32_t tb_words;         // per workgroup
     int32_t *dbg;             // optional [pair][16] debug record (nullptr = off)
+    int32_t n_pairs_total;    // pairs of the batch (the stamp build writes its record after the per-pair debug records)
     int32_t *hb;              // optional host-mapped heartbeat [16] written by workgroup 0 (debug only)
     int32_t step_slack;       // watchdog: a pair may run at most 32*(R+Q) + step_slack diagonals in total
     float gap_open, gap_extend, gap_char;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         heartbeat(a, 9, err);
 #ifdef TWL_KERNEL_STAMPS
         if (a.dbg && lane == 0 && pair == 0) {      // per wave of the workgroup that aligned pair 0: cycle sums per segment
-            long long *g = reinterpret_cast<long long *>(a.dbg) + 8 + 8 * w;
+            long long *g = reinterpret_cast<long long *>(a.dbg + 16 * (size_t)a.n_pairs_total) + 8 * w;
             g[0] = (long long)st_slots; g[1] = (long long)st_bar; g[2] = (long long)st_post; g[3] = (long long)st_n; g[4] = (long long)st_act;
             g[5] = (long long)(__builtin_amdgcn_s_memtime() - st_t0);
             g[6] = (long long)st_exit; g[7] = (long long)st_setup;

@@ -63,7 +63,6 @@ struct Device {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
     int num_cu = 0;
-    int fast_blocks_per_cu = 0, wide_blocks_per_cu = 0;
     Buf cols, tb, cells, queue, items, errs, dbg;
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
     std::vector<int32_t> dbg_host;
@@ -204,13 +203,14 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     a.cells = (unsigned long long *)d->cells.p;
     a.queue = (int32_t *)d->queue.p;
     a.seq_len = seq_len;
+    a.n_pairs_total = n_pairs;
     a.gap_open = p->gap_open; a.gap_extend = p->gap_extend; a.gap_char = p->gap_char;
     a.xdrop = p->xdrop; a.flen = p->flen; a.marker = p->marker;
     a.step_slack = 1 << 16;
     const bool want_dbg = getenv("TWL_DEBUG") != nullptr;
     a.dbg = nullptr;
     if (want_dbg) {
-        if ((rc = d->dbg.ensure(std::max<size_t>((size_t)n_pairs * 16 * sizeof(int32_t), 1024)))) return rc;
+        if ((rc = d->dbg.ensure((size_t)n_pairs * 16 * sizeof(int32_t) + 1024))) return rc;     // per-pair records, then 1 KB for the stamp build
         HIP_TRY(hipMemsetAsync(d->dbg.p, 0xff, (size_t)n_pairs * 16 * sizeof(int32_t), st));
         a.dbg = (int32_t *)d->dbg.p;
     }
@@ -545,8 +545,10 @@ int twl_debug_read(int device, long long *out, int32_t n)
 {
     Device *d = nullptr;
     if (find_dev(device, &d)) return TWL_ERR_BAD_ARGUMENT;
-    if (!d->dbg.p || (size_t)n * 8 > d->dbg.cap) return TWL_ERR_BAD_ARGUMENT;
-    return hipMemcpy(out, d->dbg.p, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWL_OK : TWL_ERR_HIP;
+    // the stamp record (TWL_KERNEL_STAMPS builds) sits after the per-pair records
+    const size_t base = d->pair_cells.size() * 16 * sizeof(int32_t);
+    if (!d->dbg.p || base + (size_t)n * 8 > d->dbg.cap) return TWL_ERR_BAD_ARGUMENT;
+    return hipMemcpy(out, (const char *)d->dbg.p + base, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWL_OK : TWL_ERR_HIP;
 }
 
 int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)
