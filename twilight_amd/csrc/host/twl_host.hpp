@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <stack>
@@ -179,8 +180,15 @@ char detectType(const std::string &seqFile);
 using alnFunction = std::function<void(Tree *, NodePairVec &, SequenceDB *, Option *, Params &)>;
 
 namespace alignment_helper {
-constexpr int _CAL_PROFILE_TH = 1000;
-constexpr int _UPDATE_SEQ_TH = 1000;
+// msa.hpp:179-180.  The two thresholds are 1000 in the reference; the environment variables exist for tests only (they let small
+// trees reach the cached-profile and compressed-group branches) and apply to the product CLI and the CPU checker alike.
+inline int thresholdFromEnv(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && atoi(v) > 0) ? atoi(v) : dflt;
+}
+static const int _CAL_PROFILE_TH = thresholdFromEnv("TWL_TEST_CAL_PROFILE_TH", 1000);
+static const int _UPDATE_SEQ_TH = thresholdFromEnv("TWL_TEST_UPDATE_SEQ_TH", 1000);
 void calculateProfile(float *profile, NodePair &nodes, SequenceDB *database, Option *option, int32_t memLen);
 void removeGappyColumns(float *hostFreq, NodePair &nodes, Option *option, std::pair<IntPairVec, IntPairVec> &gappyColumns, int32_t memLen,
                         IntPair &lens, int currentTask);
