@@ -215,3 +215,33 @@ def test_protein_score_modes_match_oracle(gpu, mode, monkeypatch):
     batch = synth.make_level_batch(5, 900, members=((1, 5), (1, 5)), seed=8, P=22, sub=0.2)
     _compare(gpu, batch, matrix=PM, marker=128)
     _compare(gpu, batch, matrix=PM, gap_char=0.0)
+
+
+@pytest.mark.timeout(900)
+def test_full_size_level_properties(gpu):
+    """BASELINE size (10 kbp profiles, a level-sized batch): properties that do not need the oracle at full size -- every path
+    consumes exactly (R, Q), replicas of a pair get the identical path and band-cell count whichever workgroup runs them, a second
+    run is identical -- plus the oracle on a sample of the full-size pairs."""
+    pool = synth.make_level_batch(24, 10000, members=((1, 8), (1, 8)), seed=20260501)
+    idx = np.arange(600) % pool.n_pairs
+    big = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx],
+                           len=pool.len[idx], num=pool.num[idx])
+    p = gpu.make_params(M)
+    aln, n, err = gpu.align_batch(p, big)
+    cells = gpu.get_pair_cells(big.n_pairs)
+    assert not err.any()
+    for i in range(big.n_pairs):
+        assert synth.path_consumes(aln[i], int(n[i])) == (int(big.len[i, 0]), int(big.len[i, 1])), f"pair {i}"
+        j = int(idx[i])
+        if i != j:
+            assert n[i] == n[j] and np.array_equal(aln[i, : n[i]], aln[j, : n[j]]) and cells[i] == cells[j], f"replica {i} of {j}"
+    aln2, n2, err2 = gpu.align_batch(p, big)
+    assert np.array_equal(n, n2) and np.array_equal(cells, gpu.get_pair_cells(big.n_pairs))
+    assert all(np.array_equal(aln[i, : n[i]], aln2[i, : n[i]]) for i in range(big.n_pairs))
+    sample = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[:4], gap_open=pool.gap_open[:4], gap_extend=pool.gap_extend[:4],
+                              len=pool.len[:4], num=pool.num[:4])
+    oa, on, oerr, ost = O.align_batch(O.make_params(M), sample, threads=8)
+    assert np.array_equal(on, n[:4]) and not oerr.any()
+    for i in range(4):
+        assert np.array_equal(oa[i, : on[i]], aln[i, : n[i]])
+    assert ost.cells == int(cells[:4].sum())
