@@ -122,3 +122,31 @@ def test_product_equals_oracle_with_cli_variants(built, tmp_path, kind, flags):
     assert _md5(outs["staged"][0]) == _md5(outs["oracle"][0]), flags
     if "--length-deviation" in flags and "--filter" not in flags:
         assert "Realign profiles that have been deferred" in outs["gpu"][1], "the variant was meant to exercise the deferred pass"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("replicas,kind,flags,th", [(2, "n", [], 0), (3, "n", ["--length-deviation", "0.004"], 0), (2, "p", ["-r", "0.8"], 0), (3, "n", [], 6)])
+@pytest.mark.timeout(900)
+def test_replicated_resident_path_equals_oracle(built, tmp_path, replicas, kind, flags, th):
+    """Several device replicas (here: virtual ones on the first GPU): every replica prepares and commits the whole level, the DP is
+    sharded over them by mask, paths meet on the host.  The MSA must equal the CPU checker's."""
+    from twilight_amd import synth
+
+    n, length = (56, 800) if kind == "n" else (30, 400)
+    nwk, seqs = synth.make_family(n, length, P=(6 if kind == "n" else 22), seed=91, sub=0.04, indel=0.004)
+    (tmp_path / "t.nwk").write_text(nwk + "\n")
+    (tmp_path / "s.fa").write_text("".join(f">{name}\n{seq}\n" for name, seq in seqs))
+    env = dict(os.environ)
+    if th:
+        env["TWL_TEST_CAL_PROFILE_TH"] = str(th)
+        env["TWL_TEST_UPDATE_SEQ_TH"] = str(th)
+    outs = {}
+    for tag, exe, e in (("oracle", os.path.join(ROOT, "oracle", "e2e_oracle"), env),
+                        ("gpu", os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), dict(env, TWL_TEST_VIRTUAL_DEVICES=str(replicas)))):
+        out = tmp_path / f"{tag}.aln"
+        r = subprocess.run([exe, "-t", str(tmp_path / "t.nwk"), "-i", str(tmp_path / "s.fa"), "-o", str(out), "--type", kind, "--check", "-v"] + flags,
+                           capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = (out, r.stderr)
+    assert f"resident on {replicas} device replica(s)" in outs["gpu"][1]
+    assert _md5(outs["gpu"][0]) == _md5(outs["oracle"][0])

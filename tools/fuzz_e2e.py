@@ -42,6 +42,7 @@ def one(seed):
     if th:
         env["TWL_TEST_CAL_PROFILE_TH"] = str(th)
         env["TWL_TEST_UPDATE_SEQ_TH"] = str(int(rng.choice([th, 2 * th])))
+    replicas = int(rng.choice([1, 1, 2, 3]))
     d = tempfile.mkdtemp(prefix="twl_fz_")
     sys.setrecursionlimit(100000)
     nwk, seqs = synth.make_family(n, length, P=(6 if kind == "n" else 22), seed=seed, sub=sub, indel=indel)
@@ -51,14 +52,14 @@ def one(seed):
     for tag, exe, extra in (("cpu", CPU, []), ("resident", CLI, []), ("staged", CLI, ["--host-staged"])):
         out = os.path.join(d, tag + ".aln")
         r = subprocess.run([exe, "-t", os.path.join(d, "t.nwk"), "-i", os.path.join(d, "s.fa"), "-o", out, "--type", kind, "--check"] + flags + extra,
-                           capture_output=True, text=True, env=env)
+                           capture_output=True, text=True, env=(dict(env, TWL_TEST_VIRTUAL_DEVICES=str(replicas)) if tag == "resident" else env))
         if r.returncode != 0:
             res[tag] = f"rc {r.returncode}: " + (r.stdout + r.stderr)[-300:].replace("\n", " | ")
         else:
             res[tag] = md5(out)
     ok = res["cpu"] == res["resident"] == res["staged"] and not res["cpu"].startswith("rc")
     same_fail = all(v.startswith("rc") for v in res.values())
-    desc = f"seed {seed} {kind} n={n} len={length} sub={sub} indel={indel} th={th} flags={' '.join(flags)}"
+    desc = f"seed {seed} {kind} n={n} len={length} sub={sub} indel={indel} th={th} replicas={replicas} flags={' '.join(flags)}"
     return ok, same_fail, desc, res
 
 

@@ -9,6 +9,12 @@
 //    reference per-level row rewriting, which here is a sub-millisecond kernel; every row is simply kept up to date.
 //  * the pass covers currentTask == 0; before the deferred pass (currentTask 1) rows and cached profiles are brought back to the
 //    host and alignmentKernel_GPU takes over.
+//
+// Several devices (phase 2) without any collective: every device holds a replica of the store.  Profile building and the
+// write-back are ~1 % of a level's device time, so EVERY device runs them for ALL pairs of the level (the replicas stay identical by
+// construction, cached profiles included); only the DP -- the 99 % -- is sharded: each device aligns its share of the pairs
+// (twl_level_align with a mask, longest-processing-time deal), the paths meet on the host, and every device commits all of them.
+// Per level only paths cross PCIe, nothing crosses xGMI.  TWL_TEST_VIRTUAL_DEVICES=k (tests) runs k replicas on the first device.
 #include "align_gpu.hpp"
 
 #include "../../../include/twl_level.h"
@@ -19,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <string>
+#include <thread>
 
 namespace msa {
 namespace progressive {
@@ -26,7 +34,9 @@ namespace gpu {
 
 namespace {
 
-twl_store *g_store = nullptr;
+std::vector<twl_store *> g_stores;      // one replica per device (or per virtual device in tests)
+std::vector<int> g_storeDev;
+#define g_store (g_stores.empty() ? nullptr : g_stores[0])
 bool g_finished = false;        // the main pass is over: rows are back on the host
 int g_nextCacheId = 0;
 
@@ -47,8 +57,36 @@ void createStore(SequenceDB *db, Option *option)
         rows[i] = s->alnStorage[s->storage];
         lens[i] = s->len;
     }
-    const int rc = twl_store_create(selectedDevices()[0], option->type, n, rows.data(), lens.data(), &g_store);
-    if (rc != TWL_OK) die("twl_store_create", rc);
+    g_storeDev = selectedDevices();
+    if (const char *v = getenv("TWL_TEST_VIRTUAL_DEVICES")) g_storeDev.assign(std::max(1, atoi(v)), selectedDevices()[0]);
+    g_stores.assign(g_storeDev.size(), nullptr);
+    std::vector<std::thread> th;
+    std::vector<std::pair<int, std::string>> res(g_storeDev.size(), {TWL_OK, ""});
+    for (size_t d = 0; d < g_storeDev.size(); ++d)
+        th.emplace_back([&, d] {
+            const int rc = twl_store_create(g_storeDev[d], option->type, n, rows.data(), lens.data(), &g_stores[d]);
+            if (rc != TWL_OK) res[d] = {rc, twl_last_error()};
+        });
+    for (auto &t : th) t.join();
+    for (auto &r : res)
+        if (r.first != TWL_OK) { std::cerr << "ERROR: twl_store_create failed (" << r.first << "): " << r.second << '\n'; exit(1); }
+}
+
+// Runs fn(replica index) for every replica on its own host thread; stops the run on the first library error.
+template <class F>
+void onAllStores(const char *what, F fn)
+{
+    const size_t nd = g_stores.size();
+    std::vector<std::pair<int, std::string>> res(nd, {TWL_OK, ""});
+    if (nd == 1) { const int rc = fn(0); if (rc != TWL_OK) res[0] = {rc, twl_last_error()}; }
+    else {
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < nd; ++d)
+            th.emplace_back([&, d] { const int rc = fn((int)d); if (rc != TWL_OK) res[d] = {rc, twl_last_error()}; });
+        for (auto &t : th) t.join();
+    }
+    for (auto &r : res)
+        if (r.first != TWL_OK) { std::cerr << "ERROR: " << what << " failed (" << r.first << "): " << r.second << '\n'; exit(1); }
 }
 
 // End of the main pass: current rows back into SequenceInfo::alnStorage, cached profiles of the nodes that go on (the root and the
@@ -96,8 +134,8 @@ void materialise(Tree *T, SequenceDB *db, Option *option)
         for (int t = 0; t < len; ++t) std::copy(&flat[(size_t)t * P], &flat[(size_t)t * P] + P, nd->msaFreq[t].begin());
         nd->cacheId = -1;
     }
-    twl_store_destroy(g_store);
-    g_store = nullptr;
+    for (twl_store *st : g_stores) twl_store_destroy(st);
+    g_stores.clear();
     g_finished = true;
     if (option->printDetail) std::cerr << "Rows back on the host in " << nowMs() - t0 << " ms\n";
 }
@@ -127,18 +165,17 @@ void runsAndConsensus(const uint8_t *info, int len, bool removal, const char *le
 
 void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database, Option *option, Params &param)
 {
-    if (database->currentTask != 0 || g_finished || selectedDevices().size() > 1) {      // deferred pass / several devices: host-staged kernel
+    if (database->currentTask != 0 || g_finished) {      // deferred pass: host-staged kernel
         if (g_store) materialise(T, database, option);
         alignmentKernel_GPU(T, nodes, database, option, param);
         return;
     }
     if (option->cpuOnly) { std::cerr << "ERROR: --cpu-only is not available: this build has no CPU alignment path.\n"; exit(1); }
     ensureInit(option);
-    if (selectedDevices().size() > 1) { alignmentKernel_GPU(T, nodes, database, option, param); return; }
     if (!g_store) {
         const double t0 = nowMs();
         createStore(database, option);
-        if (option->printDetail) std::cerr << "Sequences resident on the device in " << nowMs() - t0 << " ms\n";
+        if (option->printDetail) std::cerr << "Sequences resident on " << g_stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
         database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
     }
     const LevelTotals before = g_totals;
@@ -197,8 +234,15 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     twl_params tp = baseParams(param);
     std::vector<int32_t> lens(2 * (size_t)n);
     std::vector<uint8_t> colinfo((size_t)2 * n * stride);
-    int rc = twl_level_prepare(g_store, &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride, lens.data(), colinfo.data());
-    if (rc != TWL_OK) die("twl_level_prepare", rc);
+    const int nd = (int)g_stores.size();
+    std::vector<std::vector<int32_t>> lensOf(nd);
+    onAllStores("twl_level_prepare", [&](int d) {
+        lensOf[d].resize(2 * (size_t)n);       // every replica prepares the whole level; column info is fetched from the first only
+        return twl_level_prepare(g_stores[d], &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride,
+                                 d == 0 ? lens.data() : lensOf[d].data(), d == 0 ? colinfo.data() : nullptr);
+    });
+    for (int d = 1; d < nd; ++d)
+        if (lensOf[d] != lens) { std::cerr << "ERROR: device replicas disagree on the prepared level.\n"; exit(1); }
     const bool removal = !(option->gappyVertical == 1.0);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int i = 0; i < n; ++i) {
@@ -221,27 +265,54 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         const bool zg = (ps[i].refNum > 10000 || ps[i].qryNum > 10000);
         if (zg) { maskZero[i] = 1; ++nZero; } else { maskPlain[i] = 1; ++nPlain; }
     }
-    std::vector<int8_t> aln((size_t)n * 2 * stride);
-    std::vector<int32_t> alnLen(n);
-    std::vector<int16_t> err(n);
-    auto runMasked = [&](const twl_params &prm, const std::vector<uint8_t> &mask) {
-        const double tCall = nowMs();
-        const int r = twl_level_align(g_store, &prm, mask.data(), aln.data(), alnLen.data(), err.data());
-        if (r != TWL_OK) die("twl_level_align", r);
-        g_totals.call_ms += nowMs() - tCall;
-        twl_stats st{};
-        if (twl_get_stats(selectedDevices()[0], &st) == TWL_OK) { g_totals.band_cells += st.band_cells; g_totals.kernel_ms += st.kernel_ms; g_totals.total_ms += st.total_ms; }
-        for (int i = 0; i < n; ++i) {
-            if (!mask[i]) continue;
-            ++g_totals.pairs;
-            errs[i] = err[i];
-            paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + (err[i] == 0 ? alnLen[i] : 0));
+    // deal the pairs to the replicas, longest first (cost ~ R + Q after gappy-column removal); each replica aligns its share
+    std::vector<int> owner(n, 0);
+    if (nd > 1) {
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ps[x].lens.first + ps[x].lens.second > ps[y].lens.first + ps[y].lens.second; });
+        std::vector<long long> load(nd, 0);
+        for (int i : order) {
+            const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            owner[i] = d;
+            load[d] += ps[i].lens.first + ps[i].lens.second;
         }
-    };
+    }
     twl_params tz = tp;
     tz.gap_char = 0;
-    if (nPlain) runMasked(tp, maskPlain);
-    if (nZero) runMasked(tz, maskZero);
+    std::vector<double> callMs(nd, 0), kernMs(nd, 0), totMs(nd, 0);
+    std::vector<uint64_t> cellsOf(nd, 0);
+    onAllStores("twl_level_align", [&](int d) {
+        std::vector<int8_t> aln((size_t)n * 2 * stride);
+        std::vector<int32_t> alnLen(n);
+        std::vector<int16_t> err(n);
+        for (int grp = 0; grp < 2; ++grp) {
+            const std::vector<uint8_t> &all = grp ? maskZero : maskPlain;
+            std::vector<uint8_t> mask(n, 0);
+            int cnt = 0;
+            for (int i = 0; i < n; ++i) if (all[i] && owner[i] == d) { mask[i] = 1; ++cnt; }
+            if (!cnt) continue;
+            const double tCall = nowMs();
+            const int r = twl_level_align(g_stores[d], grp ? &tz : &tp, mask.data(), aln.data(), alnLen.data(), err.data());
+            if (r != TWL_OK) return r;
+            callMs[d] += nowMs() - tCall;
+            twl_stats st{};
+            if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
+                if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; }
+            }
+            for (int i = 0; i < n; ++i) {
+                if (!mask[i]) continue;
+                errs[i] = err[i];
+                paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + (err[i] == 0 ? alnLen[i] : 0));
+            }
+        }
+        return (int)TWL_OK;
+    });
+    g_totals.pairs += (uint64_t)(nPlain + nZero);
+    g_totals.call_ms += *std::max_element(callMs.begin(), callMs.end());           // the replicas run concurrently
+    g_totals.kernel_ms += *std::max_element(kernMs.begin(), kernMs.end());
+    g_totals.total_ms += *std::max_element(totMs.begin(), totMs.end());
+    for (uint64_t c : cellsOf) g_totals.band_cells += c;
     std::vector<int> fallbackPairs;
     for (int i = 0; i < n; ++i) {
         if (errs[i] == 0) continue;
@@ -275,8 +346,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
         finalLen[i] = (int32_t)full.size();
     }
-    rc = twl_level_commit(g_store, finalPaths.data(), finalLen.data(), pathStride);
-    if (rc != TWL_OK) die("twl_level_commit", rc);
+    onAllStores("twl_level_commit", [&](int d) { return twl_level_commit(g_stores[d], finalPaths.data(), finalLen.data(), pathStride); });
     for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
         if (finalLen[i] == 0) continue;
         Node *a = nodes[i].first, *b = nodes[i].second;
