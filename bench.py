@@ -195,7 +195,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic_per_launch(cells // max(1, launches)),
-                "traffic_source": "profiles/r01/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per band cell x cells per launch)",
+                "traffic_source": "profiles/r01/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --no-cpu --pairs 1024`: bytes per band cell, times the cells of this launch)",
                 "kernel": "twl::talco_kernel<6, 8, 2, false, true, true, 4, 2>", "kernel_ms_per_launch": kernel_ms / max(1, launches),
                 "algorithmic_bytes_per_cell": B_CELL_NUC, "cells_per_launch": cells // max(1, launches),
                 "note": "achieved = band cells x 64 B / DP-kernel time (HIP events on the library stream); the path is "
