@@ -104,6 +104,11 @@ int twl_get_stats(int device, twl_stats *out);
 /* Per-pair band-cell counts of the last call on `device` (n entries, host buffer). */
 int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n);
 
+/* Diagnostics: the column scores similarScore(i, j) (TALCO-XDrop.cpp:444: profile x matrix sum of pairs divided by refNum*qryNum) of ONE
+   pair for every query row i and reference column j, row-major out[len[1]][len[0]], as the kernels compute them.
+   freq is [2][seq_len][P] (0 = reference, 1 = query), len = {R, Q}, num = {refNum, qryNum}. */
+int twl_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const int32_t *len, const int32_t *num, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,3 +245,25 @@ def test_full_size_level_properties(gpu):
     for i in range(4):
         assert np.array_equal(oa[i, : on[i]], aln[i, : n[i]])
     assert ost.cells == int(cells[:4].sum())
+
+
+@pytest.mark.parametrize("kind", ["nuc", "nuc_wildcard", "prot"])
+def test_column_scores_match_oracle(gpu, kind):
+    """SP column scores (similarScore, TALCO-XDrop.cpp:444): the kernels' values against the oracle's twlo_column_score for every cell
+    of small profile pairs -- equal as floats (the kernels may return -0 where the oracle returns +0; nothing downstream can see that)."""
+    P = 22 if kind == "prot" else 6
+    mat = (synth.protein_matrix() if kind == "prot" else synth.nucleotide_matrix()).copy()
+    if kind == "nuc_wildcard":          # -w: N scores like a match (scoring-matrix.cpp:104-110) -> the general 5x5 arithmetic matters
+        mat[4, :] = 18.0
+        mat[:, 4] = 18.0
+    b = synth.make_level_batch(2, 80, members=((2, 7), (1, 5)), seed=31, P=P, sub=0.2, gap_col_rate=0.1)
+    for gap_char in (None, 0.0):
+        pk = {} if gap_char is None else {"gap_char": gap_char}
+        p, op = gpu.make_params(mat, **pk), O.make_params(mat, **pk)
+        for i in range(b.n_pairs):
+            R, Q = int(b.len[i, 0]), int(b.len[i, 1])
+            ref, qry = b.freq[i, 0, :R], b.freq[i, 1, :Q]
+            got = gpu.column_scores(p, ref, qry, int(b.num[i, 0]), int(b.num[i, 1]))
+            denom = float(np.float32(b.num[i, 0]) * np.float32(b.num[i, 1]))
+            want = np.array([[O.column_score(op, ref[j], qry[ii], denom) for j in range(R)] for ii in range(Q)], dtype=np.float32)
+            assert got.shape == want.shape and np.array_equal(got, want), f"{kind} pair {i}: {int((got != want).sum())} of {got.size} cells differ"

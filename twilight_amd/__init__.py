@@ -12,6 +12,7 @@ from .api import (  # noqa: F401
     TwlStats,
     align_batch,
     align_batch_device,
+    column_scores,
     exported_symbols,
     get_pair_cells,
     get_stats,

@@ -31,7 +31,7 @@ class TwlStats(C.Structure):
 
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
-            "twl_get_stats", "twl_get_pair_cells"]
+            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores"]
 
 
 def exported_symbols():
@@ -58,6 +58,7 @@ def load_library():
         lib.twl_align_batch_device.restype = C.c_int
         lib.twl_get_stats.restype = C.c_int
         lib.twl_get_pair_cells.restype = C.c_int
+        lib.twl_column_scores.restype = C.c_int
         lib.twl_shutdown.restype = None
         _lib = lib
     return _lib
@@ -142,4 +143,20 @@ def get_stats(device=0) -> TwlStats:
 def get_pair_cells(n, device=0):
     out = np.zeros(n, dtype=np.uint64)
     _check(load_library().twl_get_pair_cells(C.c_int(device), _ptr(out, C.c_uint64), C.c_int32(n)))
+    return out
+
+
+def column_scores(params: TwlParams, ref: np.ndarray, qry: np.ndarray, ref_num: int, qry_num: int) -> np.ndarray:
+    """twl_column_scores: similarScore(i, j) for every query row i and reference column j of one pair, shape [Q][R]."""
+    ref = np.ascontiguousarray(ref, dtype=np.float32)
+    qry = np.ascontiguousarray(qry, dtype=np.float32)
+    R, Q, P = ref.shape[0], qry.shape[0], ref.shape[1]
+    sl = max(R, Q)
+    freq = np.zeros((2, sl, P), dtype=np.float32)
+    freq[0, :R] = ref
+    freq[1, :Q] = qry
+    ln = np.array([R, Q], dtype=np.int32)
+    nm = np.array([ref_num, qry_num], dtype=np.int32)
+    out = np.zeros((Q, R), dtype=np.float32)
+    _check(load_library().twl_column_scores(C.byref(params), C.c_int32(sl), _ptr(freq, C.c_float), _ptr(ln, C.c_int32), _ptr(nm, C.c_int32), _ptr(out, C.c_float)))
     return out

@@ -787,17 +787,18 @@ struct ScoreArgs {
     const int32_t *blk_off;        // [n_items + 1] first workgroup of each item
     int32_t n_items, seq_len;
     float gap_char;
-    const float *M24;              // [21][24] matrix rows padded to 24 floats (global memory)
+    const float *M24;              // P = 22: [21][24] matrix rows padded to 24 floats; P = 6: the 5x5 matrix row-major, padded to 28 floats
     float *sim;
     const long long *sim_off;
 };
 
+template <int P>
 __global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
 {
-    constexpr int P = 22, CW = 24, F4 = 6;
+    constexpr int CW = P + 2, F4 = CW / 4, MS = P - 1;
     __shared__ float4 s_r[F4 * 128];           // plane-major: reference columns Jmin .. Jmin+126
     __shared__ uint32_t s_mask[128];
-    __shared__ float4 s_M4[21 * 6];
+    __shared__ float4 s_M4[P == 22 ? 21 * 6 : 8];      // P = 22: rows padded to 24 floats; P = 6: the 25 values, row-major
     int it = 0;
     while (it + 1 < a.n_items && (int)blockIdx.x >= a.blk_off[it + 1]) ++it;
     const int pair = a.items[it];
@@ -809,7 +810,7 @@ __global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
     const int Jmin = K0 - I0 - 63;
     const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * CW);
     const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * CW);
-    for (int t = threadIdx.x; t < 21 * 6; t += 256) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
+    for (int t = threadIdx.x; t < (P == 22 ? 21 * 6 : 7); t += 256) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
     if (threadIdx.x < 127) {
         const int J = Jmin + (int)threadIdx.x;
         uint32_t mk = 0;
@@ -818,10 +819,10 @@ __global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
             float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
             if (J >= 0 && J < R) c = colsR[F4 * (size_t)J + t];
             s_r[t * 128 + threadIdx.x] = c;
-            if (4 * t + 0 < 21) mk |= (c.x != 0.0f) ? (1u << (4 * t + 0)) : 0u;
-            if (4 * t + 1 < 21) mk |= (c.y != 0.0f) ? (1u << (4 * t + 1)) : 0u;
-            if (4 * t + 2 < 21) mk |= (c.z != 0.0f) ? (1u << (4 * t + 2)) : 0u;
-            if (4 * t + 3 < 21) mk |= (c.w != 0.0f) ? (1u << (4 * t + 3)) : 0u;
+            if (4 * t + 0 < MS) mk |= (c.x != 0.0f) ? (1u << (4 * t + 0)) : 0u;
+            if (4 * t + 1 < MS) mk |= (c.y != 0.0f) ? (1u << (4 * t + 1)) : 0u;
+            if (4 * t + 2 < MS) mk |= (c.z != 0.0f) ? (1u << (4 * t + 2)) : 0u;
+            if (4 * t + 3 < MS) mk |= (c.w != 0.0f) ? (1u << (4 * t + 3)) : 0u;
         }
         s_mask[threadIdx.x] = mk;
     }
@@ -840,46 +841,64 @@ __global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
     const int pitch = (Q + 63) & ~63;
     float *out = a.sim + a.sim_off[pair];
     const float *rf = reinterpret_cast<const float *>(s_r);
+    const float *Mf = reinterpret_cast<const float *>(s_M4);
     for (int kk = wave; kk < 64; kk += 4) {
         const int K = K0 + kk;
         const int J = K - I;
         const bool ok = (I < Q) && (J >= 0) && (J < R);
-        const int jr = J - Jmin;                       // 0..126 when ok
+        const int jr = ok ? J - Jmin : 0;              // 0..126 when ok
         float numer = 0.0f;
-        uint32_t mk = ok ? s_mask[jr] : 0u;
-        const uint32_t mk0 = mk;
-        while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
-            if (mk != 0u) {
-                const int l = __builtin_ctz(mk);
-                mk &= mk - 1u;
-                const float rl = rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)];
-                float Mr[24];
+        if constexpr (P == 22) {
+            uint32_t mk = ok ? s_mask[jr] : 0u;
+            const uint32_t mk0 = mk;
+            while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+                if (mk != 0u) {
+                    const int l = __builtin_ctz(mk);
+                    mk &= mk - 1u;
+                    const float rl = rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)];
+                    float Mr[24];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const float4 c = s_M4[l * 6 + t];
-                    Mr[4 * t] = c.x; Mr[4 * t + 1] = c.y; Mr[4 * t + 2] = c.z; Mr[4 * t + 3] = c.w;
+                    for (int t = 0; t < 6; ++t) {
+                        const float4 c = s_M4[l * 6 + t];
+                        Mr[4 * t] = c.x; Mr[4 * t + 1] = c.y; Mr[4 * t + 2] = c.z; Mr[4 * t + 3] = c.w;
+                    }
+#pragma unroll
+                    for (int m = 16; m < 21; ++m) numer += (rl * q[m]) * Mr[m];
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = (q[t] * Mr[t]) * rl + (q[8 + t] * Mr[8 + t]) * rl;
+                    numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
                 }
-#pragma unroll
-                for (int m = 16; m < 21; ++m) numer += (rl * q[m]) * Mr[m];
-                float v[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) v[t] = (q[t] * Mr[t]) * rl + (q[8 + t] * Mr[8 + t]) * rl;
-                numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
             }
-        }
-        // gap-letter terms: (r[l]*q[gap])*gc over l (:432) and (r[gap]*q[m])*gc over m (:433); terms with a zero factor are +-0
-        mk = mk0;
-        while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
-            if (mk != 0u) {
-                const int l = __builtin_ctz(mk);
-                mk &= mk - 1u;
-                numer += (rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)] * q[P - 1]) * gc;
+            // gap-letter terms: (r[l]*q[gap])*gc over l (:432) and (r[gap]*q[m])*gc over m (:433); terms with a zero factor are +-0
+            mk = mk0;
+            while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+                if (mk != 0u) {
+                    const int l = __builtin_ctz(mk);
+                    mk &= mk - 1u;
+                    numer += (rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)] * q[P - 1]) * gc;
+                }
             }
+        } else {
+            // nucleotide column score, TALCO-XDrop.cpp:378-395: per l the five products summed left to right, accumulated over l
+            float rc[5];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) rc[l] = rf[(size_t)((l >> 2) * 128 + jr) * 4 + (l & 3)];
+#pragma unroll
+            for (int l = 0; l < 5; ++l) {
+                float t[5];
+#pragma unroll
+                for (int m = 0; m < 5; ++m) t[m] = (q[m] * Mf[5 * l + m]) * rc[l];
+                const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+                numer = (l == 0) ? sl : numer + sl;
+            }
+#pragma unroll
+            for (int l = 0; l < 5; ++l) numer += (rc[l] * q[P - 1]) * gc;                       // :394
         }
         if (ok) {
-            const float rg = rf[(size_t)(5 * 128 + jr) * 4 + 1];
+            const float rg = rf[(size_t)(((P - 1) >> 2) * 128 + jr) * 4 + ((P - 1) & 3)];
 #pragma unroll
-            for (int m = 0; m < 21; ++m) numer += (rg * q[m]) * gc;
+            for (int m = 0; m < MS; ++m) numer += (rg * q[m]) * gc;                             // :395 / :433
             out[(size_t)K * (size_t)pitch + (size_t)I] = denomOne ? numer : numer / denom;
         }
     }

@@ -265,7 +265,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
                 sa.n_items = n_pairs; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p;
                 sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
-                hipLaunchKernelGGL(twl::score_matrix_kernel, dim3((unsigned)blk[n_pairs]), dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_pairs]), dim3(256), 0, st, sa);
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
@@ -537,6 +537,63 @@ int twl_get_stats(int device, twl_stats *out)
     int rc = find_dev(device, &d);
     if (rc) return rc;
     *out = d->stats;
+    return TWL_OK;
+}
+
+// Diagnostics: similarScore(i, j) (TALCO-XDrop.cpp:444) of one pair for every (query row i, reference column j), row-major
+// out[Q][R], computed by score_matrix_kernel -- the arithmetic the DP kernels use (for nucleotides the general 5x5 order).
+int twl_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const int32_t *len, const int32_t *num, float *out)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (seq_len < 1 || !freq || !len || !num || !out || len[0] < 1 || len[1] < 1 || len[0] > seq_len || len[1] > seq_len) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = g_devs[0];
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    const size_t P = (size_t)p->P, sl = (size_t)seq_len, CW = P + 2;
+    const int R = len[0], Q = len[1];
+    const size_t pitch = ((size_t)Q + 63) & ~(size_t)63, simFloats = (size_t)(R + Q) * pitch;
+    if ((rc = d->h2d_freq.ensure(2 * sl * P * sizeof(float)))) return rc;
+    if ((rc = d->h2d_gop.ensure(2 * sl * sizeof(float)))) return rc;
+    if ((rc = d->cols.ensure(2 * sl * CW * sizeof(float)))) return rc;
+    if ((rc = d->h2d_len.ensure(2 * sizeof(int32_t)))) return rc;
+    if ((rc = d->h2d_num.ensure(2 * sizeof(int32_t)))) return rc;
+    if ((rc = d->items.ensure(sizeof(int32_t)))) return rc;
+    if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
+    if ((rc = d->sim_off.ensure(sizeof(long long)))) return rc;
+    if ((rc = d->blk_off.ensure(2 * sizeof(int32_t)))) return rc;
+    if ((rc = d->m24.ensure(21 * 24 * sizeof(float)))) return rc;
+    std::vector<float> m24(21 * 24, 0.0f);
+    const int ms = p->P - 1;
+    for (int l = 0; l < ms; ++l) for (int m = 0; m < ms; ++m) m24[(ms == 21 ? 24 : 5) * l + m] = p->matrix[ms * l + m];
+    const int32_t item = 0, blk[2] = {0, (int32_t)(((R + Q - 1 + 63) / 64) * ((Q + 63) / 64))};
+    const long long off = 0;
+    HIP_TRY(hipMemcpyAsync(d->h2d_freq.p, freq, 2 * sl * P * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d->h2d_gop.p, 0, 2 * sl * sizeof(float), st));
+    HIP_TRY(hipMemcpyAsync(d->h2d_len.p, len, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->h2d_num.p, num, 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->items.p, &item, sizeof item, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->sim_off.p, &off, sizeof off, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->blk_off.p, blk, sizeof blk, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    const size_t n_cols = 2 * sl;
+    const int blocks = (int)((n_cols + 255) / 256);
+    if (p->P == 22) hipLaunchKernelGGL(twl::pack_kernel<22>, dim3(blocks), dim3(256), 0, st, (const float *)d->h2d_freq.p, (const float *)d->h2d_gop.p, (const float *)d->h2d_gop.p, (float *)d->cols.p, n_cols);
+    else hipLaunchKernelGGL(twl::pack_kernel<6>, dim3(blocks), dim3(256), 0, st, (const float *)d->h2d_freq.p, (const float *)d->h2d_gop.p, (const float *)d->h2d_gop.p, (float *)d->cols.p, n_cols);
+    twl::ScoreArgs sa{};
+    sa.cols = (const float *)d->cols.p; sa.len = (const int32_t *)d->h2d_len.p; sa.num = (const int32_t *)d->h2d_num.p;
+    sa.items = (const int32_t *)d->items.p; sa.blk_off = (const int32_t *)d->blk_off.p; sa.n_items = 1; sa.seq_len = seq_len;
+    sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p; sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
+    if (p->P == 22) hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[1]), dim3(256), 0, st, sa);
+    else hipLaunchKernelGGL(twl::score_matrix_kernel<6>, dim3((unsigned)blk[1]), dim3(256), 0, st, sa);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> diag(simFloats);
+    HIP_TRY(hipMemcpyAsync(diag.data(), d->sim.p, simFloats * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < Q; ++i)
+        for (int j = 0; j < R; ++j) out[(size_t)i * R + j] = diag[(size_t)(i + j) * pitch + i];
     return TWL_OK;
 }
 
