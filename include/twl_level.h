@@ -17,7 +17,8 @@
  * What stays with the caller (small, serial, policy): the retry/defer policy, addGappyColumnsBack + pairwiseGlobal
  * on the returned paths (:243-375), and the Node bookkeeping (alnNum/alnLen/alnWeight/seqsIncluded).
  *
- * A store lives on ONE device.  Same conventions as twl_align.h: plain C types, 0 or a negative twl_status,
+ * A store lives on ONE device (several devices: one replica per device) and must be destroyed before
+ * twl_shutdown().  Same conventions as twl_align.h: plain C types, 0 or a negative twl_status,
  * twl_last_error() for the text; algorithmic failures of a pair travel in err_out[].
  */
 #ifndef TWL_LEVEL_H
