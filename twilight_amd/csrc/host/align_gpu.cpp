@@ -113,7 +113,7 @@ static void runBatch(const twl_params &tp, const std::vector<int> &ids, const st
     g_totals.call_ms += nowMs() - tCall;
     for (int dev : g_devices) {
         twl_stats st{};
-        if (twl_get_stats(dev, &st) == TWL_OK) { g_totals.band_cells += st.band_cells; g_totals.kernel_ms += st.kernel_ms; g_totals.total_ms += st.total_ms; }
+        if (twl_get_stats(dev, &st) == TWL_OK) { g_totals.band_cells += st.band_cells; g_totals.relaunched += (uint64_t)st.n_relaunched; g_totals.kernel_ms += st.kernel_ms; g_totals.total_ms += st.total_ms; }
     }
     g_totals.pairs += ids.size();
     for (int id : ids) {

@@ -281,7 +281,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     twl_params tz = tp;
     tz.gap_char = 0;
     std::vector<double> callMs(nd, 0), kernMs(nd, 0), totMs(nd, 0);
-    std::vector<uint64_t> cellsOf(nd, 0);
+    std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
     onAllStores("twl_level_align", [&](int d) {
         std::vector<int8_t> aln((size_t)n * 2 * stride);
         std::vector<int32_t> alnLen(n);
@@ -298,7 +298,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             callMs[d] += nowMs() - tCall;
             twl_stats st{};
             if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
-                if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; }
+                if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; }
             }
             for (int i = 0; i < n; ++i) {
                 if (!mask[i]) continue;
@@ -313,6 +313,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     g_totals.kernel_ms += *std::max_element(kernMs.begin(), kernMs.end());
     g_totals.total_ms += *std::max_element(totMs.begin(), totMs.end());
     for (uint64_t c : cellsOf) g_totals.band_cells += c;
+    for (uint64_t c : redoOf) g_totals.relaunched += c;
     std::vector<int> fallbackPairs;
     for (int i = 0; i < n; ++i) {
         if (errs[i] == 0) continue;
@@ -368,7 +369,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (option->printDetail)
         std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << g_totals.call_ms - before.call_ms
                   << " (kernel " << g_totals.kernel_ms - before.kernel_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
-                  << ") whole " << nowMs() - tPrep << '\n';
+                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << '\n';
 }
 
 }  // namespace gpu

@@ -22,7 +22,7 @@ int main(int argc, char **argv)
     const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     const auto &g = msa::progressive::gpu::g_totals;
     std::cerr << "Wrote " << option.outFile << " (length " << alnLen << ") in " << secs << " s; level kernel: " << g.pairs << " pairs, " << g.band_cells
-              << " band cells, " << g.kernel_ms << " ms DP kernel, " << g.total_ms << " ms incl. transfers\n";
+              << " band cells, " << g.relaunched << " pairs re-run in a wider window, " << g.kernel_ms << " ms DP kernel, " << g.total_ms << " ms incl. transfers\n";
     if (option.printDetail)
         std::cerr << "Host phases (ms): prepare " << g.prepare_ms << ", stage " << g.stage_ms << ", boundary call " << g.call_ms << ", finish " << g.finish_ms
                   << "; device prepare kernels " << g.dev_prepare_ms << ", device write-back kernels " << g.dev_commit_ms << '\n';

@@ -245,7 +245,7 @@ void beginInit(Option *option);   // optional: start device initialisation early
 // building, gappy-column removal, gap penalties and the row write-back run as kernels.  Falls through to alignmentKernel_GPU
 // for the deferred pass (currentTask != 0), after bringing the rows back.
 void alignmentKernel_Resident(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
-struct LevelTotals { uint64_t band_cells = 0, pairs = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0; };
+struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0; };
 extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
 }
 
