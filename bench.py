@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=64, help="distinct synthetic pairs generated per rank (replicated to --pairs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline leg (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-final-MSA leg (N=1 only: product CLI on a generated 10k x 10 kbp family)")
     return ap.parse_args()
 
 
@@ -95,6 +96,40 @@ def cpu_baseline(batch, idx, gpu_paths, gpu_lens, target_seconds=15.0):
             "gpu_paths_equal_on_sample": parity}
 
 
+def wallclock_to_msa(leaves=10000, length=10000):
+    """Second half of BASELINE.json's metric: wall-clock from FASTA + guide tree to the final MSA for the RNASim-shaped 10k x 10 kbp family
+    (BASELINE config 3), product CLI `twilight-mi355x` on this GPU, measured around the whole process.  Never takes the bench line down."""
+    import subprocess
+    import tempfile
+
+    try:
+        exe = os.path.join(ROOT, "twilight_amd", "twilight-mi355x")
+        if not os.path.exists(exe):
+            return {"value": None, "unit": "s", "note": "twilight-mi355x not built (run __graft_entry__.build())"}
+        with tempfile.TemporaryDirectory(prefix="twl_bench_e2e_") as d:
+            outj = os.path.join(d, "e2e.json")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--leaves", str(leaves), "--length", str(length), "--out", outj],
+                               capture_output=True, text=True, timeout=600)
+            if r.returncode != 0 or not os.path.exists(outj):
+                return {"value": None, "unit": "s", "note": "e2e run failed: " + (r.stdout + r.stderr)[-300:]}
+            e = json.load(open(outj))
+        rec = {}
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01", "e2e_wallclock_10000x10k.json")))
+        except OSError:
+            pass
+        same_family = bool(rec) and rec.get("leaves") == leaves and rec.get("length") == length
+        return {"value": e["gpu"]["wall_s"], "unit": "s", "higher_is_better": False,
+                "config": f"synthetic RNASim-shaped family, {leaves} sequences x {length} bp, full progressive alignment over the guide tree ({e['gpu']['levels']} levels), "
+                          f"gappy-column removal on, device-resident level path, 1 GPU; time of the whole process (read FASTA + tree ... write MSA)",
+                "aln_len": e["aln_len"], "summary": e["gpu"]["summary"], "msa_md5": e["gpu"]["md5"],
+                "recorded_cpu_checker_s": rec.get("cpu", {}).get("wall_s") if same_family else None,
+                "msa_equals_recorded_cpu_checker_msa": (e["gpu"]["md5"] == rec.get("cpu", {}).get("md5")) if same_family else None,
+                "note": "the CPU leg (oracle/e2e_oracle, 16 threads, ~107 s) is recorded in profiles/r01/e2e_wallclock_10000x10k.json, not re-run here"}
+    except Exception as ex:  # noqa: BLE001
+        return {"value": None, "unit": "s", "note": f"e2e leg failed: {ex}"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +137,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+
+    # wall-clock-to-MSA leg first: a child process, started before this process touches the GPU
+    e2e = wallclock_to_msa() if (world == 1 and not args.no_e2e) else None
 
     # ---- synthetic workload, built on the host before the GPU is touched ----
     pool_n = min(args.pool, args.pairs)
@@ -208,6 +246,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(batch, idx[:kmax], aln[:kmax].cpu().numpy(), alen[:kmax].cpu().numpy())
             except Exception as e:  # the checker must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if e2e is not None:
+            out["wallclock_to_msa"] = e2e
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -64,6 +64,9 @@ def main():
     print(json.dumps(res, indent=1))
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
+    if not a.keep:                      # the family and the (possibly GB-sized) MSAs were only needed for the comparison
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/$1
 mkdir -p $O
-CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --pairs 1024"
+CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --pairs 1024"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $CMD > $O/bench_under_rocprof.json 2> $O/kt.err
 rocprofv3 --kernel-trace --output-format csv -d $O/p1 -o p1 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES -- $CMD > /dev/null 2> $O/p1.err
 rocprofv3 --kernel-trace --output-format csv -d $O/p2 -o p2 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -- $CMD > /dev/null 2> $O/p2.err

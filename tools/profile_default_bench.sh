@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/$1
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py > $O/bench_default_under_rocprof.json 2> $O/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-e2e > $O/bench_default_under_rocprof.json 2> $O/kt.err
 find $O -name "*kernel_stats.csv" -exec cp {} $O/default_kernel_stats.csv \;
 head -3 $O/default_kernel_stats.csv | cut -c1-200
 tail -c 900 $O/bench_default_under_rocprof.json
