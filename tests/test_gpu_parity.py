@@ -267,3 +267,12 @@ def test_column_scores_match_oracle(gpu, kind):
             denom = float(np.float32(b.num[i, 0]) * np.float32(b.num[i, 1]))
             want = np.array([[O.column_score(op, ref[j], qry[ii], denom) for j in range(R)] for ii in range(Q)], dtype=np.float32)
             assert got.shape == want.shape and np.array_equal(got, want), f"{kind} pair {i}: {int((got != want).sum())} of {got.size} cells differ"
+
+
+@pytest.mark.timeout(900)
+def test_long_pairs_100k(gpu):
+    """Two pairs of ~100 kbp profiles (~100 tiles each, ~10^8 band cells): index arithmetic, step budget and tile stitching at a length
+    ten times the benchmark's; the oracle needs a few seconds per pair."""
+    batch = synth.make_level_batch(2, 100000, members=((1, 3), (1, 3)), seed=77)
+    st, ost = _compare(gpu, batch)
+    assert ost.cells > 5e7
