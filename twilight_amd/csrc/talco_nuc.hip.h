@@ -1,0 +1,623 @@
+// twilight_amd/csrc/talco_nuc.hip.h -- the nucleotide (P = 6) TALCO-XDrop kernel of round 2: same results as
+// talco_kernel<6,...> (talco_kernel.hip.h), a diagonal step built for instruction count.
+//
+// What it computes: Talco_xdrop::Align_freq / Tile / Traceback of the reference CPU path
+// (/root/reference/src/TALCO-XDrop.cpp:62-108, :233-689, :134-231), fp32, x86 TALCO_SIMD operation order.
+//
+// Why a second kernel.  Measured on MI355X (tools/micro/issue_rates*.hip, profiles/r02/issue_rates*.log): one wave issues one
+// instruction of ANY kind per ~4 cycles; a CU retires at most ~1 scalar-type instruction (s_*, v_readlane, v_writelane) per
+// cycle; an LDS round trip is ~50 cycles and an s_barrier of 16 waves ~20.  The round-1 kernel issued ~800 instructions per
+// wave and diagonal (of which ~340 scalar and ~70 SGPR spill moves), so a lone pair's diagonal cost 1.6 us and a full CU was
+// bound by the scalar unit.  The diagonal step is therefore rebuilt around "fewer instructions per wave":
+//   * three loops, one per phase of a tile (A: k < marker-1, traceback pointers only; B: the two marker diagonals; C: k > marker,
+//     convergence pointers only) instead of per-step phase tests;
+//   * bands kept as (low, width-1) pairs that rotate, one unsigned compare per band test, one combined stop test per step
+//     with the exact decoding out of line; the watchdog counts tiles' diagonals, not steps;
+//   * per-diagonal reductions without reset or rotation: the running maximum is an LDS float max that only lanes above the
+//     current maximum touch; first/last unpruned row are ONE two-lane ds_max_u32 on (diagonal tag << 16 | row) words, so a
+//     stale slot loses by construction; slots alternate by parity;
+//   * the running maximum / X-drop threshold live in (uniform) vector registers: no scalar float emulation through integer keys;
+//   * q[m]*M[l][m] (first rounding of (q*M)*r, :386) kept per row for the whole tile; the IEEE division by refNum*qryNum
+//     (:444) as the hoisted-reciprocal form of the same correctly rounded sequence (see fast_div below);
+//   * the traceback word of a row block is stored every 8th diagonal unconditionally (no dirty tracking).
+// Everything observable (band evolution, tile boundaries, paths, error codes, band-cell counts) is unchanged and is checked
+// against the oracle by the same parity suite.
+#pragma once
+#include "talco_kernel.hip.h"
+
+namespace twl {
+
+struct NArgs {
+    const float *cols;        // packed columns [pair][2][seq_len][8]: f0..f5, gapOpen, gapExtend
+    const int32_t *len;       // [pair][2]
+    const int32_t *num;       // [pair][2]
+    int8_t *aln;              // [pair][2*seq_len]
+    int32_t *aln_len;         // [pair]
+    int16_t *err;             // [pair]
+    unsigned long long *cells;// [pair]
+    uint32_t *tb;             // [grid][tb_words]
+    int32_t *queue;           // [1] next work item
+    const int32_t *items;     // [n_items] pair ids in launch order (cost-sorted)
+    int32_t n_items;
+    int32_t seq_len;
+    int32_t tb_words;         // per workgroup
+    int32_t *dbg;             // optional [pair][16] debug record (nullptr = off)
+    int32_t n_pairs_total;
+    int32_t step_slack;       // watchdog: a pair may run at most (R+Q+2)*((R+Q)/(marker-1)+4) + step_slack diagonals in total
+    float gap_open, gap_extend, gap_char;
+    int32_t xdrop, flen, marker;
+    float M[25];              // scoreMatrix[l][m] row-major 5x5
+};
+
+typedef float nuc_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_ld128(unsigned addr)      // one ds_read_b128 at a byte address kept in a register
+{
+    const nuc_f4 v = *reinterpret_cast<const __attribute__((address_space(3))) nuc_f4 *>((const __attribute__((address_space(3))) char *)nullptr + addr);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_max_u32(unsigned addr, unsigned v) { asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_max_f32(unsigned addr, float v) { asm volatile("ds_max_f32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+
+// n / d for a divisor that is fixed for the whole pair.  `r` is the refined reciprocal fma(fma(-d, rcp(d), 1), rcp(d), rcp(d)).
+// This is the instruction sequence the compiler emits for an IEEE fp32 division (v_div_scale, v_rcp, 4 fma, v_div_fmas,
+// v_div_fixup) with the parts that depend on d alone hoisted and the scaling steps left out.  v_div_scale rescales only when
+// d or n/d is near the ends of the exponent range or |n| < 2^-103, and v_div_fixup only patches zeros, infinities and NaNs,
+// so for 1 <= d <= 2^40 and n == 0 or 2^-73 <= |n| <= 2^80 both give the same bits (a zero quotient may differ in sign, which
+// no comparison or sum downstream can see).  The kernel guards that range: profile entries and scores outside it send the
+// pair to the IEEE-division kernel (err = kErrOverflow, re-run by the next stage of the chain).  tests/test_gpu_parity.py
+// compares the two forms bit for bit on device (twl_debug_fast_div).
+__device__ __forceinline__ float fast_div(float n, float d, float r)
+{
+    const float q0 = n * r;
+    const float t0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(t0, r, q0);
+    const float t1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(t1, r, q1);
+}
+__device__ __forceinline__ float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+// a profile entry fast_div's guard accepts: zero, or 2^-20 <= |x| <= 2^30
+__device__ __forceinline__ bool div_guard_bad(float x)
+{
+    const float ax = __builtin_fabsf(x);
+    return (x != 0.0f) && !(ax >= 9.5367431640625e-07f && ax <= 1073741824.0f);
+}
+
+template <int W, int RPL>
+struct NCfg {
+    static constexpr int NV = W * RPL;          // 64-row blocks resident at once
+    static constexpr int WINDOW = 64 * NV;      // rows
+    static constexpr int NB = NV + 2;           // ring blocks
+    static constexpr int CAP = 64 * NB;         // ring columns
+    static constexpr int THREADS = 64 * W;
+};
+
+// MM = matrix mode (host-selected from the matrix values, see talco_kernel): 0 general 5x5, 1 zero N row/column (4x4 core),
+// 2 mode 1 with the match / transition / transversion structure (three products per row letter).
+template <int W, int RPL, int MM, int MINW>
+__global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
+{
+    using C = NCfg<W, RPL>;
+    constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
+    constexpr int NQM = (MM == 2) ? 12 : (MM == 1 ? 16 : 25);
+
+    __shared__ float4 s_ring[2 * CAP];        // plane-major: [0][slot] = f0..f3, [1][slot] = f4, f5(gap), gapOpen, gapExtend
+    __shared__ int4 s_exch[2][NV];            // mailbox: lane 63 of a block -> lane 0 of the next block {S, I, CS, CI}
+    __shared__ unsigned s_red[2][4];          // per parity: {running max S (float bits), first-row tag, last-row tag, -}
+    __shared__ int s_conv[2][4];              // {vmin, vmax, flags, -}
+    __shared__ int s_misc[4];
+    __shared__ int s_cd[2][WINDOW + 1];       // offset-addressed mirror of the reference's CD rows (see talco_kernel)
+    __shared__ int8_t s_rev[2 * kMaxMarker + 16];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *tb = a.tb + (size_t)blockIdx.x * (size_t)a.tb_words;
+    const int marker = a.marker;
+    const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
+    const float xdropf = (float)a.xdrop;
+    const float gc = a.gap_char;
+
+    for (;;) {
+        if (threadIdx.x == 0) s_misc[0] = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        if (item >= a.n_items) break;
+        const int pair = __builtin_amdgcn_readfirstlane(a.items[item]);
+        const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
+        const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
+        const bool denomOne = (denom == 1.0f);
+        const float rden = refined_rcp(denom);
+        const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * 8);
+        const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * 8);
+        int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
+
+        // NOTE on control flow (as in talco_kernel): no `continue`, and every single-lane block is followed by a workgroup
+        // barrier before a loop back-edge.
+        int ref_idx = 0, qry_idx = 0, tile = 0, pos = 0, err = 0;
+        bool last_tile = (R <= 0 || Q <= 0);
+        unsigned long long cells = 0;
+        long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
+        // the row tags of the reductions hold (k >> 1) + 1 in 16 bits and a row in 16 bits
+        if (!last_tile && (R + Q > 130000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
+        int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
+        bool guardBad = false;
+
+        while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
+            const int refLen = R - ref_idx, qLen = Q - qry_idx;
+            const int fLen = min(a.flen, min(refLen, qLen));                          // :258
+            // one unsigned compare per step covers "band empty", "wider than fLen" and (conservatively) "outgrew the window"
+            // (two blocks of margin: below it a block that leaves the band cannot be needed again on the same diagonal)
+            const int fcap = min(fLen, 64 * (NV - 2));
+            // ---- per-slot state ----
+            float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
+            int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
+            float qv[RPL][6], gopq[RPL], gexq[RPL], qM[RPL][NQM];
+            int blk[RPL];
+            unsigned ra[RPL];              // byte address of this lane's reference column in plane 0 of the ring
+            uint32_t tbacc[RPL];
+            bool q5any[RPL];
+
+            auto load_q = [&](int r) {
+                const int i = 64 * blk[r] + lane;
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+                if (qry_idx + i < Q) { c0 = colsQ[2 * (size_t)(qry_idx + i)]; c1 = colsQ[2 * (size_t)(qry_idx + i) + 1]; }
+                qv[r][0] = c0.x; qv[r][1] = c0.y; qv[r][2] = c0.z; qv[r][3] = c0.w; qv[r][4] = c1.x; qv[r][5] = c1.y;
+                gopq[r] = c1.z; gexq[r] = c1.w;
+                // first rounding of (q[m]*M[l][m])*r[l], :386
+                if constexpr (MM == 2) {
+                    const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { qM[r][m] = qv[r][m] * mA; qM[r][4 + m] = qv[r][m] * mB; qM[r][8 + m] = qv[r][m] * mC; }
+                } else if constexpr (MM == 1) {
+#pragma unroll
+                    for (int l = 0; l < 4; ++l)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) qM[r][4 * l + m] = qv[r][m] * a.M[5 * l + m];
+                } else {
+#pragma unroll
+                    for (int l = 0; l < 5; ++l)
+#pragma unroll
+                        for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = qv[r][m] * a.M[5 * l + m];
+                }
+                q5any[r] = __builtin_amdgcn_ballot_w64(c1.y != 0.0f) != 0ull;
+                const bool bad = div_guard_bad(c0.x) | div_guard_bad(c0.y) | div_guard_bad(c0.z) | div_guard_bad(c0.w) | div_guard_bad(c1.x) |
+                                 div_guard_bad(c1.y);
+                guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
+            };
+            auto load_ring_block = [&](int B) {
+                const int col = 64 * B + lane;
+                const int slot = (B % NB) * 64 + lane;
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+                if (col < refLen) { c0 = colsR[2 * (size_t)(ref_idx + col)]; c1 = colsR[2 * (size_t)(ref_idx + col) + 1]; }
+                s_ring[slot] = c0;
+                s_ring[CAP + slot] = c1;
+                const bool bad = div_guard_bad(c0.x) | div_guard_bad(c0.y) | div_guard_bad(c0.z) | div_guard_bad(c0.w) | div_guard_bad(c1.x) |
+                                 div_guard_bad(c1.y);
+                guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
+            };
+            auto ring_addr = [&](int r, int k) {      // ((k - 64*blk - lane) mod CAP) * 16
+                int rs = (k - 64 * blk[r] - lane) % CAP;
+                rs += (rs < 0) ? CAP : 0;
+                ra[r] = (unsigned)rs * 16u + lds_off(s_ring);
+            };
+
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                blk[r] = r * W + w;
+                ring_addr(r, 0);
+                tbacc[r] = 0;
+                S1[r] = I1[r] = D1[r] = LS2[r] = -1.0f;       // never read before written for in-band cells
+                CS1[r] = -1; CI1[r] = kIB; CD1[r] = kDB; LCS2[r] = -1;
+                load_q(r);
+            }
+            int hiBlk = 1;
+            if (w == 0 % W) load_ring_block(0);
+            if (w == 1 % W) load_ring_block(1);
+            for (int t = threadIdx.x; t < 2 * (WINDOW + 1); t += C::THREADS) (&s_cd[0][0])[t] = kDB;      // :308
+            if (threadIdx.x == 0) {
+                s_red[0][0] = s_red[1][0] = (unsigned)__float_as_int(-inf);
+                s_red[0][1] = s_red[0][2] = s_red[1][1] = s_red[1][2] = 0u;
+                s_conv[0][0] = 0x7fffffff; s_conv[0][1] = (int)0x80000000; s_conv[0][2] = 0;
+                s_conv[1][0] = 0x7fffffff; s_conv[1][1] = (int)0x80000000; s_conv[1][2] = 0;
+            }
+            __syncthreads();
+
+            // ---- Tile, TALCO-XDrop.cpp:233-689 ----
+            // bands: diagonal k as (Lk, Uk); diagonal k-1 as (lo1, w1 = width-1), diagonal k-2 as (lo2p = low+1, w2); an empty
+            // band is (0x3fffffff, 0), which no row matches (:296-297 start with L > U for k-1 and k-2)
+            int Lk = 0, Uk = 0, lo1 = 0x3fffffff, lo2p = 0x3fffffff;
+            unsigned w1 = 0, w2 = 0;
+            int wid1 = 0;                                // width of diagonal k-1 (0 when empty): the stale CD slot, see s_cd
+            float msp = -inf, convf = 0.0f;              // running maximum (:259), score at convergence (:594)
+            bool converged = false;
+            int conv_value = 0, prev_conv_s = -1;
+            const int kEnd = refLen + qLen - 1;
+            int k = 0;
+            int tile_err = 0;
+            unsigned tile_cells = 0;                     // < 2^32 per tile
+            bool spec = true;                            // the next diagonal may be a "special" one (k == 0, or tile 0's first row/column)
+            bool tbPending = false;
+            unsigned tbOff = (unsigned)lane * 4u;        // byte offset of this lane's word in the current group of 8 diagonals (slot 0)
+            const unsigned redLaneOff = (unsigned)((lane == 63) ? 8 : 4);
+            const bool is63 = (lane == 63);
+
+            // One diagonal.  PH: 0 = A (k < marker-1), 1 = B (k == marker-1 or marker), 2 = C (k > marker).
+            // Returns 0 to go on, 1 on a stop condition (tile_err set), 2 when the tile ended by convergence (:609-612).
+            auto step = [&](auto PHtag) -> int {
+                constexpr int PH = decltype(PHtag)::value;
+                constexpr bool TB = (PH != 2), CONV = (PH != 0);
+                const int width1 = Uk - Lk;
+                if (__builtin_expect((unsigned)width1 >= (unsigned)fcap, 0)) {
+                    // exact decoding: :323-329 band emptied by X-drop, :331-338 wider than fLen, or it really outgrew this window
+                    if (Lk > Uk) { tile_err = 1; return 1; }
+                    if (width1 + 1 > fLen) { tile_err = 2; return 1; }
+                    if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; return 1; }
+                    // a band this wide can need the successor of a block on the diagonal the block leaves it: advance before the activity test
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r)
+                        if (64 * blk[r] + 63 < Lk) { while (64 * blk[r] + 63 < Lk) blk[r] += NV; ring_addr(r, k); load_q(r); }
+                }
+                tile_cells += (unsigned)(width1 + 1);
+                const int par = k & 1;
+                const float thr = ((msp > 0.0f) ? msp : 0.0f) - xdropf;        // :495 with :607
+                bool special = false;
+                if (__builtin_expect(spec, 0)) {
+                    special = (k == 0) | ((tile == 0) && (Lk == 0 || Uk == k));
+                    spec = special;                                          // both conditions are monotone: once false, false for the tile
+                }
+                {
+                    const int need_hi = ((k - Lk) >> 6) + 1;
+                    if (__builtin_expect(hiBlk < need_hi, 0)) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
+                }
+                int staleCD = kDB;
+                if constexpr (PH == 2) staleCD = s_cd[par ^ 1][wid1];         // one broadcast read per diagonal
+                const unsigned kk = (unsigned)(k >> 1) + 1u;
+
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int vw = r * W + w;
+                    const int b = 64 * blk[r];
+                    // the block takes part when the band touches it or will reach it on the next diagonal (its lane 0 then needs
+                    // S[k-1][b-1] now, to have S[k-2][i-1] next time): Lk - 63 <= b <= Uk + 1
+                    const bool act = (unsigned)(b - (Lk - 63)) <= (unsigned)(width1 + 64);
+                    if (act) {
+                        const int i = b + lane;
+                        // ---- loads: mailbox of the previous block, reference column of this cell ----
+                        float eS, eI; int eCS = 0, eCI = 0;
+                        if constexpr (CONV) {
+                            const int4 e = s_exch[par ^ 1][(vw + NV - 1) % NV];
+                            eS = __int_as_float(e.x); eI = __int_as_float(e.y); eCS = e.z; eCI = e.w;
+                        } else {
+                            const int2 e = *reinterpret_cast<const int2 *>(&s_exch[par ^ 1][(vw + NV - 1) % NV]);
+                            eS = __int_as_float(e.x); eI = __int_as_float(e.y);
+                        }
+                        const float4 c0 = lds_ld128(ra[r]);
+                        const float4 c1 = lds_ld128(ra[r] + CAP * 16);
+                        const float rc[5] = {c0.x, c0.y, c0.z, c0.w, c1.x};
+                        const float rg = c1.y, gopr = c1.z, gexr = c1.w;
+                        // ---- column score, :378-395 (order: per l the products summed left to right, accumulated over l) ----
+                        float numer;
+                        if constexpr (MM == 2) {
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) {
+                                float t[4];
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) t[m] = qM[r][((l == m) ? 0 : (((l ^ m) == 2) ? 4 : 8)) + m] * rc[l];
+                                const float sl = ((t[0] + t[1]) + t[2]) + t[3];
+                                numer = (l == 0) ? sl : numer + sl;
+                            }
+                        } else if constexpr (MM == 1) {
+#pragma unroll
+                            for (int l = 0; l < 4; ++l) {
+                                float t[4];
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) t[m] = qM[r][4 * l + m] * rc[l];
+                                const float sl = ((t[0] + t[1]) + t[2]) + t[3];
+                                numer = (l == 0) ? sl : numer + sl;
+                            }
+                        } else {
+#pragma unroll
+                            for (int l = 0; l < 5; ++l) {
+                                float t[5];
+#pragma unroll
+                                for (int m = 0; m < 5; ++m) t[m] = qM[r][5 * l + m] * rc[l];
+                                const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+                                numer = (l == 0) ? sl : numer + sl;
+                            }
+                        }
+                        const unsigned long long inbandMask = __builtin_amdgcn_ballot_w64((unsigned)(i - Lk) <= (unsigned)width1);
+                        if (q5any[r]) {
+#pragma unroll
+                            for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
+                        }
+                        if ((inbandMask & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
+#pragma unroll
+                            for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
+                        }
+                        float sim = numer;                                                         // :444
+                        if (!denomOne) sim = fast_div(numer, denom, rden);
+
+                        // ---- neighbours ----
+                        const float LS1 = dpp_shr1_f(eS, S1[r]);
+                        const float LI1 = dpp_shr1_f(eI, I1[r]);
+                        int LCS1 = 0, LCI1 = 0;
+                        if constexpr (CONV) { LCS1 = dpp_shr1_i(eCS, CS1[r]); LCI1 = dpp_shr1_i(eCI, CI1[r]); }
+                        const unsigned t1 = (unsigned)(i - lo1);
+                        const bool up_ok = t1 <= w1;                      // i   in band(k-1)
+                        const bool left_ok = (t1 - 1u) <= w1;             // i-1 in band(k-1)
+                        const bool diag_ok = (unsigned)(i - lo2p) <= w2;  // i-1 in band(k-2)
+                        // ---- recurrence, :445-497 ----
+                        float match = diag_ok ? LS2[r] + sim : -inf;
+                        if (__builtin_expect(special, 0)) {
+                            const int j = k - i;
+                            if (k == 0) match = sim;
+                            else if (i == 0 || j == 0) {
+                                int far = max(i, j) - 1; far = far < 0 ? 0 : far;
+                                match = (sim + a.gap_open) + a.gap_extend * (float)far;
+                            }
+                        }
+                        const float delOp = S1[r] + gopr, delExt = D1[r] + gexr;                  // :456-463
+                        const float insOp = LS1 + gopq[r], insExt = LI1 + gexq[r];
+                        // an invalid neighbour makes both candidates -inf: the state is -inf and "extend" wins the tie (:468-475).
+                        // (compare + select rather than fmaxf: the compare is needed for the pointer bits anyway, and a max would be
+                        // preceded by two canonicalising moves)
+                        const bool dGE = delExt >= delOp, iGE = insExt >= insOp;
+                        const bool Dptr = !up_ok | dGE;
+                        const bool Iptr = !left_ok | iGE;
+                        const float Dv = up_ok ? (dGE ? delExt : delOp) : -inf;
+                        const float Iv = left_ok ? (iGE ? insExt : insOp) : -inf;
+                        // :477-494: G = (I > D ? I : D) is the better gap state (D wins ties); M wins when match >= G
+                        const bool gapIsI = Iv > Dv;
+                        const float Gv = gapIsI ? Iv : Dv;
+                        const bool isM = match >= Gv;
+                        float Sv = isM ? match : Gv;
+                        Sv = (Sv < thr) ? -inf : Sv;                                               // :495-497
+                        const bool inband = (unsigned)(i - Lk) <= (unsigned)width1;
+
+                        if constexpr (CONV) {                                                      // :520-547
+                            int CSn, CIn, CDn;
+                            const int i16 = i & 0xFFFF;
+                            if (PH == 1 && k == marker - 1) { CSn = (3 << 16) | i16; CIn = CI1[r]; CDn = CD1[r]; }
+                            else if (PH == 1) { CSn = i16; CIn = (1 << 16) | i16; CDn = (2 << 16) | i16; }
+                            else {
+                                const int viaS = (LCS1 != -1) ? LCS1 : kIB;
+                                CIn = left_ok ? (Iptr ? LCI1 : viaS) : kIB;
+                                const int cdUp = up_ok ? CD1[r] : staleCD;      // above the stored band the reference reads the stale slot (:535)
+                                CDn = Dptr ? cdUp : ((CS1[r] != -1) ? CS1[r] : kDB);
+                                const int viaGap = gapIsI ? CIn : CDn;
+                                CSn = isM ? (diag_ok ? LCS2[r] : -1) : viaGap;   // M without a diagonal predecessor: "unset", as in the oracle (:541)
+                            }
+                            CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn;
+                            if (PH == 2 || k == marker) { if (inband) s_cd[par][i - Lk] = CDn; }
+                        }
+                        S1[r] = Sv; I1[r] = Iv; D1[r] = Dv;
+                        // ---- reductions of this diagonal ----
+                        const unsigned long long vm = inbandMask & __builtin_amdgcn_ballot_w64(Sv > -inf);
+                        if (inband && Sv > msp) lds_max_f32(lds_off(&s_red[par][0]), Sv);         // :501-503
+                        if (vm) {
+                            const unsigned firstRow = (unsigned)(b + (int)__builtin_ctzll(vm));
+                            const unsigned lastRow = (unsigned)(b + 63 - (int)__builtin_clzll(vm));
+                            const unsigned tagF = (kk << 16) | (0xFFFFu - firstRow), tagL = (kk << 16) | lastRow;
+                            if (lane >= 62) lds_max_u32(lds_off(&s_red[par][0]) + redLaneOff, is63 ? tagL : tagF);
+                        }
+                        if (is63) {
+                            if constexpr (CONV) s_exch[par][vw] = make_int4(__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]);
+                            else *reinterpret_cast<int2 *>(&s_exch[par][vw]) = make_int2(__float_as_int(Sv), __float_as_int(Iv));
+                        }
+                        if constexpr (TB) {                                                        // :548-557
+                            const uint32_t nib = (isM ? 0u : (gapIsI ? 1u : 2u)) | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
+                            tbacc[r] |= nib << (4 * (k & 7));
+                        }
+                        LS2[r] = LS1;
+                        if constexpr (CONV) LCS2[r] = LCS1;
+                    } else if (b + 63 < Lk) {                  // block fell out of the band: take the next one
+                        while (64 * blk[r] + 63 < Lk) blk[r] += NV;
+                        ring_addr(r, k);
+                        load_q(r);
+                    }
+                    ra[r] += 16u;
+                    if (ra[r] == lds_off(s_ring) + CAP * 16u) ra[r] = lds_off(s_ring);
+                }
+                if constexpr (TB) {
+                    tbPending = true;
+                    if ((k & 7) == 7 || (PH == 1 && k == marker)) {
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) {
+                            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
+                            tbacc[r] = 0;
+                        }
+                        tbOff += (unsigned)WINDOW * 4u;
+                        tbPending = false;
+                    }
+                }
+                __syncthreads();
+
+                // ---- post: the band of the next diagonal, :563-604 ----
+                const uint4 rd = *reinterpret_cast<const uint4 *>(&s_red[par][0]);
+                { const float g = __uint_as_float(rd.x); msp = (g > msp) ? g : msp; }
+                const unsigned tF = (unsigned)__builtin_amdgcn_readfirstlane((int)rd.y), tL = (unsigned)__builtin_amdgcn_readfirstlane((int)rd.z);
+                const bool anyValid = (tL >> 16) == kk;
+                const int newL = anyValid ? (int)(0xFFFFu - (tF & 0xFFFFu)) : Uk + 1;
+                const int newU = anyValid ? (int)(tL & 0xFFFFu) : Lk - 1;
+
+                if constexpr (CONV) {                                                              // :585-595
+                    if (!converged && k < kEnd - 1) {
+                        int conv_S = -1;
+                        bool all3 = false;
+                        if constexpr (PH == 1) {
+                            if (k == marker - 1) conv_S = (newL == newU) ? ((3 << 16) | (newL & 0xFFFF)) : -1;
+                            else conv_S = (newL == newU) ? (newL & 0xFFFF) : -1;
+                        } else {
+                            if (threadIdx.x == 0) { s_conv[par ^ 1][0] = 0x7fffffff; s_conv[par ^ 1][1] = (int)0x80000000; s_conv[par ^ 1][2] = 0; }
+#pragma unroll
+                            for (int r = 0; r < RPL; ++r) {
+                                const int b = 64 * blk[r];
+                                if (b <= newU && b + 63 >= newL) {
+                                    const int i = b + lane;
+                                    const bool inr = (i >= newL) && (i <= newU);
+                                    const unsigned long long rm = __builtin_amdgcn_ballot_w64(inr);
+                                    if (rm) {
+                                        const int fl = (int)__builtin_ctzll(rm);
+                                        const int v = __builtin_amdgcn_readlane(CS1[r], fl);
+                                        const bool badS = __builtin_amdgcn_ballot_w64(inr && CS1[r] != v) != 0ull;
+                                        const bool badID = __builtin_amdgcn_ballot_w64(inr && (CI1[r] != v || CD1[r] != v)) != 0ull;
+                                        if (lane == 0) {
+                                            lds_min_i32(&s_conv[par][0], v);
+                                            lds_max_i32(&s_conv[par][1], v);
+                                            if (badS || badID) lds_or_b32(&s_conv[par][2], (badS ? 1 : 0) | (badID ? 2 : 0));
+                                        }
+                                    }
+                                }
+                            }
+                            __syncthreads();
+                            const int vmin = __builtin_amdgcn_readfirstlane(s_conv[par][0]);
+                            const int vmax = __builtin_amdgcn_readfirstlane(s_conv[par][1]);
+                            const int fl = __builtin_amdgcn_readfirstlane(s_conv[par][2]);
+                            if (newU >= newL && vmin == vmax && !(fl & 1)) { conv_S = vmin; all3 = !(fl & 2); }
+                        }
+                        if (all3 && prev_conv_s == conv_S && conv_S != -1) { converged = true; conv_value = prev_conv_s; convf = msp; }
+                        prev_conv_s = conv_S;
+                    }
+                }
+                {                                                                                  // :597-604
+                    const int Lprime = max(k + 2 - refLen, 0);
+                    lo2p = lo1 + 1; w2 = w1;                   // (an empty band keeps an unreachable low)
+                    lo1 = Lk; w1 = (unsigned)width1; wid1 = width1 + 1;
+                    Lk = max(newL, Lprime);
+                    Uk = min(qLen - 1, newU + 1);
+                }
+                if constexpr (CONV) {
+                    if (converged) {                                                               // :607-612: max(0, max') > score at convergence
+                        if (__builtin_amdgcn_ballot_w64(((msp > 0.0f) ? msp : 0.0f) > convf) != 0ull) return 2;
+                    }
+                }
+                return 0;
+            };
+
+            int brk = 0;
+            if (steps_left < 0) { tile_err = 3; brk = 1; }
+            {
+                const int kA = min(kEnd, marker - 1);
+                for (; !brk && k < kA; ++k) { brk = step(std::integral_constant<int, 0>{}); if (brk) break; }
+                const int kB = min(kEnd, marker + 1);
+                if (!brk) for (; k < kB; ++k) { brk = step(std::integral_constant<int, 1>{}); if (brk) break; }
+                if (!brk) for (; k < kEnd; ++k) { brk = step(std::integral_constant<int, 2>{}); if (brk) break; }
+            }
+            const bool conv_logic = (brk == 2);
+            const int last_k = conv_logic ? k : k - 1;
+            steps_left -= (long long)(last_k + 1);
+
+            cells += tile_cells;
+            dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
+            if (tile_err != 0) { err = tile_err; break; }
+            if (guardBad && !denomOne) { err = kErrOverflow; break; }   // a profile entry outside fast_div's range: the IEEE-division kernel re-runs the pair
+
+            // a tile that ends before the marker leaves its last (partial) group of 8 diagonals unflushed
+            if (tbPending) {
+#pragma unroll
+                for (int r = 0; r < RPL; ++r)
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
+            }
+
+            // ---- tile exit, :615-682 ----
+            // after the loop (lo1, w1) is the band of diagonal last_k (rotated once more at its end)
+            int conv_q = 0, conv_r = 0, tb_state = 0, start_k = 0;
+            bool bad = false;
+            if (!conv_logic && last_k >= marker) {                            // :633-635 needs CS[last_k][0]
+                const int Llast = lo1;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const int b = 64 * blk[r];
+                    if (Llast >= b && Llast <= b + 63 && lane == Llast - b) s_misc[1] = CS1[r];
+                }
+                __syncthreads();
+                conv_value = __builtin_amdgcn_readfirstlane(s_misc[1]);
+            }
+            if (conv_logic || last_k >= marker) {
+                conv_q = conv_value & 0xFFFF;
+                tb_state = (conv_value >> 16) & 0xFFFF;
+                if (tb_state > 3) bad = true;      // boundary sentinel / unset: the reference indexes out of range here
+                else {
+                    conv_r = marker - conv_q - ((tb_state == 3) ? 1 : 0);
+                    start_k = (tb_state == 3) ? marker - 1 : marker;
+                    if (conv_r < 0) bad = true;
+                }
+            } else {                                                          // :625-632
+                conv_q = qLen - 1; conv_r = refLen - 1; start_k = last_k; tb_state = 0; last_tile = true;
+            }
+            if (bad) { err = 3; break; }
+            ref_idx += conv_r; qry_idx += conv_q;                             // :654-655
+            if (R - ref_idx < 0 || Q - qry_idx < 0) { err = 3; break; }       // :659-668
+            int tailDir = 0, tailLen = 0;
+            if (ref_idx == R - 1 && qry_idx < Q - 1) { tailDir = 1; tailLen = Q - qry_idx - 1; last_tile = true; }   // :671-674
+            if (qry_idx == Q - 1 && ref_idx < R - 1) { tailDir = 2; tailLen = R - ref_idx - 1; last_tile = true; }   // :675-678
+            if (ref_idx == R - 1 && qry_idx == Q - 1) last_tile = true;       // :679
+
+            __syncthreads();   // all traceback-pointer stores of this tile are complete and visible
+            if (w == 0) {
+                int n = 0;
+                if (lane == 0) {   // Traceback, :134-231, addressed by (diagonal, row) instead of a ragged offset
+                    int kk2 = start_k, ii = conv_q, qi = conv_q, ri = conv_r, st = tb_state % 3;
+                    const bool first = (tile == 0);
+                    while (kk2 >= 0) {
+                        const uint32_t word = __hip_atomic_load(&tb[(size_t)(kk2 >> 3) * WINDOW + (ii % WINDOW)], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                        const int v = (int)((word >> (4 * (kk2 & 7))) & 0xFu);
+                        int dir;
+                        if (st == 0) {
+                            st = v & 3;
+                            if (st == 0) dir = 0;
+                            else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
+                            else { dir = 2; st = (v & 8) ? 2 : 0; }
+                        } else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
+                        else { dir = 2; st = (v & 8) ? 2 : 0; }
+                        if (dir == 0) { kk2 -= 2; ii -= 1; qi--; ri--; }
+                        else if (dir == 1) { kk2 -= 1; ii -= 1; qi--; }
+                        else { kk2 -= 1; ri--; }
+                        s_rev[n++] = (int8_t)dir;
+                        if (first && (ri < 0 || qi < 0)) break;
+                        if (ii < 0) break;   // defensive: a pointer chain left the tile (never on valid data)
+                    }
+                    if (first) {
+                        while (ri > -1) { s_rev[n++] = 2; ri--; }
+                        while (qi > -1) { s_rev[n++] = 1; qi--; }
+                    }
+                }
+                n = __builtin_amdgcn_readfirstlane(n);
+                const int skip = (tile > 0) ? 1 : 0;                          // :98-102
+                const int cnt = n - skip;
+                if (pos + cnt + tailLen > 2 * a.seq_len) { err = 3; }
+                else {
+                    for (int t = lane; t < cnt; t += 64) out[pos + t] = s_rev[n - 1 - skip - t];
+                    for (int t = lane; t < tailLen; t += 64) out[pos + cnt + t] = (int8_t)tailDir;
+                    pos += cnt + tailLen;
+                }
+                if (lane == 0) { s_misc[2] = err; s_misc[3] = pos; }
+            }
+            __syncthreads();
+            err = __builtin_amdgcn_readfirstlane(s_misc[2] == 3 ? 3 : err);
+            pos = __builtin_amdgcn_readfirstlane(s_misc[3]);
+            if (err != 0) break;
+            ++tile;
+        }
+
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.err[pair] = (int16_t)err;
+            a.aln_len[pair] = (err == 0) ? pos : 0;
+            a.cells[pair] = cells;
+            if (a.dbg) {
+                int32_t *g = a.dbg + 16 * (size_t)pair;
+                g[0] = tile; g[1] = dbg_lastk; g[2] = dbg_conv; g[3] = dbg_L; g[4] = dbg_U; g[5] = ref_idx; g[6] = qry_idx;
+                g[7] = pos; g[8] = err; g[9] = (int)min(steps_left, 0x7fffffffll); g[10] = R; g[11] = Q;
+            }
+        }
+        __syncthreads();   // keeps the single-lane block above out of the loop latch
+    }
+}
+
+}  // namespace twl

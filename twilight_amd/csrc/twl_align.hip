@@ -6,11 +6,13 @@
 #include "../../include/twl_level.h"
 #include "level_kernels.hip.h"
 #include "talco_kernel.hip.h"
+#include "talco_nuc.hip.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -148,6 +150,40 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     return TWL_OK;
 }
 
+// The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
+template <int W, int RPL, int MM, int MINW>
+int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
+{
+    using CfgT = twl::NCfg<W, RPL>;
+    static int cached = 0;      // one value per template instantiation
+    if (cached == 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, MM, MINW>), CfgT::THREADS, 0));
+        cached = std::max(1, nb);
+    }
+    int blocks_per_cu = cached;
+    if (const char *cap = getenv("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));   // development knob
+    if (window_out) *window_out = CfgT::WINDOW;
+    int grid = std::min(n_items, d->num_cu * blocks_per_cu);
+    if (grid < 1) grid = 1;
+    const size_t tbw = ((size_t)(base.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
+    int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
+    if (rc) return rc;
+    twl::NArgs a{};
+    a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
+    a.cells = base.cells; a.tb = (uint32_t *)d->tb.p; a.queue = base.queue; a.items = d_items; a.n_items = n_items;
+    a.seq_len = base.seq_len; a.tb_words = (int32_t)tbw; a.dbg = base.dbg; a.n_pairs_total = base.n_pairs_total;
+    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char;
+    a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
+    for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
+    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    TRACE("launch nuc W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
+    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, MM, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    *grid_out = grid;
+    return TWL_OK;
+}
+
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
@@ -219,7 +255,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int grid = 0, window = 0;
     const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry (nucleotide only)
-    const std::string c = cfg ? cfg : "w8r2";
+    const std::string c = cfg ? cfg : "nuc";
     const int32_t *items = (const int32_t *)d->items.p;
     auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
         return prot ? launch_dp<22, 8, 9, false, false, false>(d, st, a, it, n_it, 1, g, w)
@@ -275,7 +311,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             }
         }
     }
-    else if (c == "w8r2") {
+    else if (c == "w8r2" || c == "nuc" || c == "nuc16") {
         // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
         const float *M = a.M;
         bool nz = true, st3 = true;
@@ -285,7 +321,24 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const char *mmEnv = getenv("TWL_MATRIX_MODE");
         int mm = nz ? (st3 ? 2 : 1) : 0;
         if (mmEnv) mm = std::min(mm, atoi(mmEnv));          // development knob: force a more general mode
-        if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
+        // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]; anything else takes the IEEE-division kernel
+        bool divOk = true;
+        auto inRange = [](float x) { const float ax = std::fabs(x); return x == 0.0f || (ax >= 0.0009765625f && ax <= 1024.0f); };
+        for (int t = 0; t < 25; ++t) divOk = divOk && inRange(M[t]);
+        divOk = divOk && inRange(p->gap_char);
+        const bool lean = (c != "w8r2") && divOk;
+        // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
+        const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu);
+        if (lean && few) {
+            if (mm == 2) rc = launch_nuc<16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 1) rc = launch_nuc<16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
+            else rc = launch_nuc<16, 1, 0, 1>(d, st, a, items, n_pairs, &grid, &window);
+        } else if (lean) {
+            if (mm == 2) rc = launch_nuc<8, 2, 2, 4>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 1) rc = launch_nuc<8, 2, 1, 4>(d, st, a, items, n_pairs, &grid, &window);
+            else rc = launch_nuc<8, 2, 0, 2>(d, st, a, items, n_pairs, &grid, &window);
+        }
+        else if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
         else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
         else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_pairs, 0, &grid, &window);
     }
