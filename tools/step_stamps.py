@@ -23,10 +23,10 @@ api.init([0])
 api.align_batch(api.make_params(synth.nucleotide_matrix()), big)
 lib = api.load_library()
 lib.twl_debug_read.restype = C.c_int
-buf = (C.c_longlong * 80)()
-rc = lib.twl_debug_read(0, buf, 80)
+buf = (C.c_longlong * 136)()
+rc = lib.twl_debug_read(0, buf, 136)
 print("rc", rc)
-for w in range(8):
+for w in range(16):
     g = [buf[8 * w + t] for t in range(8)]
     if g[3]:
         print(f"wave {w}: steps {g[3]} active(slot0) {g[4]}  cycles/step: slots {g[0]/g[3]:.0f}  barrier wait {g[1]/g[3]:.0f}  post {g[2]/g[3]:.0f}  total/step {g[5]/g[3]:.0f};  whole pair {g[5]}  in steps {g[0]+g[1]+g[2]}  tile setup {g[7]}  tile exit+traceback {g[6]}")

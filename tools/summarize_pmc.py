@@ -10,7 +10,7 @@ for i in (1, 2, 3, 4):
         continue
     sums, disp, meta = {}, set(), {}
     for row in csv.DictReader(open(files[0])):
-        if "talco_kernel" not in row["Kernel_Name"]:
+        if "talco_" not in row["Kernel_Name"]:
             continue
         disp.add(row["Dispatch_Id"])
         sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])

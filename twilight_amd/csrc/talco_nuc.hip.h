@@ -55,6 +55,34 @@ __device__ __forceinline__ float4 lds_ld128(unsigned addr)      // one ds_read_b
     const nuc_f4 v = *reinterpret_cast<const __attribute__((address_space(3))) nuc_f4 *>((const __attribute__((address_space(3))) char *)nullptr + addr);
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef int nuc_i2 __attribute__((ext_vector_type(2)));
+typedef int nuc_i4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T lds_ld(unsigned addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) T *>((const __attribute__((address_space(3))) char *)nullptr + addr);
+}
+template <class T>
+__device__ __forceinline__ void lds_st(unsigned addr, T v)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) T *>((__attribute__((address_space(3))) char *)nullptr + addr) = v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_max_u32_off(unsigned addr, unsigned v) { asm volatile("ds_max_u32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void lds_max_f32_off(unsigned addr, float v) { asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+// ds atomics on (address register + immediate offset)
+#define TWL_LDS_ATOM(NAME)                                                                                                     \
+    template <int OFF>                                                                                                         \
+    __device__ __forceinline__ void NAME##_off(unsigned addr, int v) { asm volatile(#NAME " %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+TWL_LDS_ATOM(ds_min_i32)
+TWL_LDS_ATOM(ds_max_i32)
+TWL_LDS_ATOM(ds_or_b32)
+#undef TWL_LDS_ATOM
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory counter, which
+// makes every eighth diagonal wait for the round trip of its traceback store; those stores are only read after the tile's
+// final __syncthreads().
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void lds_max_u32(unsigned addr, unsigned v) { asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_max_f32(unsigned addr, float v) { asm volatile("ds_max_f32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
@@ -106,12 +134,20 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
     constexpr int NQM = (MM == 2) ? 12 : (MM == 1 ? 16 : 25);
 
     __shared__ float4 s_ring[2 * CAP];        // plane-major: [0][slot] = f0..f3, [1][slot] = f4, f5(gap), gapOpen, gapExtend
-    __shared__ int4 s_exch[2][NV];            // mailbox: lane 63 of a block -> lane 0 of the next block {S, I, CS, CI}
-    __shared__ unsigned s_red[2][4];          // per parity: {running max S (float bits), first-row tag, last-row tag, -}
-    __shared__ int s_conv[2][4];              // {vmin, vmax, flags, -}
+    // everything that alternates with the parity of the diagonal sits in one struct per parity, so that ONE register
+    // (vcur / vprev: the LDS address of the current / previous diagonal's struct) selects it and the rest is an immediate offset
+    struct ParBuf {
+        int cd[WINDOW + 4];          // offset-addressed mirror of the reference's CD rows (see talco_kernel)
+        int4 exch[NV];               // mailbox: lane 63 of a block -> lane 0 of the next block {S, I, CS, CI}
+        unsigned red[4];             // {running max S (float bits), low-end tag, high-end tag, -}
+        int conv[4];                 // {vmin, vmax, flags, -}
+        int4 trash[64];              // per-lane trash slots: single-lane LDS side effects without touching EXEC
+    };
+    __shared__ ParBuf s_par[2];
     __shared__ int s_misc[4];
-    __shared__ int s_cd[2][WINDOW + 1];       // offset-addressed mirror of the reference's CD rows (see talco_kernel)
     __shared__ int8_t s_rev[2 * kMaxMarker + 16];
+    constexpr unsigned O_CD = (unsigned)offsetof(ParBuf, cd), O_EXCH = (unsigned)offsetof(ParBuf, exch), O_RED = (unsigned)offsetof(ParBuf, red),
+                       O_CONV = (unsigned)offsetof(ParBuf, conv), O_TRASH = (unsigned)offsetof(ParBuf, trash);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -142,9 +178,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
         unsigned long long cells = 0;
         long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
         // the row tags of the reductions hold (k >> 1) + 1 in 16 bits and a row in 16 bits
-        if (!last_tile && (R + Q > 130000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
+        if (!last_tile && (R + Q > 130000 || Q > 65000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
         bool guardBad = false;
+#ifdef TWL_KERNEL_STAMPS
+        unsigned long long st_slots = 0, st_bar = 0, st_post = 0, st_n = 0, st_act = 0, st_exit = 0, st_setup = 0;
+        const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
             const int refLen = R - ref_idx, qLen = Q - qry_idx;
@@ -217,52 +257,62 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             int hiBlk = 1;
             if (w == 0 % W) load_ring_block(0);
             if (w == 1 % W) load_ring_block(1);
-            for (int t = threadIdx.x; t < 2 * (WINDOW + 1); t += C::THREADS) (&s_cd[0][0])[t] = kDB;      // :308
+            for (int t = threadIdx.x; t < WINDOW + 4; t += C::THREADS) { s_par[0].cd[t] = kDB; s_par[1].cd[t] = kDB; }      // :308
             if (threadIdx.x == 0) {
-                s_red[0][0] = s_red[1][0] = (unsigned)__float_as_int(-inf);
-                s_red[0][1] = s_red[0][2] = s_red[1][1] = s_red[1][2] = 0u;
-                s_conv[0][0] = 0x7fffffff; s_conv[0][1] = (int)0x80000000; s_conv[0][2] = 0;
-                s_conv[1][0] = 0x7fffffff; s_conv[1][1] = (int)0x80000000; s_conv[1][2] = 0;
+                s_par[0].red[0] = s_par[1].red[0] = (unsigned)__float_as_int(-inf);
+                s_par[0].red[1] = s_par[0].red[2] = s_par[1].red[1] = s_par[1].red[2] = 0u;
+                for (int t = 0; t < 2; ++t) { s_par[t].conv[0] = 0x7fffffff; s_par[t].conv[1] = (int)0x80000000; s_par[t].conv[2] = 0; }
             }
             __syncthreads();
 
             // ---- Tile, TALCO-XDrop.cpp:233-689 ----
-            // bands: diagonal k as (Lk, Uk); diagonal k-1 as (lo1, w1 = width-1), diagonal k-2 as (lo2p = low+1, w2); an empty
-            // band is (0x3fffffff, 0), which no row matches (:296-297 start with L > U for k-1 and k-2)
-            int Lk = 0, Uk = 0, lo1 = 0x3fffffff, lo2p = 0x3fffffff;
-            unsigned w1 = 0, w2 = 0;
-            int wid1 = 0;                                // width of diagonal k-1 (0 when empty): the stale CD slot, see s_cd
+            // The band bookkeeping lives twice: as "uniform vectors" (v*: the same value in every lane, in vector registers, so
+            // that the per-diagonal arithmetic and every lane test run on the four vector units) and, for the few branches, as the
+            // scalars Lk / Uk read back once per diagonal.  Bands: diagonal k as (vL, vU); diagonal k-1 as (vlo1, vw1 = width-1),
+            // diagonal k-2 as (vlo2p = low+1, vw2); an empty band is (0x3fffffff, 0), which no row matches (:296-297 start with
+            // L > U for k-1 and k-2).
+            int vL = 0, vU = 0, vlo1 = 0x3fffffff, vlo2p = 0x3fffffff;
+            unsigned vw1 = 0, vw2 = 0;
+            int vwid1 = 0;                               // width of diagonal k-1 (0 when empty): the stale CD slot, see s_cd
+            unsigned vcells = 0;                         // < 2^32 per tile
+            int Lk = 0, Uk = 0;
             float msp = -inf, convf = 0.0f;              // running maximum (:259), score at convergence (:594)
             bool converged = false;
             int conv_value = 0, prev_conv_s = -1;
             const int kEnd = refLen + qLen - 1;
             int k = 0;
             int tile_err = 0;
-            unsigned tile_cells = 0;                     // < 2^32 per tile
+            bool go = true, conv_logic = false;
             bool spec = true;                            // the next diagonal may be a "special" one (k == 0, or tile 0's first row/column)
             bool tbPending = false;
             unsigned tbOff = (unsigned)lane * 4u;        // byte offset of this lane's word in the current group of 8 diagonals (slot 0)
-            const unsigned redLaneOff = (unsigned)((lane == 63) ? 8 : 4);
-            const bool is63 = (lane == 63);
+            unsigned kk16 = 0u, kkF = 0xFFFFu;           // ((k >> 1) + 1) << 16 and the same + 0xFFFF: the tags of the row reductions
+            // Parity: vcur is the struct of diagonal k, vprev that of k-1; they swap by one xor each per diagonal.
+            constexpr unsigned PARX = (unsigned)sizeof(ParBuf);      // s_par[1] - s_par[0]
+            unsigned vcur = lds_off(&s_par[0]), vprev = lds_off(&s_par[1]);
+            const unsigned parx = lds_off(&s_par[0]) ^ lds_off(&s_par[1]);
+            (void)PARX;
+            // Single-lane LDS side effects without touching EXEC: every lane issues the instruction, the lanes that have nothing
+            // to say aim at their trash slot of the same struct.
+            const unsigned relTrashRed = O_TRASH + (unsigned)lane * 16u - O_RED;     // + O_RED (immediate) = this lane's trash slot
+            unsigned mbRel[RPL], exRel[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int vw = r * W + w;
+                mbRel[r] = (lane == 63) ? O_EXCH + 16u * (unsigned)vw : O_TRASH + (unsigned)lane * 16u;
+                exRel[r] = O_EXCH + 16u * (unsigned)((vw + NV - 1) % NV);
+            }
 
             // One diagonal.  PH: 0 = A (k < marker-1), 1 = B (k == marker-1 or marker), 2 = C (k > marker).
-            // Returns 0 to go on, 1 on a stop condition (tile_err set), 2 when the tile ended by convergence (:609-612).
-            auto step = [&](auto PHtag) -> int {
+            // Ends the loops by clearing `go`: tile_err on a stop condition, conv_logic when the tile ended by convergence (:609-612).
+            auto step = [&](auto PHtag) {
                 constexpr int PH = decltype(PHtag)::value;
                 constexpr bool TB = (PH != 2), CONV = (PH != 0);
+                TWL_STAMP(t_head);
+                if (!(k & 1)) { kk16 += 0x10000u; kkF += 0x10000u; }
                 const int width1 = Uk - Lk;
-                if (__builtin_expect((unsigned)width1 >= (unsigned)fcap, 0)) {
-                    // exact decoding: :323-329 band emptied by X-drop, :331-338 wider than fLen, or it really outgrew this window
-                    if (Lk > Uk) { tile_err = 1; return 1; }
-                    if (width1 + 1 > fLen) { tile_err = 2; return 1; }
-                    if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; return 1; }
-                    // a band this wide can need the successor of a block on the diagonal the block leaves it: advance before the activity test
-#pragma unroll
-                    for (int r = 0; r < RPL; ++r)
-                        if (64 * blk[r] + 63 < Lk) { while (64 * blk[r] + 63 < Lk) blk[r] += NV; ring_addr(r, k); load_q(r); }
-                }
-                tile_cells += (unsigned)(width1 + 1);
-                const int par = k & 1;
+                const unsigned vwidth1 = (unsigned)(vU - vL);
+                vcells += vwidth1 + 1u;
                 const float thr = ((msp > 0.0f) ? msp : 0.0f) - xdropf;        // :495 with :607
                 bool special = false;
                 if (__builtin_expect(spec, 0)) {
@@ -274,25 +324,25 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                     if (__builtin_expect(hiBlk < need_hi, 0)) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
                 }
                 int staleCD = kDB;
-                if constexpr (PH == 2) staleCD = s_cd[par ^ 1][wid1];         // one broadcast read per diagonal
-                const unsigned kk = (unsigned)(k >> 1) + 1u;
+                if constexpr (PH == 2) staleCD = lds_ld<int>(vprev + 4u * (unsigned)vwid1 + O_CD);   // one broadcast read per diagonal
+                const unsigned vTrashRed = vcur + relTrashRed;
+                const int lkm63 = Lk - 63;
+                const unsigned wlim = (unsigned)(width1 + 64);
 
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
-                    const int vw = r * W + w;
                     const int b = 64 * blk[r];
                     // the block takes part when the band touches it or will reach it on the next diagonal (its lane 0 then needs
                     // S[k-1][b-1] now, to have S[k-2][i-1] next time): Lk - 63 <= b <= Uk + 1
-                    const bool act = (unsigned)(b - (Lk - 63)) <= (unsigned)(width1 + 64);
-                    if (act) {
+                    if ((unsigned)(b - lkm63) <= wlim) {
                         const int i = b + lane;
                         // ---- loads: mailbox of the previous block, reference column of this cell ----
                         float eS, eI; int eCS = 0, eCI = 0;
                         if constexpr (CONV) {
-                            const int4 e = s_exch[par ^ 1][(vw + NV - 1) % NV];
+                            const nuc_i4 e = lds_ld<nuc_i4>(vprev + exRel[r]);
                             eS = __int_as_float(e.x); eI = __int_as_float(e.y); eCS = e.z; eCI = e.w;
                         } else {
-                            const int2 e = *reinterpret_cast<const int2 *>(&s_exch[par ^ 1][(vw + NV - 1) % NV]);
+                            const nuc_i2 e = lds_ld<nuc_i2>(vprev + exRel[r]);
                             eS = __int_as_float(e.x); eI = __int_as_float(e.y);
                         }
                         const float4 c0 = lds_ld128(ra[r]);
@@ -329,12 +379,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                                 numer = (l == 0) ? sl : numer + sl;
                             }
                         }
-                        const unsigned long long inbandMask = __builtin_amdgcn_ballot_w64((unsigned)(i - Lk) <= (unsigned)width1);
+                        const bool inband = (unsigned)(i - vL) <= vwidth1;
                         if (q5any[r]) {
 #pragma unroll
                             for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
                         }
-                        if ((inbandMask & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
+                        if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
 #pragma unroll
                             for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
                         }
@@ -346,10 +396,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                         const float LI1 = dpp_shr1_f(eI, I1[r]);
                         int LCS1 = 0, LCI1 = 0;
                         if constexpr (CONV) { LCS1 = dpp_shr1_i(eCS, CS1[r]); LCI1 = dpp_shr1_i(eCI, CI1[r]); }
-                        const unsigned t1 = (unsigned)(i - lo1);
-                        const bool up_ok = t1 <= w1;                      // i   in band(k-1)
-                        const bool left_ok = (t1 - 1u) <= w1;             // i-1 in band(k-1)
-                        const bool diag_ok = (unsigned)(i - lo2p) <= w2;  // i-1 in band(k-2)
+                        const unsigned t1 = (unsigned)(i - vlo1);
+                        const bool up_ok = t1 <= vw1;                      // i   in band(k-1)
+                        const bool left_ok = (t1 - 1u) <= vw1;             // i-1 in band(k-1)
+                        const bool diag_ok = (unsigned)(i - vlo2p) <= vw2; // i-1 in band(k-2)
                         // ---- recurrence, :445-497 ----
                         float match = diag_ok ? LS2[r] + sim : -inf;
                         if (__builtin_expect(special, 0)) {
@@ -376,7 +426,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                         const bool isM = match >= Gv;
                         float Sv = isM ? match : Gv;
                         Sv = (Sv < thr) ? -inf : Sv;                                               // :495-497
-                        const bool inband = (unsigned)(i - Lk) <= (unsigned)width1;
 
                         if constexpr (CONV) {                                                      // :520-547
                             int CSn, CIn, CDn;
@@ -392,29 +441,29 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                                 CSn = isM ? (diag_ok ? LCS2[r] : -1) : viaGap;   // M without a diagonal predecessor: "unset", as in the oracle (:541)
                             }
                             CS1[r] = CSn; CI1[r] = CIn; CD1[r] = CDn;
-                            if (PH == 2 || k == marker) { if (inband) s_cd[par][i - Lk] = CDn; }
+                            if (PH == 2 || k == marker) { if (inband) lds_st<int>(vcur + 4u * (unsigned)(i - vL) + O_CD, CDn); }
                         }
                         S1[r] = Sv; I1[r] = Iv; D1[r] = Dv;
-                        // ---- reductions of this diagonal ----
-                        const unsigned long long vm = inbandMask & __builtin_amdgcn_ballot_w64(Sv > -inf);
-                        if (inband && Sv > msp) lds_max_f32(lds_off(&s_red[par][0]), Sv);         // :501-503
-                        if (vm) {
-                            const unsigned firstRow = (unsigned)(b + (int)__builtin_ctzll(vm));
-                            const unsigned lastRow = (unsigned)(b + 63 - (int)__builtin_clzll(vm));
-                            const unsigned tagF = (kk << 16) | (0xFFFFu - firstRow), tagL = (kk << 16) | lastRow;
-                            if (lane >= 62) lds_max_u32(lds_off(&s_red[par][0]) + redLaneOff, is63 ? tagL : tagF);
-                        }
-                        if (is63) {
-                            if constexpr (CONV) s_exch[par][vw] = make_int4(__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]);
-                            else *reinterpret_cast<int2 *>(&s_exch[par][vw]) = make_int2(__float_as_int(Sv), __float_as_int(Iv));
-                        }
+                        // ---- reductions of this diagonal (:501-503, :563-583), all lanes issuing, see vTrash ----
+                        const float Sin = inband ? Sv : -inf;             // out-of-band lanes take no part
+                        lds_max_f32_off<O_RED>((Sin > msp) ? vcur : vTrashRed, Sin);
+                        const unsigned long long vm = __builtin_amdgcn_ballot_w64(Sin > -inf);
+                        // the first unpruned lane posts the low end, the last one the high end
+                        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                        const int rank = (Sin > -inf) ? below : -2;
+                        const int nValid1 = (int)__builtin_popcountll(vm) - 1;
+                        lds_max_u32_off<O_RED + 4>((rank == 0) ? vcur : vTrashRed, kkF - (unsigned)i);
+                        lds_max_u32_off<O_RED + 8>((rank == nValid1) ? vcur : vTrashRed, kk16 + (unsigned)i);
+                        if constexpr (CONV) lds_st<nuc_i4>(vcur + mbRel[r], nuc_i4{__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]});
+                        else lds_st<nuc_i2>(vcur + mbRel[r], nuc_i2{__float_as_int(Sv), __float_as_int(Iv)});
                         if constexpr (TB) {                                                        // :548-557
                             const uint32_t nib = (isM ? 0u : (gapIsI ? 1u : 2u)) | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
                             tbacc[r] |= nib << (4 * (k & 7));
                         }
                         LS2[r] = LS1;
                         if constexpr (CONV) LCS2[r] = LCS1;
-                    } else if (b + 63 < Lk) {                  // block fell out of the band: take the next one
+                    }
+                    if (__builtin_expect(b + 63 < Lk, 0)) {    // block fell out of the band: take the next one
                         while (64 * blk[r] + 63 < Lk) blk[r] += NV;
                         ring_addr(r, k);
                         load_q(r);
@@ -434,82 +483,109 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                         tbPending = false;
                     }
                 }
-                __syncthreads();
+                TWL_STAMP(t_slots);
+                wg_barrier_lds();
+                TWL_STAMP(t_bar);
 
                 // ---- post: the band of the next diagonal, :563-604 ----
-                const uint4 rd = *reinterpret_cast<const uint4 *>(&s_red[par][0]);
-                { const float g = __uint_as_float(rd.x); msp = (g > msp) ? g : msp; }
-                const unsigned tF = (unsigned)__builtin_amdgcn_readfirstlane((int)rd.y), tL = (unsigned)__builtin_amdgcn_readfirstlane((int)rd.z);
-                const bool anyValid = (tL >> 16) == kk;
-                const int newL = anyValid ? (int)(0xFFFFu - (tF & 0xFFFFu)) : Uk + 1;
-                const int newU = anyValid ? (int)(tL & 0xFFFFu) : Lk - 1;
+                // {running max, low-end tag, high-end tag}: a tag from an older diagonal is smaller than this diagonal's, so when no
+                // row survived the differences below come out as newU <= -1 and newL >= 65536: an empty band, caught by the next test
+                const nuc_i4 rd = lds_ld<nuc_i4>(vcur + O_RED);
+                { const float g = __int_as_float(rd.x); msp = (g > msp) ? g : msp; }
+                const int newL = (int)(kkF - (unsigned)rd.y);
+                const int newU = (int)((unsigned)rd.z - kk16);
 
                 if constexpr (CONV) {                                                              // :585-595
                     if (!converged && k < kEnd - 1) {
                         int conv_S = -1;
                         bool all3 = false;
                         if constexpr (PH == 1) {
-                            if (k == marker - 1) conv_S = (newL == newU) ? ((3 << 16) | (newL & 0xFFFF)) : -1;
-                            else conv_S = (newL == newU) ? (newL & 0xFFFF) : -1;
+                            const int sL = __builtin_amdgcn_readfirstlane(newL), sU = __builtin_amdgcn_readfirstlane(newU);
+                            if (k == marker - 1) conv_S = (sL == sU) ? ((3 << 16) | (sL & 0xFFFF)) : -1;
+                            else conv_S = (sL == sU) ? (sL & 0xFFFF) : -1;
                         } else {
-                            if (threadIdx.x == 0) { s_conv[par ^ 1][0] = 0x7fffffff; s_conv[par ^ 1][1] = (int)0x80000000; s_conv[par ^ 1][2] = 0; }
+                            if (threadIdx.x == 0) lds_st<nuc_i4>(vprev + O_CONV, nuc_i4{0x7fffffff, (int)0x80000000, 0, 0});
+                            const unsigned cw = (unsigned)(newU - newL);
 #pragma unroll
                             for (int r = 0; r < RPL; ++r) {
-                                const int b = 64 * blk[r];
-                                if (b <= newU && b + 63 >= newL) {
-                                    const int i = b + lane;
-                                    const bool inr = (i >= newL) && (i <= newU);
-                                    const unsigned long long rm = __builtin_amdgcn_ballot_w64(inr);
-                                    if (rm) {
-                                        const int fl = (int)__builtin_ctzll(rm);
-                                        const int v = __builtin_amdgcn_readlane(CS1[r], fl);
-                                        const bool badS = __builtin_amdgcn_ballot_w64(inr && CS1[r] != v) != 0ull;
-                                        const bool badID = __builtin_amdgcn_ballot_w64(inr && (CI1[r] != v || CD1[r] != v)) != 0ull;
-                                        if (lane == 0) {
-                                            lds_min_i32(&s_conv[par][0], v);
-                                            lds_max_i32(&s_conv[par][1], v);
-                                            if (badS || badID) lds_or_b32(&s_conv[par][2], (badS ? 1 : 0) | (badID ? 2 : 0));
-                                        }
+                                const int i = 64 * blk[r] + lane;
+                                const bool inr = (unsigned)(i - newL) <= cw;      // (no lane when the band is empty: both differences negative)
+                                const unsigned long long rm = __builtin_amdgcn_ballot_w64(inr);
+                                if (rm) {
+                                    const int fl = (int)__builtin_ctzll(rm);
+                                    const int v = __builtin_amdgcn_readlane(CS1[r], fl);
+                                    const bool badS = __builtin_amdgcn_ballot_w64(inr && CS1[r] != v) != 0ull;
+                                    const bool badID = __builtin_amdgcn_ballot_w64(inr && (CI1[r] != v || CD1[r] != v)) != 0ull;
+                                    if (lane == 0) {
+                                        ds_min_i32_off<O_CONV>(vcur, v);
+                                        ds_max_i32_off<O_CONV + 4>(vcur, v);
+                                        if (badS || badID) ds_or_b32_off<O_CONV + 8>(vcur, (badS ? 1 : 0) | (badID ? 2 : 0));
                                     }
                                 }
                             }
-                            __syncthreads();
-                            const int vmin = __builtin_amdgcn_readfirstlane(s_conv[par][0]);
-                            const int vmax = __builtin_amdgcn_readfirstlane(s_conv[par][1]);
-                            const int fl = __builtin_amdgcn_readfirstlane(s_conv[par][2]);
-                            if (newU >= newL && vmin == vmax && !(fl & 1)) { conv_S = vmin; all3 = !(fl & 2); }
+                            wg_barrier_lds();
+                            const nuc_i4 cv = lds_ld<nuc_i4>(vcur + O_CONV);
+                            const int vmin = __builtin_amdgcn_readfirstlane(cv.x);
+                            const int vmax = __builtin_amdgcn_readfirstlane(cv.y);
+                            const int fl = __builtin_amdgcn_readfirstlane(cv.z);
+                            if (vmin == vmax && !(fl & 1)) { conv_S = vmin; all3 = !(fl & 2); }   // (an empty band posts nothing: vmin > vmax)
                         }
                         if (all3 && prev_conv_s == conv_S && conv_S != -1) { converged = true; conv_value = prev_conv_s; convf = msp; }
                         prev_conv_s = conv_S;
                     }
                 }
                 {                                                                                  // :597-604
-                    const int Lprime = max(k + 2 - refLen, 0);
-                    lo2p = lo1 + 1; w2 = w1;                   // (an empty band keeps an unreachable low)
-                    lo1 = Lk; w1 = (unsigned)width1; wid1 = width1 + 1;
-                    Lk = max(newL, Lprime);
-                    Uk = min(qLen - 1, newU + 1);
+                    vlo2p = vlo1 + 1; vw2 = vw1;                // (an empty band keeps an unreachable low)
+                    vlo1 = vL; vw1 = vwidth1; vwid1 = (int)vwidth1 + 1;
+                    vL = max(max(newL, k + 2 - refLen), 0);
+                    vU = min(newU + 1, qLen - 1);
+                    Lk = __builtin_amdgcn_readfirstlane(vL);
+                    Uk = __builtin_amdgcn_readfirstlane(vU);
+                    vcur ^= parx; vprev ^= parx;
                 }
+#ifdef TWL_KERNEL_STAMPS
+                {
+                    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+                    st_slots += t_slots - t_head; st_bar += t_bar - t_slots; st_post += t_end - t_bar; st_n += 1;
+                    st_act += (64 * blk[0] <= Uk + 1 && 64 * blk[0] + 63 >= Lk) ? 1 : 0;
+                }
+#endif
+                bool ended = false;
                 if constexpr (CONV) {
                     if (converged) {                                                               // :607-612: max(0, max') > score at convergence
-                        if (__builtin_amdgcn_ballot_w64(((msp > 0.0f) ? msp : 0.0f) > convf) != 0ull) return 2;
+                        if (__builtin_amdgcn_ballot_w64(((msp > 0.0f) ? msp : 0.0f) > convf) != 0ull) { conv_logic = true; go = false; ended = true; }
                     }
                 }
-                return 0;
+                if (!ended) {
+                    ++k;
+                    // stop conditions of the next diagonal (the reference tests them at its top, :323-338; not after the last one)
+                    if (__builtin_expect((unsigned)(Uk - Lk) >= (unsigned)fcap && k < kEnd, 0)) {
+                        if (Lk > Uk) { tile_err = 1; go = false; }                                  // band emptied by X-drop
+                        else if (Uk - Lk + 1 > fLen) { tile_err = 2; go = false; }                  // wider than fLen
+                        else if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; go = false; }   // it really outgrew this window
+                        else {
+                            // a band this wide can need the successor of a block on the diagonal the block leaves it: advance before the activity test
+#pragma unroll
+                            for (int r = 0; r < RPL; ++r)
+                                if (64 * blk[r] + 63 < Lk) { while (64 * blk[r] + 63 < Lk) blk[r] += NV; ring_addr(r, k); load_q(r); }
+                        }
+                    }
+                }
             };
 
-            int brk = 0;
-            if (steps_left < 0) { tile_err = 3; brk = 1; }
+            if (steps_left < 0) { tile_err = 3; go = false; }
             {
+                using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
                 const int kA = min(kEnd, marker - 1);
-                for (; !brk && k < kA; ++k) { brk = step(std::integral_constant<int, 0>{}); if (brk) break; }
+                while (go && k < kA) step(T0{});
                 const int kB = min(kEnd, marker + 1);
-                if (!brk) for (; k < kB; ++k) { brk = step(std::integral_constant<int, 1>{}); if (brk) break; }
-                if (!brk) for (; k < kEnd; ++k) { brk = step(std::integral_constant<int, 2>{}); if (brk) break; }
+                while (go && k < kB) step(T1{});
+                while (go && k < kEnd) step(T2{});
             }
-            const bool conv_logic = (brk == 2);
             const int last_k = conv_logic ? k : k - 1;
             steps_left -= (long long)(last_k + 1);
+            const unsigned tile_cells = (unsigned)__builtin_amdgcn_readfirstlane((int)vcells);
+            const int lo1 = __builtin_amdgcn_readfirstlane(vlo1);
 
             cells += tile_cells;
             dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
@@ -605,6 +681,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             ++tile;
         }
 
+#ifdef TWL_KERNEL_STAMPS
+        if (a.dbg && lane == 0 && pair == 0) {      // per wave of the workgroup that aligned pair 0: cycle sums per segment
+            long long *g = reinterpret_cast<long long *>(a.dbg + 16 * (size_t)a.n_pairs_total) + 8 * w;
+            g[0] = (long long)st_slots; g[1] = (long long)st_bar; g[2] = (long long)st_post; g[3] = (long long)st_n; g[4] = (long long)st_act;
+            g[5] = (long long)(__builtin_amdgcn_s_memtime() - st_t0);
+            g[6] = (long long)st_exit; g[7] = (long long)st_setup;
+        }
+#endif
         __syncthreads();
         if (threadIdx.x == 0) {
             a.err[pair] = (int16_t)err;

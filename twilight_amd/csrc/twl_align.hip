@@ -246,7 +246,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     const bool want_dbg = getenv("TWL_DEBUG") != nullptr;
     a.dbg = nullptr;
     if (want_dbg) {
-        if ((rc = d->dbg.ensure((size_t)n_pairs * 16 * sizeof(int32_t) + 1024))) return rc;     // per-pair records, then 1 KB for the stamp build
+        if ((rc = d->dbg.ensure((size_t)n_pairs * 16 * sizeof(int32_t) + 2048))) return rc;     // per-pair records, then 1 KB for the stamp build
         HIP_TRY(hipMemsetAsync(d->dbg.p, 0xff, (size_t)n_pairs * 16 * sizeof(int32_t), st));
         a.dbg = (int32_t *)d->dbg.p;
     }
@@ -311,7 +311,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             }
         }
     }
-    else if (c == "w8r2" || c == "nuc" || c == "nuc16") {
+    else if (c == "w8r2" || c == "nuc" || c == "nuc16" || c == "nuc8") {
         // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
         const float *M = a.M;
         bool nz = true, st3 = true;
@@ -328,7 +328,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         divOk = divOk && inRange(p->gap_char);
         const bool lean = (c != "w8r2") && divOk;
         // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
-        const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu);
+        const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu && !getenv("TWL_NO_FEW"));
         if (lean && few) {
             if (mm == 2) rc = launch_nuc<16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
             else if (mm == 1) rc = launch_nuc<16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
