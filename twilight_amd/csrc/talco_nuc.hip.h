@@ -177,8 +177,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
         bool last_tile = (R <= 0 || Q <= 0);
         unsigned long long cells = 0;
         long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
-        // the row tags of the reductions hold (k >> 1) + 1 in 16 bits and a row in 16 bits
-        if (!last_tile && (R + Q > 130000 || Q > 65000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
+        // the row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits
+        if (!last_tile && (R + Q > 65000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
         bool guardBad = false;
 #ifdef TWL_KERNEL_STAMPS
@@ -251,7 +251,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 ring_addr(r, 0);
                 tbacc[r] = 0;
                 S1[r] = I1[r] = D1[r] = LS2[r] = -1.0f;       // never read before written for in-band cells
-                CS1[r] = -1; CI1[r] = kIB; CD1[r] = kDB; LCS2[r] = -1;
                 load_q(r);
             }
             int hiBlk = 1;
@@ -286,7 +285,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             bool spec = true;                            // the next diagonal may be a "special" one (k == 0, or tile 0's first row/column)
             bool tbPending = false;
             unsigned tbOff = (unsigned)lane * 4u;        // byte offset of this lane's word in the current group of 8 diagonals (slot 0)
-            unsigned kk16 = 0u, kkF = 0xFFFFu;           // ((k >> 1) + 1) << 16 and the same + 0xFFFF: the tags of the row reductions
             // Parity: vcur is the struct of diagonal k, vprev that of k-1; they swap by one xor each per diagonal.
             constexpr unsigned PARX = (unsigned)sizeof(ParBuf);      // s_par[1] - s_par[0]
             unsigned vcur = lds_off(&s_par[0]), vprev = lds_off(&s_par[1]);
@@ -309,19 +307,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 constexpr int PH = decltype(PHtag)::value;
                 constexpr bool TB = (PH != 2), CONV = (PH != 0);
                 TWL_STAMP(t_head);
-                if (!(k & 1)) { kk16 += 0x10000u; kkF += 0x10000u; }
+                const unsigned kk16 = (unsigned)(k + 1) << 16;                // tag of this diagonal's row reductions (k + 1 <= 65535)
                 const int width1 = Uk - Lk;
                 const unsigned vwidth1 = (unsigned)(vU - vL);
                 vcells += vwidth1 + 1u;
-                const float thr = ((msp > 0.0f) ? msp : 0.0f) - xdropf;        // :495 with :607
+                const float thr = __int_as_float(max(__float_as_int(msp), 0)) - xdropf;   // :495 with :607 (max(x, 0) of a float is max of its bits as an integer)
                 bool special = false;
                 if (__builtin_expect(spec, 0)) {
                     special = (k == 0) | ((tile == 0) && (Lk == 0 || Uk == k));
                     spec = special;                                          // both conditions are monotone: once false, false for the tile
-                }
-                {
-                    const int need_hi = ((k - Lk) >> 6) + 1;
-                    if (__builtin_expect(hiBlk < need_hi, 0)) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
                 }
                 int staleCD = kDB;
                 if constexpr (PH == 2) staleCD = lds_ld<int>(vprev + 4u * (unsigned)vwid1 + O_CD);   // one broadcast read per diagonal
@@ -452,7 +446,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                         const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
                         const int rank = (Sin > -inf) ? below : -2;
                         const int nValid1 = (int)__builtin_popcountll(vm) - 1;
-                        lds_max_u32_off<O_RED + 4>((rank == 0) ? vcur : vTrashRed, kkF - (unsigned)i);
+                        lds_max_u32_off<O_RED + 4>((rank == 0) ? vcur : vTrashRed, kk16 + (0xFFFFu - (unsigned)i));
                         lds_max_u32_off<O_RED + 8>((rank == nValid1) ? vcur : vTrashRed, kk16 + (unsigned)i);
                         if constexpr (CONV) lds_st<nuc_i4>(vcur + mbRel[r], nuc_i4{__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]});
                         else lds_st<nuc_i2>(vcur + mbRel[r], nuc_i2{__float_as_int(Sv), __float_as_int(Iv)});
@@ -471,9 +465,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                     ra[r] += 16u;
                     if (ra[r] == lds_off(s_ring) + CAP * 16u) ra[r] = lds_off(s_ring);
                 }
-                if constexpr (TB) {
-                    tbPending = true;
-                    if ((k & 7) == 7 || (PH == 1 && k == marker)) {
+                if constexpr (TB) tbPending = true;
+                if ((k & 7) == 7 || (PH == 1 && k == marker)) {
+                    if constexpr (TB) {
 #pragma unroll
                         for (int r = 0; r < RPL; ++r) {
                             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
@@ -482,6 +476,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                         tbOff += (unsigned)WINDOW * 4u;
                         tbPending = false;
                     }
+                    // every 8th diagonal: stage the next 64 reference columns when the band gets within 8 + 64 columns of them (the ring has
+                    // two blocks more than the window, so a block loaded this early never overwrites one still in use)
+                    const int need_hi = ((k + 9 - Lk) >> 6) + 1;
+                    if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
                 }
                 TWL_STAMP(t_slots);
                 wg_barrier_lds();
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 // row survived the differences below come out as newU <= -1 and newL >= 65536: an empty band, caught by the next test
                 const nuc_i4 rd = lds_ld<nuc_i4>(vcur + O_RED);
                 { const float g = __int_as_float(rd.x); msp = (g > msp) ? g : msp; }
-                const int newL = (int)(kkF - (unsigned)rd.y);
+                const int newL = (int)((kk16 + 0xFFFFu) - (unsigned)rd.y);
                 const int newU = (int)((unsigned)rd.z - kk16);
 
                 if constexpr (CONV) {                                                              // :585-595
@@ -553,14 +551,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 bool ended = false;
                 if constexpr (CONV) {
                     if (converged) {                                                               // :607-612: max(0, max') > score at convergence
-                        if (__builtin_amdgcn_ballot_w64(((msp > 0.0f) ? msp : 0.0f) > convf) != 0ull) { conv_logic = true; go = false; ended = true; }
+                        if (__builtin_amdgcn_ballot_w64(__int_as_float(max(__float_as_int(msp), 0)) > convf) != 0ull) { conv_logic = true; go = false; ended = true; }
                     }
                 }
                 if (!ended) {
                     ++k;
                     // stop conditions of the next diagonal (the reference tests them at its top, :323-338; not after the last one)
-                    if (__builtin_expect((unsigned)(Uk - Lk) >= (unsigned)fcap && k < kEnd, 0)) {
-                        if (Lk > Uk) { tile_err = 1; go = false; }                                  // band emptied by X-drop
+                    if (__builtin_expect((unsigned)(Uk - Lk) >= (unsigned)fcap, 0)) {
+                        if (k >= kEnd) {}                                                            // (that was the last diagonal)
+                        else if (Lk > Uk) { tile_err = 1; go = false; }                                  // band emptied by X-drop
                         else if (Uk - Lk + 1 > fLen) { tile_err = 2; go = false; }                  // wider than fLen
                         else if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; go = false; }   // it really outgrew this window
                         else {
@@ -579,6 +578,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 const int kA = min(kEnd, marker - 1);
                 while (go && k < kA) step(T0{});
                 const int kB = min(kEnd, marker + 1);
+                // (set here rather than with the tile: through phase A these are constants, not live registers; :306-308)
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) { CS1[r] = -1; CI1[r] = kIB; CD1[r] = kDB; LCS2[r] = -1; }
                 while (go && k < kB) step(T1{});
                 while (go && k < kEnd) step(T2{});
             }
