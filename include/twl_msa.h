@@ -1,0 +1,67 @@
+/*
+ * include/twl_msa.h -- C ABI of libtwl_host: TWILIGHT's tree + sequences alignment flow with the MI355X level kernel.
+ *
+ * libtwl_align (twl_align.h / twl_level.h) replaces the reference's per-level DP; this header exposes the CALLER of that path --
+ * the host flow of /root/reference/src/twilight-main.cpp:115-176 (DEFAULT_ALN, single partition): read the guide tree and the
+ * sequences, msa::progressive::msaOnSubtree (progressive.cpp:232-299) over the level schedule with the GPU level kernel injected
+ * as msa::alnFunction (msa.hpp:175), write the MSA -- in steps, so that a caller can keep the inputs resident in HBM, time the
+ * alignment alone, repeat it on fresh handles, and run it on several processes (one per GPU) that align ONE family together.
+ * The product CLI `twilight-mi355x` is this same flow in one go.
+ *
+ * Plain C types only.  Functions return 0 or a negative code; twl_msa_last_error() describes the failure.  Errors the
+ * reference treats as fatal (unsupported flags, unreadable files, inconsistent trees) end the process with a message, as there.
+ */
+#ifndef TWL_MSA_H
+#define TWL_MSA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct twl_msa twl_msa;
+
+/* One level-kernel call (= one line of the reference's per-level report, progressive.cpp:178-189). */
+typedef struct twl_msa_level {
+    int32_t  pairs;         /* sibling pairs of the level */
+    int32_t  task;          /* 0 main pass, 1 deferred pass */
+    uint64_t band_cells;    /* DP band cells of the level, all ranks */
+    uint64_t relaunched;    /* pairs re-run in a wider window */
+    double   kernel_ms;     /* DP kernel time (HIP events; max over the ranks / devices that ran concurrently) */
+    double   level_ms;      /* host wall time of the level-kernel call */
+    double   exchange_ms;   /* of which: all-gather of the paths between processes */
+} twl_msa_level;
+
+typedef struct twl_msa_totals {
+    int32_t  n_levels, aln_len, n_sequences, reserved;
+    uint64_t pairs, band_cells, relaunched;
+    double   kernel_ms, exchange_ms, align_s;
+} twl_msa_totals;
+
+/* All-gather of equal-sized host blocks between the processes of a sharded run: send = this rank's block of bytes_per_rank
+   bytes, recv = [world][bytes_per_rank].  Returns 0 on success. */
+typedef int (*twl_msa_exchange_fn)(void *user, const void *send, int64_t bytes_per_rank, void *recv);
+
+/* argv: the flags of the CLI (-t tree -i sequences -o output [-r ...] [--type n|p] [--gpu-index k] ...; argv[0] is ignored).
+   Parses the options, reads the tree and the sequences, builds nothing on the device yet. */
+int  twl_msa_open(int argc, const char *const *argv, twl_msa **out);
+/* Several processes, one GPU each, align this family together: every process opens the same inputs, aligns the pairs dealt to
+   `rank` and gets the others' paths through `exchange` once per level (twilight_amd/dist.py: torch.distributed all_gather, backend
+   nccl = RCCL over xGMI on GPUs, gloo in CPU tests).  Call before twl_msa_align; world == 1 is the default. */
+int  twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange, void *user);
+/* Device-resident path: put the sequences into HBM now (otherwise the first level does it). */
+int  twl_msa_upload(twl_msa *m);
+/* The progressive alignment: every level of the main pass and the deferred pass. */
+int  twl_msa_align(twl_msa *m);
+/* Totals and the per-level records of the run (levels may be NULL; at most max_levels records are written). */
+int  twl_msa_report(twl_msa *m, twl_msa_totals *totals, twl_msa_level *levels, int32_t max_levels);
+/* Write the MSA (path NULL: the -o of twl_msa_open), FASTA as the reference writes it (io.cpp:512-525). */
+int  twl_msa_write(twl_msa *m, const char *path);
+void twl_msa_close(twl_msa *m);
+const char *twl_msa_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

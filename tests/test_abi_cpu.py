@@ -36,6 +36,19 @@ def test_level_header_symbols_are_exported(built):
     assert C.sizeof(level.TwlSide) == 8 * 4
 
 
+def test_host_library_header_symbols_are_exported(built):
+    """libtwl_host.so (include/twl_msa.h): the caller of the hot path as a C ABI; loads without a GPU and exports every entry point."""
+    from twilight_amd import msa
+
+    lib = msa.load_library()
+    declared = _declared_symbols("twl_msa.h")
+    assert set(declared) == set(msa.exported_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    assert C.sizeof(msa.MsaLevel) == 2 * 4 + 2 * 8 + 3 * 8
+    assert C.sizeof(msa.MsaTotals) == 4 * 4 + 3 * 8 + 3 * 8
+
+
 def test_struct_layouts_match_header(built):
     import twilight_amd as twl
 

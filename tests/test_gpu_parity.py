@@ -276,3 +276,15 @@ def test_long_pairs_100k(gpu):
     batch = synth.make_level_batch(2, 100000, members=((1, 3), (1, 3)), seed=77)
     st, ost = _compare(gpu, batch)
     assert ost.cells > 5e7
+
+
+def test_retry_parameters_beyond_flen_4096(gpu):
+    """The deferred pass retries with xdrop *= 2 and fLen = min((xdrop * 4) << 1, min(R, Q)) (alignment-cpu.cpp:124-128): on profiles of
+    more than 4096 columns that is an fLen above the default cap.  fLen only caps the anti-diagonal width, so the kernels must take it."""
+    batch = synth.make_level_batch(4, 6400, members=((1, 4), (1, 4)), seed=77, sub=0.2, indel=0.02)
+    minlen = int(batch.len.min())
+    assert minlen > 4096
+    st, ost = _compare(gpu, batch, xdrop=10000, flen=minlen)
+    assert ost.max_width > 500
+    # errorType 2 -> fLen = min(int(fLen * 1.2) << 1, min(R, Q)) (:116-119): 9830 for 10 kbp inputs; here capped by the lengths
+    _compare(gpu, batch, flen=min(int(4096 * 1.2) << 1, minlen))

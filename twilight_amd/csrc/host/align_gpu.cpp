@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <future>
 #include <iostream>
 #include <map>
@@ -22,6 +23,93 @@ namespace gpu {
 
 LevelTotals g_totals;
 static std::vector<int> g_devices;
+
+RunCtx::~RunCtx()
+{
+    for (twl_store *st : stores) twl_store_destroy(st);
+}
+RunCtx &ctxOf(SequenceDB *database)
+{
+    if (!database->gpuCtx) {
+        database->gpuCtx = new RunCtx();
+        database->gpuCtxFree = [](void *p) { delete static_cast<RunCtx *>(p); };
+    }
+    return *static_cast<RunCtx *>(database->gpuCtx);
+}
+void setShard(SequenceDB *database, const Shard &shard) { ctxOf(database).shard = shard; }
+const std::vector<LevelRecord> &levelRecords(SequenceDB *database) { return ctxOf(database).levels; }
+const LevelTotals &runTotals(SequenceDB *database) { return ctxOf(database).totals; }
+
+std::vector<int> dealPairs(const std::vector<long long> &cost, const std::vector<char> &takesPart, int parts)
+{
+    const int n = (int)cost.size();
+    std::vector<int> owner(n, 0);
+    if (parts <= 1) return owner;
+    std::vector<int> order;
+    for (int i = 0; i < n; ++i) if (takesPart[i]) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+    std::vector<long long> load(parts, 0);
+    for (int i : order) {
+        const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        owner[i] = d;
+        load[d] += std::max<long long>(cost[i], 1);
+    }
+    return owner;
+}
+
+// Block layout per rank: header {band cells u64, relaunched u64, kernel ms f64, reserved} then, for the rank's pairs in ascending
+// order, {path length i32, errorType i32, path bytes padded to pathCap}.  Every rank knows every rank's pair list (the deal is
+// deterministic), so only the blocks travel.
+void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector<char> &takesPart, int pathCap, std::vector<alnPath> &paths,
+                   std::vector<int16_t> &errs, LevelRecord &rec)
+{
+    const Shard &sh = ctx.shard;
+    if (!sh.exchange) {          // (a 1-rank "world" with an exchange function still goes through it: lets one GPU cover the collective)
+        if (sh.world > 1) { std::cerr << "ERROR: sharded run without an exchange function.\n"; exit(1); }
+        return;
+    }
+    const double t0 = nowMs();
+    const int n = (int)owner.size();
+    std::vector<std::vector<int>> mine(sh.world);
+    for (int i = 0; i < n; ++i) if (takesPart[i]) mine[owner[i]].push_back(i);
+    size_t maxOwn = 0;
+    for (auto &v : mine) maxOwn = std::max(maxOwn, v.size());
+    const size_t rowBytes = 8 + (size_t)((pathCap + 7) & ~7), head = 32;
+    const size_t blockBytes = head + maxOwn * rowBytes;
+    std::vector<char> send(blockBytes, 0), recv(blockBytes * (size_t)sh.world, 0);
+    {
+        uint64_t h[4] = {rec.band_cells, rec.relaunched, 0, 0};
+        memcpy(&h[2], &rec.kernel_ms, sizeof(double));
+        memcpy(send.data(), h, sizeof h);
+        size_t at = head;
+        for (int i : mine[sh.rank]) {
+            const int32_t len = (int32_t)paths[i].size(), e = errs[i];
+            if (len > pathCap) { std::cerr << "ERROR: path longer than the exchange row.\n"; exit(1); }
+            memcpy(&send[at], &len, 4); memcpy(&send[at + 4], &e, 4);
+            if (len) memcpy(&send[at + 8], paths[i].data(), (size_t)len);
+            at += rowBytes;
+        }
+    }
+    const int rc = sh.exchange(sh.user, send.data(), (int64_t)blockBytes, recv.data());
+    if (rc != 0) { std::cerr << "ERROR: exchange of the level's paths failed (" << rc << ").\n"; exit(1); }
+    rec.band_cells = 0; rec.relaunched = 0;
+    double kmax = 0;
+    for (int r = 0; r < sh.world; ++r) {
+        const char *blk = &recv[blockBytes * (size_t)r];
+        uint64_t h[4]; memcpy(h, blk, sizeof h);
+        double km; memcpy(&km, &h[2], sizeof(double));
+        rec.band_cells += h[0]; rec.relaunched += h[1]; kmax = std::max(kmax, km);      // the ranks ran concurrently
+        size_t at = head;
+        for (int i : mine[r]) {
+            int32_t len, e; memcpy(&len, blk + at, 4); memcpy(&e, blk + at + 4, 4);
+            if (r != sh.rank) { errs[i] = (int16_t)e; paths[i].assign(blk + at + 8, blk + at + 8 + len); }
+            at += rowBytes;
+        }
+    }
+    rec.kernel_ms = kmax;
+    rec.exchange_ms += nowMs() - t0;
+}
+
 const std::vector<int> &selectedDevices() { return g_devices; }
 
 static std::future<std::pair<int, std::string>> g_initJob;   // (return code, twl_last_error() of the helper thread)
@@ -90,7 +178,7 @@ static Staging g_stage;
 // Align the pairs `ids` (ascending indices into the level's slots) with one parameter set; results land in paths/errs.  The
 // call covers the slot span [ids.front(), ids.back()]; slots in the span that are not in `ids` are passed with length 0, which the
 // boundary answers with aln_len 0 without running them.
-static void runBatch(const twl_params &tp, const std::vector<int> &ids, const std::vector<PairInputs> &in, int P, int stride,
+static void runBatch(RunCtx &ctx, LevelRecord &rec, const twl_params &tp, const std::vector<int> &ids, const std::vector<PairInputs> &in, int P, int stride,
                      std::vector<alnPath> &paths, std::vector<int16_t> &errs)
 {
     if (ids.empty()) return;
@@ -111,11 +199,13 @@ static void runBatch(const twl_params &tp, const std::vector<int> &ids, const st
                              g_stage.gex + (size_t)first * 2 * sl, len.data(), num.data(), aln, alnLen.data(), err.data());
     if (rc != TWL_OK) { std::cerr << "ERROR: twl_align_batch failed (" << rc << "): " << twl_last_error() << '\n'; exit(1); }
     g_totals.call_ms += nowMs() - tCall;
-    for (int dev : g_devices) {
+    double kms = 0, tms = 0;
+    for (int dev : g_devices) {      // the devices of one call run concurrently: cells add up, times do not
         twl_stats st{};
-        if (twl_get_stats(dev, &st) == TWL_OK) { g_totals.band_cells += st.band_cells; g_totals.relaunched += (uint64_t)st.n_relaunched; g_totals.kernel_ms += st.kernel_ms; g_totals.total_ms += st.total_ms; }
+        if (twl_get_stats(dev, &st) == TWL_OK) { rec.band_cells += st.band_cells; rec.relaunched += (uint64_t)st.n_relaunched; kms = std::max(kms, st.kernel_ms); tms = std::max(tms, st.total_ms); }
     }
-    g_totals.pairs += ids.size();
+    rec.kernel_ms += kms;
+    g_totals.total_ms += tms; ctx.totals.total_ms += tms;
     for (int id : ids) {
         const int t = id - first;
         errs[id] = err[t];
@@ -127,6 +217,10 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
 {
     if (option->cpuOnly) { std::cerr << "ERROR: --cpu-only is not available: this build has no CPU alignment path.\n"; exit(1); }
     ensureInit(option);
+    RunCtx &ctx = ctxOf(database);
+    LevelRecord rec;
+    rec.pairs = (int32_t)nodes.size();
+    rec.task = database->currentTask;
     const int n = (int)nodes.size();
     const int P = param.matrixSize + 1;
     std::vector<PairInputs> in(n);
@@ -147,37 +241,51 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
 
     std::vector<alnPath> paths(n);
     std::vector<int16_t> errs(n, 0);
-    // pairs that go to the DP, grouped by gapCharScore (alignment-cpu.cpp:88)
-    std::vector<int> plain, zeroGap;
+    // pairs that go to the DP, grouped by gapCharScore (alignment-cpu.cpp:88); with several processes each aligns the pairs dealt to it
+    std::vector<char> takesPart(n, 0);
+    std::vector<long long> cost(n, 0);
     for (int i = 0; i < n; ++i) {
         if (in[i].refLen == 0) paths[i].assign(in[i].qryLen, 1);                              // :89-90
         if (in[i].qryLen == 0) paths[i].insert(paths[i].end(), in[i].refLen, 2);
         if (!paths[i].empty() || in[i].lowQ_r || in[i].lowQ_q) continue;                       // :93,95
-        const bool zg = (database->currentTask == 1 || database->currentTask == 2 || in[i].refNum > 10000 || in[i].qryNum > 10000);
-        (zg ? zeroGap : plain).push_back(i);
+        takesPart[i] = 1;
+        cost[i] = (long long)in[i].lens.first + in[i].lens.second;
     }
+    const std::vector<int> owner = dealPairs(cost, takesPart, ctx.shard.world);
+    std::vector<int> plain, zeroGap;
+    auto zeroGapPair = [&](int i) { return database->currentTask == 1 || database->currentTask == 2 || in[i].refNum > 10000 || in[i].qryNum > 10000; };
+    for (int i = 0; i < n; ++i)
+        if (takesPart[i] && owner[i] == ctx.shard.rank) (zeroGapPair(i) ? zeroGap : plain).push_back(i);
     twl_params tp = baseParams(param);
-    runBatch(tp, plain, in, P, stride, paths, errs);
+    runBatch(ctx, rec, tp, plain, in, P, stride, paths, errs);
     twl_params tz = tp;
     tz.gap_char = 0;
-    runBatch(tz, zeroGap, in, P, stride, paths, errs);
+    runBatch(ctx, rec, tz, zeroGap, in, P, stride, paths, errs);
 
-    // alignment-cpu.cpp:108-129: task 0 defers a failed pair; later tasks retry with a larger X-drop / band limit
+    // alignment-cpu.cpp:116-129: in the later tasks a failed pair is retried with a larger X-drop / band limit (by the rank that owns it)
+    if (database->currentTask != 0) {
+        for (int i = 0; i < n; ++i) {
+            if (!takesPart[i] || owner[i] != ctx.shard.rank || errs[i] == 0) continue;
+            twl_params tr = zeroGapPair(i) ? tz : tp;
+            const int minLen = std::min(in[i].lens.first, in[i].lens.second);
+            while (errs[i] != 0) {
+                if (errs[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
+                if (errs[i] == 2) tr.flen = std::min(static_cast<int32_t>(tr.flen * 1.2) << 1, minLen);
+                else { tr.xdrop = static_cast<int32_t>(tr.xdrop * 2); tr.flen = std::min(static_cast<int32_t>(tr.xdrop * 4) << 1, minLen); }
+                if (option->printDetail) std::cout << "Retry pair No. " << i << "\txdrop " << tr.xdrop << " flen " << tr.flen << '\n';
+                runBatch(ctx, rec, tr, std::vector<int>{i}, in, P, stride, paths, errs);
+            }
+        }
+    }
+    exchangePaths(ctx, owner, takesPart, 2 * stride, paths, errs, rec);
+
+    // alignment-cpu.cpp:108-115: task 0 defers a failed pair
     std::vector<int> fallbackPairs;
     for (int i = 0; i < n; ++i) {
         if (errs[i] == 0) continue;
         if (errs[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
-        if (database->currentTask == 0) { paths[i].clear(); fallbackPairs.push_back(i); continue; }
-        twl_params tr = (database->currentTask == 1 || database->currentTask == 2 || in[i].refNum > 10000 || in[i].qryNum > 10000) ? tz : tp;
-        const int minLen = std::min(in[i].lens.first, in[i].lens.second);
-        while (errs[i] != 0) {
-            if (errs[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
-            if (errs[i] == 2) tr.flen = std::min(static_cast<int32_t>(tr.flen * 1.2) << 1, minLen);
-            else { tr.xdrop = static_cast<int32_t>(tr.xdrop * 2); tr.flen = std::min(static_cast<int32_t>(tr.xdrop * 4) << 1, minLen); }
-            if (option->printDetail) std::cout << "Retry pair No. " << i << "\txdrop " << tr.xdrop << " flen " << tr.flen << '\n';
-            if (tr.flen > 4096) { std::cerr << "ERROR: retry needs an anti-diagonal limit of " << tr.flen << " > 4096, which this build's kernels do not cover.\n"; exit(1); }
-            runBatch(tr, std::vector<int>{i}, in, P, stride, paths, errs);
-        }
+        paths[i].clear();
+        fallbackPairs.push_back(i);
     }
 
     std::vector<char> deferred(n, 0);
@@ -193,6 +301,10 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
     for (int i = 0; i < n; ++i)
         if (deferred[i]) fallbackPairs.push_back(i);
     if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
+    rec.level_ms = nowMs() - tPrep;
+    g_totals.pairs += (uint64_t)n; g_totals.band_cells += rec.band_cells; g_totals.relaunched += rec.relaunched; g_totals.kernel_ms += rec.kernel_ms; g_totals.exchange_ms += rec.exchange_ms;
+    ctx.totals.pairs += (uint64_t)n; ctx.totals.band_cells += rec.band_cells; ctx.totals.relaunched += rec.relaunched; ctx.totals.kernel_ms += rec.kernel_ms; ctx.totals.exchange_ms += rec.exchange_ms;
+    ctx.levels.push_back(rec);
     if (option->printDetail)
         std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " stage " << g_totals.stage_ms - before.stage_ms << " call "
                   << g_totals.call_ms - before.call_ms << " (kernel " << g_totals.kernel_ms - before.kernel_ms << ") finish " << g_totals.finish_ms - before.finish_ms

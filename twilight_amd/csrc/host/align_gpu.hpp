@@ -3,6 +3,7 @@
 #include "twl_host.hpp"
 
 #include "../../../include/twl_align.h"
+#include "../../../include/twl_level.h"
 
 #include <chrono>
 
@@ -11,6 +12,22 @@ namespace progressive {
 namespace gpu {
 
 void ensureInit(Option *option);
+
+struct RunCtx {
+    std::vector<twl_store *> stores;      // device-resident mode: one replica per device (or per virtual device in tests)
+    std::vector<int> storeDev;
+    bool finished = false;                         // the main pass is over: rows are back on the host
+    int nextCacheId = 0;
+    LevelTotals totals;
+    std::vector<LevelRecord> levels;
+    Shard shard;
+    ~RunCtx();
+};
+// Longest-processing-time deal of a level's pairs to `parts` owners (deterministic: every rank computes the same answer).
+std::vector<int> dealPairs(const std::vector<long long> &cost, const std::vector<char> &takesPart, int parts);
+// All-gather of the paths the ranks aligned: on return paths/errs hold every pair of the level on every rank.
+void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector<char> &takesPart, int pathCap, std::vector<alnPath> &paths,
+                   std::vector<int16_t> &errs, LevelRecord &rec);
 const std::vector<int> &selectedDevices();
 twl_params baseParams(Params &param);          // == Talco_xdrop::Params(msa::Params&), TALCO-XDrop.cpp:36-53
 inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

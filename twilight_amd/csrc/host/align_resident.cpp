@@ -17,8 +17,6 @@
 // Per level only paths cross PCIe, nothing crosses xGMI.  TWL_TEST_VIRTUAL_DEVICES=k (tests) runs k replicas on the first device.
 #include "align_gpu.hpp"
 
-#include "../../../include/twl_level.h"
-
 #include <omp.h>
 
 #include <algorithm>
@@ -34,11 +32,12 @@ namespace gpu {
 
 namespace {
 
-std::vector<twl_store *> g_stores;      // one replica per device (or per virtual device in tests)
-std::vector<int> g_storeDev;
-#define g_store (g_stores.empty() ? nullptr : g_stores[0])
-bool g_finished = false;        // the main pass is over: rows are back on the host
-int g_nextCacheId = 0;
+// the per-run state (store replicas, cache ids, totals) lives in RunCtx (align_gpu.hpp), reached through the SequenceDB
+#define g_stores (ctx.stores)
+#define g_storeDev (ctx.storeDev)
+#define g_store (ctx.stores.empty() ? nullptr : ctx.stores[0])
+#define g_finished (ctx.finished)
+#define g_nextCacheId (ctx.nextCacheId)
 
 void die(const char *what, int rc)
 {
@@ -46,7 +45,7 @@ void die(const char *what, int rc)
     exit(1);
 }
 
-void createStore(SequenceDB *db, Option *option)
+void createStore(RunCtx &ctx, SequenceDB *db, Option *option)
 {
     const int n = (int)db->sequences.size();
     std::vector<const char *> rows(n);
@@ -74,7 +73,7 @@ void createStore(SequenceDB *db, Option *option)
 
 // Runs fn(replica index) for every replica on its own host thread; stops the run on the first library error.
 template <class F>
-void onAllStores(const char *what, F fn)
+void onAllStores(RunCtx &ctx, const char *what, F fn)
 {
     const size_t nd = g_stores.size();
     std::vector<std::pair<int, std::string>> res(nd, {TWL_OK, ""});
@@ -93,6 +92,7 @@ void onAllStores(const char *what, F fn)
 // deferred nodes) back into Node::msaFreq, store released.
 void materialise(Tree *T, SequenceDB *db, Option *option)
 {
+    RunCtx &ctx = ctxOf(db);
     if (!g_store) return;
     const double t0 = nowMs();
     const int n = (int)db->sequences.size();
@@ -163,8 +163,20 @@ void runsAndConsensus(const uint8_t *info, int len, bool removal, const char *le
 
 }  // namespace
 
+void uploadSequences(SequenceDB *database, Option *option)
+{
+    RunCtx &ctx = ctxOf(database);
+    if (g_store || g_finished) return;
+    ensureInit(option);
+    const double t0 = nowMs();
+    createStore(ctx, database, option);
+    if (option->printDetail) std::cerr << "Sequences resident on " << g_stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
+    database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
+}
+
 void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database, Option *option, Params &param)
 {
+    RunCtx &ctx = ctxOf(database);
     if (database->currentTask != 0 || g_finished) {      // deferred pass: host-staged kernel
         if (g_store) materialise(T, database, option);
         alignmentKernel_GPU(T, nodes, database, option, param);
@@ -172,12 +184,10 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     }
     if (option->cpuOnly) { std::cerr << "ERROR: --cpu-only is not available: this build has no CPU alignment path.\n"; exit(1); }
     ensureInit(option);
-    if (!g_store) {
-        const double t0 = nowMs();
-        createStore(database, option);
-        if (option->printDetail) std::cerr << "Sequences resident on " << g_stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
-        database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
-    }
+    uploadSequences(database, option);
+    if (ctx.shard.world > 1 && g_stores.size() > 1) { std::cerr << "ERROR: several processes with several device replicas each are not supported.\n"; exit(1); }
+    LevelRecord rec;
+    rec.pairs = (int32_t)nodes.size();
     const LevelTotals before = g_totals;
     const double tPrep = nowMs();
     const int n = (int)nodes.size();
@@ -236,7 +246,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<uint8_t> colinfo((size_t)2 * n * stride);
     const int nd = (int)g_stores.size();
     std::vector<std::vector<int32_t>> lensOf(nd);
-    onAllStores("twl_level_prepare", [&](int d) {
+    onAllStores(ctx, "twl_level_prepare", [&](int d) {
         lensOf[d].resize(2 * (size_t)n);       // every replica prepares the whole level; column info is fetched from the first only
         return twl_level_prepare(g_stores[d], &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride,
                                  d == 0 ? lens.data() : lensOf[d].data(), d == 0 ? colinfo.data() : nullptr);
@@ -265,24 +275,19 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         const bool zg = (ps[i].refNum > 10000 || ps[i].qryNum > 10000);
         if (zg) { maskZero[i] = 1; ++nZero; } else { maskPlain[i] = 1; ++nPlain; }
     }
-    // deal the pairs to the replicas, longest first (cost ~ R + Q after gappy-column removal); each replica aligns its share
-    std::vector<int> owner(n, 0);
-    if (nd > 1) {
-        std::vector<int> order(n);
-        for (int i = 0; i < n; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ps[x].lens.first + ps[x].lens.second > ps[y].lens.first + ps[y].lens.second; });
-        std::vector<long long> load(nd, 0);
-        for (int i : order) {
-            const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            owner[i] = d;
-            load[d] += ps[i].lens.first + ps[i].lens.second;
-        }
-    }
+    // deal the pairs, longest first (cost ~ R + Q after gappy-column removal), to the device replicas of this process or, with several
+    // processes (one device each), to the ranks; everybody aligns its share
+    std::vector<char> takesPart(n, 0);
+    std::vector<long long> cost(n, 0);
+    for (int i = 0; i < n; ++i) { takesPart[i] = (maskPlain[i] || maskZero[i]) ? 1 : 0; cost[i] = (long long)ps[i].lens.first + ps[i].lens.second; }
+    const bool procs = ctx.shard.world > 1;
+    const std::vector<int> owner = dealPairs(cost, takesPart, procs ? ctx.shard.world : nd);
+    const int meBase = procs ? ctx.shard.rank : 0;       // replica d of this process aligns the pairs of owner meBase + d
     twl_params tz = tp;
     tz.gap_char = 0;
     std::vector<double> callMs(nd, 0), kernMs(nd, 0), totMs(nd, 0);
     std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
-    onAllStores("twl_level_align", [&](int d) {
+    onAllStores(ctx, "twl_level_align", [&](int d) {
         std::vector<int8_t> aln((size_t)n * 2 * stride);
         std::vector<int32_t> alnLen(n);
         std::vector<int16_t> err(n);
@@ -290,7 +295,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             const std::vector<uint8_t> &all = grp ? maskZero : maskPlain;
             std::vector<uint8_t> mask(n, 0);
             int cnt = 0;
-            for (int i = 0; i < n; ++i) if (all[i] && owner[i] == d) { mask[i] = 1; ++cnt; }
+            for (int i = 0; i < n; ++i) if (all[i] && owner[i] == meBase + d) { mask[i] = 1; ++cnt; }
             if (!cnt) continue;
             const double tCall = nowMs();
             const int r = twl_level_align(g_stores[d], grp ? &tz : &tp, mask.data(), aln.data(), alnLen.data(), err.data());
@@ -308,12 +313,13 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         }
         return (int)TWL_OK;
     });
-    g_totals.pairs += (uint64_t)(nPlain + nZero);
+    (void)nPlain; (void)nZero;
     g_totals.call_ms += *std::max_element(callMs.begin(), callMs.end());           // the replicas run concurrently
-    g_totals.kernel_ms += *std::max_element(kernMs.begin(), kernMs.end());
     g_totals.total_ms += *std::max_element(totMs.begin(), totMs.end());
-    for (uint64_t c : cellsOf) g_totals.band_cells += c;
-    for (uint64_t c : redoOf) g_totals.relaunched += c;
+    rec.kernel_ms = *std::max_element(kernMs.begin(), kernMs.end());
+    for (uint64_t c : cellsOf) rec.band_cells += c;
+    for (uint64_t c : redoOf) rec.relaunched += c;
+    exchangePaths(ctx, owner, takesPart, 2 * stride, paths, errs, rec);             // several processes: everybody gets every path
     std::vector<int> fallbackPairs;
     for (int i = 0; i < n; ++i) {
         if (errs[i] == 0) continue;
@@ -347,7 +353,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
         finalLen[i] = (int32_t)full.size();
     }
-    onAllStores("twl_level_commit", [&](int d) { return twl_level_commit(g_stores[d], finalPaths.data(), finalLen.data(), pathStride); });
+    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit(g_stores[d], finalPaths.data(), finalLen.data(), pathStride); });
     for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
         if (finalLen[i] == 0) continue;
         Node *a = nodes[i].first, *b = nodes[i].second;
@@ -366,9 +372,13 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     for (int i = 0; i < n; ++i)
         if (deferred[i]) fallbackPairs.push_back(i);
     if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
+    rec.level_ms = nowMs() - tPrep;
+    g_totals.pairs += (uint64_t)n; g_totals.band_cells += rec.band_cells; g_totals.relaunched += rec.relaunched; g_totals.kernel_ms += rec.kernel_ms; g_totals.exchange_ms += rec.exchange_ms;
+    ctx.totals.pairs += (uint64_t)n; ctx.totals.band_cells += rec.band_cells; ctx.totals.relaunched += rec.relaunched; ctx.totals.kernel_ms += rec.kernel_ms; ctx.totals.exchange_ms += rec.exchange_ms;
+    ctx.levels.push_back(rec);
     if (option->printDetail)
         std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << g_totals.call_ms - before.call_ms
-                  << " (kernel " << g_totals.kernel_ms - before.kernel_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
+                  << " (kernel " << rec.kernel_ms << ", exchange " << rec.exchange_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
                   << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << '\n';
 }
 

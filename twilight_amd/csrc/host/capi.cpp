@@ -1,0 +1,122 @@
+// twilight_amd/csrc/host/capi.cpp -- C ABI of libtwl_host (include/twl_msa.h): the DEFAULT_ALN flow of driver.cpp in steps.
+#include "../../../include/twl_msa.h"
+
+#include "twl_host.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+namespace {
+thread_local std::string g_msaErr;
+double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+struct twl_msa {
+    msa::Option option;
+    msa::Params *param = nullptr;
+    msa::SequenceDB *db = nullptr;
+    msa::Tree *T = nullptr, *subT = nullptr;
+    bool hostStaged = false, aligned = false;
+    int alnLen = 0;
+    double alignS = 0;
+};
+
+extern "C" {
+
+const char *twl_msa_last_error(void) { return g_msaErr.c_str(); }
+
+int twl_msa_open(int argc, const char *const *argv, twl_msa **out)
+{
+    if (!out || argc < 1 || !argv) { g_msaErr = "bad argument"; return -2; }
+    auto *m = new twl_msa();
+    std::vector<std::string> keep(argv, argv + argc);
+    std::vector<char *> av;
+    for (auto &s : keep) av.push_back(const_cast<char *>(s.c_str()));
+    if (!msa::parseCommandLine((int)av.size(), av.data(), m->option)) { delete m; g_msaErr = "missing -t / -i / -o"; return -2; }
+    m->hostStaged = m->option.hostStaged;
+    msa::progressive::gpu::beginInit(&m->option);
+    m->db = new msa::SequenceDB();
+    m->param = new msa::Params(m->option, m->option.type);
+    m->T = new msa::Tree(m->option.treeFile);                                     // twilight-main.cpp:122
+    phylogeny::assignSinglePartition(m->T->root);                                 // :129-130 with maxSubtree = INT32_MAX
+    m->subT = new msa::Tree(m->T->root, m->option.reroot);                        // :145
+    msa::io::readSequences(m->option.seqFile, m->db, &m->option, m->subT);       // :146
+    *out = m;
+    return 0;
+}
+
+int twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange, void *user)
+{
+    if (!m || world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) { g_msaErr = "bad argument"; return -2; }
+    if (m->aligned) { g_msaErr = "already aligned"; return -2; }
+    msa::progressive::gpu::Shard sh;
+    sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user;
+    msa::progressive::gpu::setShard(m->db, sh);
+    return 0;
+}
+
+int twl_msa_upload(twl_msa *m)
+{
+    if (!m) { g_msaErr = "bad argument"; return -2; }
+    if (!m->hostStaged && !m->aligned) msa::progressive::gpu::uploadSequences(m->db, &m->option);
+    return 0;
+}
+
+int twl_msa_align(twl_msa *m)
+{
+    if (!m) { g_msaErr = "bad argument"; return -2; }
+    if (m->aligned) { g_msaErr = "already aligned: open a fresh handle"; return -2; }
+    msa::alnFunction kernel = msa::progressive::gpu::alignmentKernel_Resident;
+    if (m->hostStaged) kernel = msa::progressive::gpu::alignmentKernel_GPU;
+    const double t0 = nowS();
+    msa::progressive::msaOnSubtree(m->subT, m->db, &m->option, *m->param, kernel, kernel);   // :148
+    m->alignS = nowS() - t0;
+    if (m->option.debug && !m->db->debug()) std::cerr << "WARNING: --check found an illegal alignment row.\n";
+    m->alnLen = m->subT->root->getAlnLen(m->db->currentTask);
+    m->aligned = true;
+    return 0;
+}
+
+int twl_msa_report(twl_msa *m, twl_msa_totals *t, twl_msa_level *levels, int32_t max_levels)
+{
+    if (!m || !t) { g_msaErr = "bad argument"; return -2; }
+    const auto &recs = msa::progressive::gpu::levelRecords(m->db);
+    const auto &tot = msa::progressive::gpu::runTotals(m->db);
+    memset(t, 0, sizeof *t);
+    t->n_levels = (int32_t)recs.size();
+    t->aln_len = m->alnLen;
+    t->n_sequences = (int32_t)m->db->sequences.size();
+    t->pairs = tot.pairs; t->band_cells = tot.band_cells; t->relaunched = tot.relaunched;
+    t->kernel_ms = tot.kernel_ms; t->exchange_ms = tot.exchange_ms; t->align_s = m->alignS;
+    for (int32_t i = 0; levels && i < max_levels && i < (int32_t)recs.size(); ++i) {
+        levels[i].pairs = recs[i].pairs; levels[i].task = recs[i].task; levels[i].band_cells = recs[i].band_cells;
+        levels[i].relaunched = recs[i].relaunched; levels[i].kernel_ms = recs[i].kernel_ms; levels[i].level_ms = recs[i].level_ms;
+        levels[i].exchange_ms = recs[i].exchange_ms;
+    }
+    return 0;
+}
+
+int twl_msa_write(twl_msa *m, const char *path)
+{
+    if (!m || !m->aligned) { g_msaErr = "not aligned yet"; return -2; }
+    const std::string keep = m->option.outFile;
+    if (path) m->option.outFile = path;
+    msa::io::writeFinalMSA(m->db, &m->option, m->alnLen);                          // :165
+    m->option.outFile = keep;
+    return 0;
+}
+
+void twl_msa_close(twl_msa *m)
+{
+    if (!m) return;
+    delete m->db;
+    delete m->param;
+    delete m->subT;
+    delete m->T;
+    delete m;
+}
+
+}  // extern "C"

@@ -151,6 +151,8 @@ void SequenceDB::addSequence(int id, const std::string &name, std::string &seq, 
 
 SequenceDB::~SequenceDB()
 {
+    if (gpuCtx && gpuCtxFree) gpuCtxFree(gpuCtx);
+    gpuCtx = nullptr;
     for (auto *s : sequences) delete s;
     free(rowArena);
 }

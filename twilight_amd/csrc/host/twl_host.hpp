@@ -164,6 +164,8 @@ struct SequenceDB {
     std::unordered_map<std::string, SequenceInfo *> name_map;
     std::unordered_map<int, alnPath> subtreeAln;
     char *rowArena = nullptr;                      // owns the rows of sequences with `borrowed` set
+    void *gpuCtx = nullptr;                        // per-run state of the GPU level kernels (progressive::gpu::RunCtx), freed through gpuCtxFree
+    void (*gpuCtxFree)(void *) = nullptr;
     std::function<void(Tree *)> afterMainPass;    // set by the device-resident level kernel: bring rows/caches back to the host
     void addSequence(int id, const std::string &name, std::string &seq, int subtreeIdx, float weight, bool debug);
     bool debug();      // --check: true when every aligned row reproduces its input sequence and all rows are equally long
@@ -245,8 +247,24 @@ void beginInit(Option *option);   // optional: start device initialisation early
 // building, gappy-column removal, gap penalties and the row write-back run as kernels.  Falls through to alignmentKernel_GPU
 // for the deferred pass (currentTask != 0), after bringing the rows back.
 void alignmentKernel_Resident(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
-struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0; };
+struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0, exchange_ms = 0; };
 extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
+// One level-kernel call, as the reference's per-level report line (progressive.cpp:178-189) plus what the DP did in it.
+struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relaunched = 0; double kernel_ms = 0, level_ms = 0, exchange_ms = 0; };
+// Several processes (one per GPU) aligning ONE family together: every process runs the same host flow on its own replica, aligns
+// the pairs dealt to its rank and receives the other ranks' paths through `exchange` (an all-gather of equal-sized host blocks:
+// send = this rank's block, recv = [world][bytes_per_rank]; returns 0 on success).  twilight_amd/dist.py provides it over
+// torch.distributed (backend nccl = RCCL over xGMI on GPUs, gloo in the CPU tests).
+using ExchangeFn = int (*)(void *user, const void *send, int64_t bytes_per_rank, void *recv);
+struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *user = nullptr; };
+// Per-run state of the level kernels; hangs off SequenceDB::gpuCtx so that several runs can live in one process.
+struct RunCtx;
+RunCtx &ctxOf(SequenceDB *database);
+void setShard(SequenceDB *database, const Shard &shard);
+const std::vector<LevelRecord> &levelRecords(SequenceDB *database);
+const LevelTotals &runTotals(SequenceDB *database);
+// Device-resident mode: create the store (sequences into HBM) ahead of the first level, e.g. before a timed region.
+void uploadSequences(SequenceDB *database, Option *option);
 }
 
 }  // namespace progressive

@@ -89,7 +89,9 @@ int check_params(const twl_params *p)
     if (!p) { g_err = "params is null"; return TWL_ERR_BAD_ARGUMENT; }
     if (p->P != 6 && p->P != 22) { g_err = "profile width P must be 6 (nucleotide) or 22 (protein)"; return TWL_ERR_UNSUPPORTED; }
     if (p->marker < 2 || p->marker > TWL_MAX_MARKER) { g_err = "marker outside [2, TWL_MAX_MARKER]"; return TWL_ERR_UNSUPPORTED; }
-    if (p->flen < 1 || p->flen > 4096) { g_err = "flen outside [1, 4096]"; return TWL_ERR_UNSUPPORTED; }
+    // flen is only a cap on the anti-diagonal width (TALCO-XDrop.cpp:258,331-338): the deferred pass raises it to min(R, Q)
+    // (alignment-cpu.cpp:116-129).  Any value is accepted; what is limited is the band the widest kernel can hold (4608 rows).
+    if (p->flen < 1) { g_err = "flen < 1"; return TWL_ERR_UNSUPPORTED; }
     if (p->xdrop < 0) { g_err = "xdrop < 0"; return TWL_ERR_BAD_ARGUMENT; }
     return TWL_OK;
 }
@@ -384,6 +386,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         d->stats.n_relaunched += (int32_t)redo.size();
         if (!mid) { stage = 2; }
     }
+    // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
+    HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int32_t n = 0; n < n_pairs; ++n)
+        if (h_err[n] == twl::kErrOverflow) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
     std::vector<unsigned long long> cells((size_t)n_pairs);
     HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

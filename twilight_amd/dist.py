@@ -1,9 +1,11 @@
-"""Sharding of one guide-tree level over ranks (one process per GPU).
+"""Several processes (one per GPU) aligning one family together.
 
 The pairs of a level are independent units (reference alignment-cpu.cpp:46; the reference's GPU host code deals
-batches to devices with an atomic counter, hip/alignment-gpu.hip.cpp:239-254), so ranks never exchange DP data:
-each rank aligns its shard and only the report scalars (and, for a caller that wants them on one rank, the paths)
-travel.  torch.distributed is plumbing here: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+batches to devices with an atomic counter, hip/alignment-gpu.hip.cpp:239-254).  In a sharded run (include/twl_msa.h,
+twl_msa_shard) every process holds a replica of the sequences, runs the same host flow, aligns the pairs dealt to its
+rank, and once per level the paths are all-gathered: `make_exchange` below is that all-gather over torch.distributed --
+backend "nccl" (= RCCL over xGMI) moves the blocks GPU to GPU, "gloo" serves the CPU tests.  torch.distributed is plumbing
+here; the dealing and the block format live in the C++ host library (twilight_amd/csrc/host/align_gpu.cpp).
 """
 from __future__ import annotations
 
@@ -33,15 +35,6 @@ def lpt_shards(costs, world: int):
     return [np.asarray(s, dtype=np.int64) for s in shards]
 
 
-def take(batch, idx):
-    """Sub-batch of a LevelBatch-like object."""
-    from .synth import LevelBatch
-
-    idx = np.asarray(idx, dtype=np.int64)
-    return LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq[idx], gap_open=batch.gap_open[idx],
-                      gap_extend=batch.gap_extend[idx], len=batch.len[idx], num=batch.num[idx])
-
-
 def reduce_report(cells: float, seconds: float, device=None):
     """(sum of cells over ranks, max of seconds over ranks): the whole-job rate is their quotient."""
     import torch
@@ -56,35 +49,28 @@ def reduce_report(cells: float, seconds: float, device=None):
     return float(t_c.item()), float(t_s.item())
 
 
-def align_level_sharded(align_fn, batch, rank: int, world: int, gather_to_rank0: bool = True):
-    """Align one level on `world` ranks.  `align_fn(sub_batch) -> (aln, aln_len, err)` is the per-rank aligner
-    (twl.align_batch on a GPU rank).  Returns this rank's (indices, aln, aln_len, err); with gather_to_rank0, rank 0
-    additionally gets the full-level arrays in original pair order (other ranks get None)."""
+def make_exchange(device=None):
+    """The all-gather a sharded twl_msa run calls once per level: exchange(send_ptr, bytes_per_rank, recv_ptr) -> 0.
+    send/recv are host buffers of the C++ side (recv = [world][bytes_per_rank]).  With a CUDA/HIP `device` (backend nccl) the
+    blocks travel GPU to GPU over RCCL/xGMI; with device None (backend gloo) they stay on the host."""
+    import ctypes
+
+    import torch
     import torch.distributed as dist
 
-    shards = lpt_shards(pair_costs(batch.len), world)
-    mine = shards[rank]
-    aln, n, err = align_fn(take(batch, mine)) if len(mine) else (np.zeros((0, 2 * batch.seq_len), np.int8), np.zeros(0, np.int32), np.zeros(0, np.int16))
-    full = None
-    if gather_to_rank0 and world > 1:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object((mine, aln, n, err), parts, dst=0)
-        if rank == 0:
-            N = batch.n_pairs
-            f_aln = np.zeros((N, 2 * batch.seq_len), np.int8)
-            f_n = np.zeros(N, np.int32)
-            f_err = np.zeros(N, np.int16)
-            for idx, a, ln, e in parts:
-                f_aln[idx] = a
-                f_n[idx] = ln
-                f_err[idx] = e
-            full = (f_aln, f_n, f_err)
-    elif gather_to_rank0:
-        f_aln = np.zeros((batch.n_pairs, 2 * batch.seq_len), np.int8)
-        f_n = np.zeros(batch.n_pairs, np.int32)
-        f_err = np.zeros(batch.n_pairs, np.int16)
-        f_aln[mine] = aln
-        f_n[mine] = n
-        f_err[mine] = err
-        full = (f_aln, f_n, f_err)
-    return (mine, aln, n, err), full
+    def exchange(send_ptr, nbytes, recv_ptr):
+        world = dist.get_world_size()
+        send = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(send_ptr), dtype=torch.uint8)
+        recv = torch.frombuffer((ctypes.c_uint8 * (nbytes * world)).from_address(recv_ptr), dtype=torch.uint8)
+        if device is not None:
+            d_send = send.to(device, non_blocking=False)
+            d_recv = torch.empty(nbytes * world, dtype=torch.uint8, device=device)
+            dist.all_gather_into_tensor(d_recv, d_send)
+            recv.copy_(d_recv)
+        else:
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, send)
+            recv.copy_(torch.cat(parts))
+        return 0
+
+    return exchange
