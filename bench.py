@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- TALCO-XDrop level-batch throughput on MI355X (BASELINE.json metric: DP cells/s).
+"""bench.py -- TALCO-XDrop progressive alignment on MI355X (BASELINE.json metric: DP cells/s + wall-clock to final MSA).
 
-One "step" = one pass of the hot path (twl_align_batch_device: column packing + the DP/traceback
-kernel) over one synthetic guide-tree-level batch that is already resident in HBM.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config rnasim10k|rnasim100k|protein5k|rnasim1k_band512]
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--length L]
+Default workload = the configuration the metric is quoted on: RNASim-shaped 10 000 sequences x 10 kbp, FULL progressive
+alignment over the guide tree (BASELINE.json configs[2]).  One "step" = one complete pass of the hot path over that family:
+every guide-tree level's batch of sibling pairs through the product path (libtwl_host -> libtwl_align: profile kernels, the
+TALCO-XDrop DP kernel, write-back kernels), with the sequences already resident in HBM when the timed region starts
+(twl_msa_upload is outside it).  Each step runs on a fresh handle, all opened and uploaded before the clock starts.
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run; the pairs of a level
-are independent, so each rank aligns its own shard (no data-path collective) and rank 0 reports the
-whole-job rate: all ranks' band cells / max-over-ranks wall time ("weak" scaling: per-GPU work fixed).
-Prints ONE JSON line on rank 0.
+    value        = band cells of K passes / wall seconds of the timed region (whole job, max over ranks)
+    dp_kernel    = the same cells / summed DP-kernel time (HIP events inside the library): the rate the roofline fraction uses
+    levels       = per guide-tree level {pairs, cells, kernel_ms, level_ms} of the last pass (reference progressive.cpp:178-189 prints the same)
+    peak_level   = one wide synthetic level (2048 pairs x 10 kbp profiles) through twl_align_batch_device: the kernel's best case
+
+For N > 1 the driver launches one process per GPU (torch.distributed.run); the ranks align the SAME family together: every rank
+holds a replica, aligns the pairs of each level that the longest-first deal gives to it, and the paths are all-gathered once per
+level over RCCL (twilight_amd/dist.py) -- "strong" scaling: total work fixed.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,20 +36,19 @@ import numpy as np  # noqa: E402
 
 from twilight_amd import synth  # noqa: E402
 
-B_CELL_NUC = 64          # algorithmic operand bytes per band cell, P=6: 2*P*4 + 4*4
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "final_pmc_summary.json")
-
-
-def measured_traffic_per_launch(cells_per_launch):
-    """HBM bytes per DP-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, per the
-    gfx950 correction in MI355X_MICROARCH.md), scaled by band cells to this launch size.  None if no profile is committed."""
-    try:
-        with open(PMC_SUMMARY) as f:
-            h = json.load(f)["hbm_per_launch"]
-        return h["traffic_bytes_per_cell"] * cells_per_launch
-    except Exception:
-        return None
+# algorithmic operand bytes per band cell (SURVEY.md 8d / BASELINE.md 3): 2 profile columns + 4 gap penalties = 2*P*4 + 16
+CONFIGS = {
+    "rnasim10k": dict(kind="family", leaves=10000, length=10000, type="n", P=6, bcell=64, sub=0.015, indel=0.001,
+                      name="RNASim-shaped 10k seqs x 10 kbp, full progressive over the guide tree, gappy-column removal on (BASELINE configs[2])"),
+    "rnasim100k": dict(kind="family", leaves=100000, length=1600, type="n", P=6, bcell=64, sub=0.015, indel=0.001,
+                       name="RNASim-shaped 100k seqs x 1.6 kbp, full progressive (BASELINE configs[3])"),
+    "protein5k": dict(kind="family", leaves=5000, length=2000, type="p", P=22, bcell=192, sub=0.015, indel=0.001,
+                      name="protein 5k seqs x 2 kaa, 5xBLOSUM62, full progressive (BASELINE configs[4])"),
+    "rnasim1k_band512": dict(kind="level", pairs=320, length=1600, type="n", P=6, bcell=64, flen=512, xdrop=4000,
+                             name="RNASim-shaped 1k seqs x 1.6 kbp: the leaf level (320 sibling pairs) as ONE batch, fLen 512 / xdrop 4000 (BASELINE configs[1])"),
+}
+PMC = os.path.join(ROOT, "profiles", "r02", "bench_pmc_summary.json")
 
 
 def parse():
@@ -47,12 +56,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=2048, help="sibling pairs per GPU per step")
-    ap.add_argument("--length", type=int, default=10000, help="ancestor length in columns (10 kbp)")
-    ap.add_argument("--pool", type=int, default=64, help="distinct synthetic pairs generated per rank (replicated to --pairs)")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="pairs for the CPU baseline leg (0 = auto)")
+    ap.add_argument("--config", default="rnasim10k", choices=sorted(CONFIGS))
+    ap.add_argument("--leaves", type=int, default=0, help="override the family size (development)")
+    ap.add_argument("--length", type=int, default=0, help="override the sequence length (development)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-final-MSA leg (N=1 only: product CLI on a generated 10k x 10 kbp family)")
+    ap.add_argument("--no-peak", action="store_true", help="skip the single-level peak leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-final-MSA leg (product CLI as a child process)")
+    ap.add_argument("--keep", default="", help="directory for the generated family (kept)")
     return ap.parse_args()
 
 
@@ -68,10 +78,33 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(batch, idx, gpu_paths, gpu_lens, target_seconds=15.0):
-    """Oracle ("port" of the reference CPU path, OpenMP over pairs like tbb::parallel_for at alignment-cpu.cpp:46) timed on
-    the host cores this process may use.  A short calibration sizes the sample to about `target_seconds` of CPU work; the
-    sample is the first k pairs of the very batch the GPU aligned, and the paths are compared while we are at it."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def write_family(cfg, d):
+    sys.setrecursionlimit(1000000)
+    nwk, seqs = synth.make_family(cfg["leaves"], cfg["length"], P=cfg["P"], seed=20260501, sub=cfg["sub"], indel=cfg["indel"])
+    tree, fasta = os.path.join(d, "t.nwk"), os.path.join(d, "s.fa")
+    with open(tree, "w") as f:
+        f.write(nwk + "\n")
+    with open(fasta, "w") as f:
+        for name, s in seqs:
+            f.write(f">{name}\n{s}\n")
+    return tree, fasta
+
+
+def cpu_baseline(batch, matrix, pk, gpu_paths, gpu_lens, target_seconds=12.0):
+    """The oracle ("port" of the reference CPU path; OpenMP over pairs like tbb::parallel_for at alignment-cpu.cpp:46) timed on this
+    box's host cores, all usable cores and one: a bounded sample of wide-level pairs of the workload's shape, the very pairs the GPU
+    aligned in the peak leg, and the paths are compared while we are at it.  The reference's own code, with its vector<vector<float>>
+    layout and 14 allocations per tile, ran at 1.6e7 cells/s/core: this flat-array port is the stronger baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
@@ -80,54 +113,97 @@ def cpu_baseline(batch, idx, gpu_paths, gpu_lens, target_seconds=15.0):
                                 gap_extend=batch.gap_extend[ix], len=batch.len[ix], num=batch.num[ix])
 
     threads = effective_cpus()
-    p = O.make_params(synth.nucleotide_matrix())
-    cal = idx[: max(threads, 8)]
+    p = O.make_params(matrix, **pk)
+    n = batch.n_pairs                      # distinct pairs; the sample cycles through them (the GPU leg replicated them the same way)
+    cal = np.arange(min(n, max(threads, 4)))
     t0 = time.perf_counter()
     _, _, _, st = O.align_batch(p, sub(cal), threads=threads)
     rate = st.cells / (time.perf_counter() - t0)
     per_pair = st.cells / len(cal)
-    k = int(min(len(idx), max(len(cal), target_seconds * rate / per_pair)))
+    k = int(max(len(cal), min(4096, target_seconds * rate / per_pair)))
+    ix = np.arange(k) % n
     t0 = time.perf_counter()
-    aln, n, err, st = O.align_batch(p, sub(idx[:k]), threads=threads)
+    aln, ln, err, st = O.align_batch(p, sub(ix), threads=threads)
     dt = time.perf_counter() - t0
-    parity = bool(np.array_equal(n, gpu_lens[:k]) and all(np.array_equal(aln[i, : n[i]], gpu_paths[i][: n[i]]) for i in range(k)))
-    return {"value": st.cells / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"first {k} pairs of the same batch ({st.cells} band cells) in {dt:.1f} s, OpenMP over pairs, {threads} threads",
+    parity = bool(all(ln[i] == gpu_lens[ix[i]] and np.array_equal(aln[i, : ln[i]], gpu_paths[ix[i]][: ln[i]]) for i in range(k)))
+    k1 = max(1, int(round(3.0 * rate / threads / per_pair)))
+    t0 = time.perf_counter()
+    _, _, _, st1 = O.align_batch(p, sub(np.arange(k1) % n), threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": st.cells / dt, "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "one_thread_value": st1.cells / dt1,
+            "sample": f"{k} pairs of ~{batch.seq_len}-column profiles of this workload's shape ({st.cells} band cells) in {dt:.1f} s on {threads} threads "
+                      f"(OpenMP over pairs); 1 thread: {k1} pairs in {dt1:.1f} s",
+            "reference_code_cells_per_s_per_core": 1.6e7,
+            "note": "flat-array restatement of the reference CPU path (oracle/talco_oracle.c); faster per core than the reference's own code (BASELINE.md section 2)",
             "gpu_paths_equal_on_sample": parity}
 
 
-def wallclock_to_msa(leaves=10000, length=10000):
-    """Second half of BASELINE.json's metric: wall-clock from FASTA + guide tree to the final MSA for the RNASim-shaped 10k x 10 kbp family
-    (BASELINE config 3), product CLI `twilight-mi355x` on this GPU, measured around the whole process.  Never takes the bench line down."""
-    import subprocess
-    import tempfile
+def peak_level(twl, dev, local_rank, cfg, pairs=2048, pool=64, reps=3):
+    """One wide level through twl_align_batch_device (HBM in, HBM out): what the DP kernel does when the GPU is full."""
+    import torch
 
-    try:
-        exe = os.path.join(ROOT, "twilight_amd", "twilight-mi355x")
-        if not os.path.exists(exe):
-            return {"value": None, "unit": "s", "note": "twilight-mi355x not built (run __graft_entry__.build())"}
-        with tempfile.TemporaryDirectory(prefix="twl_bench_e2e_") as d:
-            outj = os.path.join(d, "e2e.json")
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--leaves", str(leaves), "--length", str(length), "--out", outj],
-                               capture_output=True, text=True, timeout=600)
-            if r.returncode != 0 or not os.path.exists(outj):
-                return {"value": None, "unit": "s", "note": "e2e run failed: " + (r.stdout + r.stderr)[-300:]}
-            e = json.load(open(outj))
-        rec = {}
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01", "e2e_wallclock_10000x10k.json")))
-        except OSError:
-            pass
-        same_family = bool(rec) and rec.get("leaves") == leaves and rec.get("length") == length
-        return {"value": e["gpu"]["wall_s"], "unit": "s", "higher_is_better": False,
-                "config": f"synthetic RNASim-shaped family, {leaves} sequences x {length} bp, full progressive alignment over the guide tree ({e['gpu']['levels']} levels), "
-                          f"gappy-column removal on, device-resident level path, 1 GPU; time of the whole process (read FASTA + tree ... write MSA)",
-                "aln_len": e["aln_len"], "summary": e["gpu"]["summary"], "msa_md5": e["gpu"]["md5"],
-                "recorded_cpu_checker_s": rec.get("cpu", {}).get("wall_s") if same_family else None,
-                "msa_equals_recorded_cpu_checker_msa": (e["gpu"]["md5"] == rec.get("cpu", {}).get("md5")) if same_family else None,
-                "note": "the CPU leg (oracle/e2e_oracle, 16 threads, ~107 s) is recorded in profiles/r01/e2e_wallclock_10000x10k.json, not re-run here"}
-    except Exception as ex:  # noqa: BLE001
-        return {"value": None, "unit": "s", "note": f"e2e leg failed: {ex}"}
+    P = cfg["P"]
+    prot = P == 22
+    length = cfg["length"]
+    if cfg["kind"] == "level":
+        pairs = cfg["pairs"]
+    pool = min(pool, pairs)
+    batch = synth.make_level_batch(pool, length, members=((1, 8), (1, 8)), seed=20260501 + 3, P=P, sub=(0.15 if prot else 0.06))
+    idx = np.arange(pairs) % pool
+    tidx = torch.from_numpy(idx).to(dev)
+    freq = torch.from_numpy(batch.freq).to(dev)[tidx].contiguous()
+    gop = torch.from_numpy(batch.gap_open).to(dev)[tidx].contiguous()
+    gex = torch.from_numpy(batch.gap_extend).to(dev)[tidx].contiguous()
+    ln = torch.from_numpy(batch.len).to(dev)[tidx].contiguous()
+    nm = torch.from_numpy(batch.num).to(dev)[tidx].contiguous()
+    sl = batch.seq_len
+    aln = torch.zeros((pairs, 2 * sl), dtype=torch.int8, device=dev)
+    alen = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    err = torch.zeros(pairs, dtype=torch.int16, device=dev)
+    matrix = synth.protein_matrix() if prot else synth.nucleotide_matrix()
+    pk = {k: cfg[k] for k in ("flen", "xdrop") if k in cfg}
+    params = twl.make_params(matrix, **pk)
+    torch.cuda.synchronize()        # the inputs above were produced on torch's stream; the library runs on its own
+    cells = kms = 0.0
+    for r in range(reps + 1):
+        twl.align_batch_device(params, pairs, sl, freq.data_ptr(), gop.data_ptr(), gex.data_ptr(), ln.data_ptr(), nm.data_ptr(),
+                               aln.data_ptr(), alen.data_ptr(), err.data_ptr(), device=local_rank)
+        st = twl.get_stats(local_rank)
+        if r:
+            cells += st.band_cells
+            kms += st.kernel_ms
+    out = {"pairs": pairs, "seq_len": sl, "band_cells_per_launch": int(cells // reps), "kernel_ms_per_launch": kms / reps,
+           "cells_per_s": cells / (kms * 1e-3), "frac_of_hbm_roofline": cells * cfg["bcell"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "deferred_pairs": int((err != 0).sum().item()), "relaunched_pairs": int(st.n_relaunched), "window_rows": int(st.window),
+           "persistent_workgroups": int(st.grid),
+           "workload": f"{pairs} sibling pairs of ~{length}-column profiles (1-8 member sequences per side, weighted counts, PSGP gap penalties), "
+                       f"{pool} distinct pairs replicated"}
+    k = min(pairs, pool)
+    return out, batch, matrix, pk, aln[:k].cpu().numpy(), alen[:k].cpu().numpy()
+
+
+def wallclock_to_msa(tree, fasta, typ, d):
+    """Second half of the metric: wall-clock from FASTA + guide tree to the final MSA, product CLI as a child process (whole process:
+    start-up, read, align, write)."""
+    exe = os.path.join(ROOT, "twilight_amd", "twilight-mi355x")
+    out = os.path.join(d, "cli.aln")
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, "-t", tree, "-i", fasta, "-o", out, "--type", typ, "-v"], capture_output=True, text=True, timeout=1200)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"value": None, "unit": "s", "note": "CLI failed: " + (r.stdout + r.stderr)[-300:]}
+    tail = [l for l in r.stderr.splitlines() if l.startswith("Wrote")][-1]
+    md5 = hashlib.md5(open(out, "rb").read()).hexdigest()
+    os.remove(out)
+    return {"value": wall, "unit": "s", "higher_is_better": False, "summary": tail, "msa_md5": md5,
+            "note": "twilight-mi355x on the same family files, 1 GPU, time of the whole process (HIP start-up, read FASTA + tree, align, write MSA)"}
+
+
+def variant_of(pairs, num_cu, P):
+    if P == 22:
+        return "talco_kernel<22, 8, 2, ..., 4> (precomputed column scores)" if pairs <= max(1, num_cu // 2) else "talco_kernel<22, 8, 2, ..., 3> (sparse column scores)"
+    return "talco_nuc_kernel<16, 1, 2, 1>" if pairs <= num_cu else "talco_nuc_kernel<8, 2, 2, 4>"
 
 
 def main():
@@ -135,45 +211,53 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus N > 1 must be launched with one process per GPU: python -m torch.distributed.run --nnodes=1 "
+                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port <port> bench.py --gpus {args.gpus} ...")
+    # the host library reports on C-level stdout as TWILIGHT does; this process's stdout carries the ONE JSON line only
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    cfg = dict(CONFIGS[args.config])
+    if args.leaves:
+        cfg["leaves"] = args.leaves
+    if args.length:
+        cfg["length"] = args.length
+    family = cfg["kind"] == "family"
 
-    # wall-clock-to-MSA leg first: a child process, started before this process touches the GPU
-    e2e = wallclock_to_msa() if (world == 1 and not args.no_e2e) else None
-
-    # ---- synthetic workload, built on the host before the GPU is touched ----
-    pool_n = min(args.pool, args.pairs)
-    batch = synth.make_level_batch(pool_n, args.length, members=((1, 8), (1, 8)), seed=20260501 + 3 + 1000 * rank)
-    idx = np.arange(args.pairs) % pool_n
+    # ---- the workload, built on the host before the GPU is touched: rank 0 writes the family, every rank reads the same files ----
+    base = args.keep or os.environ.get("TWL_BENCH_DIR") or os.path.join(tempfile.gettempdir(), f"twl_bench_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid() if world > 1 else os.getpid()}")
+    tree = fasta = None
+    gen_s = 0.0
+    if family:
+        os.makedirs(base, exist_ok=True)
+        tree, fasta = os.path.join(base, "t.nwk"), os.path.join(base, "s.fa")
+        if rank == 0:
+            t0 = time.perf_counter()
+            tree, fasta = write_family(cfg, base)
+            gen_s = time.perf_counter() - t0
+            open(os.path.join(base, "ready"), "w").write("1")
+    e2e = None
+    if family and world == 1 and not args.no_e2e:
+        try:    # a child process, started before this process touches the GPU
+            e2e = wallclock_to_msa(tree, fasta, cfg["type"], base)
+        except Exception as ex:  # noqa: BLE001
+            e2e = {"value": None, "unit": "s", "note": f"e2e leg failed: {ex}"}
 
     import torch
     import torch.distributed as dist
 
     import twilight_amd as twl
+    from twilight_amd import dist as tdist
+    from twilight_amd import msa
 
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()          # rank 0 has written the family
     twl.init([local_rank])
-
-    tidx = torch.from_numpy(idx).to(dev)
-    freq = torch.from_numpy(batch.freq).to(dev)[tidx].contiguous()
-    gop = torch.from_numpy(batch.gap_open).to(dev)[tidx].contiguous()
-    gex = torch.from_numpy(batch.gap_extend).to(dev)[tidx].contiguous()
-    ln = torch.from_numpy(batch.len).to(dev)[tidx].contiguous()
-    nm = torch.from_numpy(batch.num).to(dev)[tidx].contiguous()
-    n, sl = args.pairs, batch.seq_len
-    aln = torch.zeros((n, 2 * sl), dtype=torch.int8, device=dev)
-    alen = torch.zeros(n, dtype=torch.int32, device=dev)
-    err = torch.zeros(n, dtype=torch.int16, device=dev)
-    params = twl.make_params(synth.nucleotide_matrix())          # CLI defaults: 18/-8/-4, gap -50/-5, xdrop 5000, marker 1024, flen 4096
-
-    def step():
-        twl.align_batch_device(params, n, sl, freq.data_ptr(), gop.data_ptr(), gex.data_ptr(), ln.data_ptr(), nm.data_ptr(),
-                               aln.data_ptr(), alen.data_ptr(), err.data_ptr(), device=local_rank)
-        return twl.get_stats(local_rank)
+    num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
 
     def fence():
         torch.cuda.synchronize()
@@ -181,74 +265,143 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    cells = 0
-    kernel_ms = 0.0
-    pack_ms = 0.0
-    launches = 0
-    relaunched = 0
-    for _ in range(args.steps):
-        st = step()
-        cells += st.band_cells
-        kernel_ms += st.kernel_ms
-        pack_ms += st.pack_ms
-        launches += st.n_launches
-        relaunched += st.n_relaunched
-    fence()
-    dt = time.perf_counter() - t0
+    peak = pk_batch = None
+    if family:
+        # ---- K + W fresh handles, opened and made resident in HBM before the clock starts ----
+        exchange = tdist.make_exchange(dev) if world > 1 else None
+        handles = []
+        t0 = time.perf_counter()
+        for i in range(args.warmup + args.steps):
+            m = msa.Msa(["-t", tree, "-i", fasta, "-o", os.path.join(base, f"out_r{rank}_{i}.aln"), "--type", cfg["type"], "--gpu-index", str(local_rank)])
+            if world > 1:
+                m.shard(rank, world, exchange)
+            m.upload()
+            handles.append(m)
+        open_s = time.perf_counter() - t0
+        for m in handles[: args.warmup]:
+            m.align()
+        fence()
+        t0 = time.perf_counter()
+        for m in handles[args.warmup:]:
+            m.align()
+        fence()
+        dt = time.perf_counter() - t0
+        cells = 0
+        kernel_ms = exch_ms = 0.0
+        for m in handles[args.warmup:]:
+            tot, levels = m.report()
+            cells += tot.band_cells
+            kernel_ms += tot.kernel_ms
+            exch_ms += tot.exchange_ms
+        md5 = None
+        if rank == 0:
+            out = os.path.join(base, "bench.aln")
+            handles[-1].write(out)
+            md5 = hashlib.md5(open(out, "rb").read()).hexdigest()
+            os.remove(out)
+        for m in handles:
+            m.close()
+    else:
+        # single-level configuration: the step is one launch of the level through twl_align_batch_device
+        peak, pk_batch, matrix, pk, gp, gl = peak_level(twl, dev, local_rank, cfg, reps=max(1, args.steps))
+        fence()
+        t0 = time.perf_counter()
+        peak, pk_batch, matrix, pk, gp, gl = peak_level(twl, dev, local_rank, cfg, reps=args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        cells = peak["band_cells_per_launch"] * args.steps
+        kernel_ms = peak["kernel_ms_per_launch"] * args.steps
+        exch_ms = 0.0
+        levels, tot, md5, open_s = [], None, None, 0.0
 
-    n_bad = int((err != 0).sum().item())
-    from twilight_amd.dist import reduce_report
-
-    cells_all, dt_max = reduce_report(cells, dt, device=dev)      # SUM of cells, MAX of seconds over ranks
+    dt_max = tdist.reduce_report(0.0, dt, device=dev)[1] if world > 1 else dt      # MAX of seconds over ranks (cells are whole-job already)
 
     if rank == 0:
-        value = cells_all / dt_max
-        achieved = (cells * B_CELL_NUC) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0     # GB/s, this rank's DP kernel
+        steps = max(1, args.steps)
+        bcell = cfg["bcell"]
+        achieved = cells * bcell / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0          # GB/s of algorithmic operand bytes
         out = {
-            "metric": "DP band cells/s, TALCO-XDrop level-batch alignment (bit-exact vs reference CPU path)",
-            "value": value,
+            "metric": "DP band cells/s, TALCO-XDrop progressive profile-profile alignment (bit-exact vs reference CPU path)",
+            "value": cells / dt_max,
             "unit": "cells/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max * 1e3 / max(1, args.steps),
+            "ms_per_step": dt_max * 1e3 / steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if family else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"RNASim-shaped 10k seqs x 10 kbp: one guide-tree level batch, {args.pairs} sibling pairs/GPU "
-                            f"of ~{args.length}-column profiles (1-8 member seqs per side, weighted counts, PSGP gap penalties); "
-                            f"{pool_n} distinct pairs per rank replicated; scoring 18/-8/-4, gap -50/-5, xdrop 5000, marker 1024, flen 4096",
-                "pairs_per_gpu": args.pairs, "seq_len": sl, "P": 6,
-                "band_cells_per_step_per_gpu": cells // max(1, args.steps),
-                "deferred_pairs": n_bad, "relaunched_pairs": relaunched,
-                "window_rows": st.window, "persistent_workgroups": st.grid,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic_per_launch(cells // max(1, launches)),
-                "traffic_source": "profiles/r01/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 2 --warmup 1 --no-cpu --pairs 1024`: bytes per band cell, times the cells of this launch)",
-                "kernel": "twl::talco_kernel<6, 8, 2, false, true, true, 4, 2>", "kernel_ms_per_launch": kernel_ms / max(1, launches),
-                "algorithmic_bytes_per_cell": B_CELL_NUC, "cells_per_launch": cells // max(1, launches),
-                "note": "achieved = band cells x 64 B / DP-kernel time (HIP events on the library stream); the path is "
-                        "VALU/latency-bound, real HBM traffic is far below this (DESIGN.md section 5)",
+                "workload": cfg["name"] + (f"; synthetic family: random root evolved down a random binary tree, per-branch substitution {cfg['sub']} x U(0.5,1.5), "
+                                           f"indel rate {cfg['indel']}/site (calibrated on the reference's RNASim sample: band avg 310-420, max ~640 at 10 kbp; milder than "
+                                           f"SURVEY 8d's 0.03-0.10 / 0.005); scoring = CLI defaults (18/-8/-4 or 5xBLOSUM62, gap -50/-5, xdrop 5000, marker 1024, fLen 4096)"
+                                           if family else ""),
+                "name": args.config,
             },
         }
-        if world == 1 and not args.no_cpu:
-            kmax = args.cpu_sample or min(args.pairs, 4096)
+        if family:
+            out["config"].update({"n_sequences": int(tot.n_sequences), "seq_length": cfg["length"], "levels": int(tot.n_levels), "pairs": int(tot.pairs),
+                                  "band_cells_per_pass": int(cells // steps), "aln_len": int(tot.aln_len), "pairs_rerun_in_wider_window": int(tot.relaunched),
+                                  "msa_md5": md5, "generate_s": gen_s, "open_and_upload_s_per_handle": open_s / max(1, args.warmup + args.steps),
+                                  "parallelism": f"pairs of each level dealt to {world} rank(s), paths all-gathered per level over RCCL" if world > 1 else "1 GPU"})
+            out["dp_kernel"] = {"cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms_per_pass": kernel_ms / steps, "exchange_ms_per_pass": exch_ms / steps,
+                                "share_of_step_time": (kernel_ms / steps) / (dt_max * 1e3 / steps),
+                                "note": "all DP launches of a pass (HIP events on the library's stream; with several ranks the slowest rank of each level)"}
+            out["levels"] = [{"pairs": int(lv.pairs), "cells": int(lv.band_cells), "kernel_ms": round(lv.kernel_ms, 3), "level_ms": round(lv.level_ms, 3)} for lv in levels]
+            by = {}
+            for lv in levels:
+                v = by.setdefault(variant_of(lv.pairs, num_cu, cfg["P"]), [0, 0.0, 0])
+                v[0] += 1; v[1] += lv.kernel_ms; v[2] += lv.band_cells
+            kernels = [{"kernel": k, "launches": v[0], "avg_ms": v[1] / v[0], "cells_per_launch": v[2] // v[0],
+                        "frac": (v[2] * bcell / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[1] > 0 else 0.0} for k, v in by.items()]
+            dom = max(kernels, key=lambda x: x["launches"] * x["avg_ms"]) if kernels else None
+        else:
+            out["config"].update(peak)
+            kernels, dom = [], None
+        traffic = None
+        try:
+            traffic = json.load(open(PMC))["hbm_per_pass"]["traffic_bytes"]
+        except Exception:
+            pass
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_live": False,
+            "traffic_source": "profiles/r02/bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per pass; FETCH_SIZE doubled per MI355X_MICROARCH.md)" if traffic else None,
+            "algorithmic_bytes_per_cell": bcell, "cells": int(cells // steps), "kernel_ms": kernel_ms / steps,
+            "dominant_kernel": dom, "kernels": kernels,
+            "note": "achieved = band cells x algorithmic operand bytes per cell / DP-kernel time over ALL launches of a pass (every level of the family); the operand "
+                    "stream is a notional figure (BASELINE.md section 3): columns are reused from LDS/registers, real HBM traffic is ~1 % of it and the kernel is "
+                    "bound by instruction issue, see DESIGN.md section 3",
+        }
+        if world == 1 and not args.no_peak and family:
             try:
-                out["cpu_baseline"] = cpu_baseline(batch, idx[:kmax], aln[:kmax].cpu().numpy(), alen[:kmax].cpu().numpy())
+                peak, pk_batch, matrix, pk, gp, gl = peak_level(twl, dev, local_rank, cfg)
+                out["peak_level"] = peak
+            except Exception as e:  # noqa: BLE001
+                out["peak_level"] = {"note": f"failed: {e}"}
+        if world == 1 and not args.no_cpu:
+            try:
+                if pk_batch is None:
+                    peak2, pk_batch, matrix, pk, gp, gl = peak_level(twl, dev, local_rank, cfg, pairs=64, reps=1)
+                out["cpu_baseline"] = cpu_baseline(pk_batch, matrix, pk, gp, gl)
             except Exception as e:  # the checker must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if e2e is not None:
             out["wallclock_to_msa"] = e2e
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if family and not args.keep:
+            for f in (tree, fasta, os.path.join(base, "ready")):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+            try:
+                os.rmdir(base)
+            except OSError:
+                pass
 
     if world > 1:
         dist.barrier()

@@ -92,7 +92,9 @@ int twl_align_batch(const twl_params *p, int32_t n_pairs, int32_t seq_len,
 /*
  * Same, with every array already resident in device memory of `device` (HBM in, HBM out; no PCIe
  * traffic).  `stream` is a hipStream_t (NULL = the library's stream for that device).  The call
- * returns after the work completed.  This is the form bench.py times.
+ * returns after the work completed.  The library orders its work on `stream` only: with stream == NULL
+ * every producer of the input buffers must have completed before the call (e.g. torch.cuda.synchronize()
+ * after building them with torch); with the producers' own stream passed in, stream order suffices.
  */
 int twl_align_batch_device(int device, void *stream, const twl_params *p, int32_t n_pairs, int32_t seq_len,
                            const float *d_freq, const float *d_gap_open, const float *d_gap_extend,

@@ -128,6 +128,7 @@ def test_device_pointer_form_equals_host_form(gpu):
     aln = torch.zeros((n, 2 * sl), dtype=torch.int8, device=dev)
     alen = torch.zeros(n, dtype=torch.int32, device=dev)
     err = torch.full((n,), 7, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()      # the inputs were produced on torch's stream; with stream=None the library runs on its own (twl_align.h)
     for _ in range(2):      # twice: buffers and the work queue are reused across calls
         gpu.align_batch_device(p, n, sl, t["freq"].data_ptr(), t["gap_open"].data_ptr(), t["gap_extend"].data_ptr(), t["len"].data_ptr(),
                                t["num"].data_ptr(), aln.data_ptr(), alen.data_ptr(), err.data_ptr())

@@ -1,16 +1,16 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py's dominant kernel (run on the GPU box): tools/profile_bench.sh <outdir under the repo>
+# rocprofv3 evidence for bench.py (run on the GPU box): tools/profile_bench.sh <outdir under the repo> [bench.py args]
 # One kernel-trace pass, then the PMC counters in separate passes (--pmc never together with other trace domains).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/$1
+O=$R/$1; shift
 mkdir -p $O
-CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --pairs 1024"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $CMD > $O/bench_under_rocprof.json 2> $O/kt.err
-rocprofv3 --kernel-trace --output-format csv -d $O/p1 -o p1 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES -- $CMD > /dev/null 2> $O/p1.err
-rocprofv3 --kernel-trace --output-format csv -d $O/p2 -o p2 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -- $CMD > /dev/null 2> $O/p2.err
-rocprofv3 --kernel-trace --output-format csv -d $O/p3 -o p3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- $CMD > /dev/null 2> $O/p3.err
-rocprofv3 --kernel-trace --output-format csv -d $O/p4 -o p4 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE WRITE_SIZE -- $CMD > /dev/null 2> $O/p4.err
-python3 $R/tools/summarize_pmc.py $O > $O/pmc_summary.json
+ARGS="--steps 2 --warmup 1 --no-cpu --no-e2e --no-peak $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --kernel-trace --output-format csv -d $O/p1 -o p1 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAVES SQ_WAVE_CYCLES -- python3 $R/bench.py $ARGS > /dev/null 2> $O/p1.err
+rocprofv3 --kernel-trace --output-format csv -d $O/p2 -o p2 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -- python3 $R/bench.py $ARGS > /dev/null 2> $O/p2.err
+rocprofv3 --kernel-trace --output-format csv -d $O/p3 -o p3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 $R/bench.py $ARGS > /dev/null 2> $O/p3.err
+rocprofv3 --kernel-trace --output-format csv -d $O/p4 -o p4 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE WRITE_SIZE -- python3 $R/bench.py $ARGS > /dev/null 2> $O/p4.err
+python3 $R/tools/summarize_pmc.py $O 3 > $O/pmc_summary.json
 find $O -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 ls $O

@@ -1,21 +1,27 @@
-"""Summarise the rocprofv3 PMC passes written by tools/profile_bench.sh into one JSON (stdout): counter sums of the DP kernel's
-dispatches and the HBM bytes per launch (FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE is doubled on gfx950 per MI355X_MICROARCH.md)."""
+"""Summarise the rocprofv3 PMC passes written by tools/profile_bench.sh / tools/profile_cmd.sh into one JSON (stdout): counter sums of the
+DP kernels' dispatches, per kernel name, and the HBM bytes per bench pass (FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE is doubled on
+gfx950 per MI355X_MICROARCH.md).  Usage: summarize_pmc.py <dir> [passes of the family per command run]"""
 import csv, glob, json, os, sys
 
 root = sys.argv[1]
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 out = {}
 for i in (1, 2, 3, 4):
     files = glob.glob(os.path.join(root, f"p{i}", "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
-    sums, disp, meta = {}, set(), {}
+    sums, disp, per = {}, set(), {}
     for row in csv.DictReader(open(files[0])):
         if "talco_" not in row["Kernel_Name"]:
             continue
         disp.add(row["Dispatch_Id"])
         sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-        meta = {"kernel": row["Kernel_Name"], "grid": row["Grid_Size"], "wg": row["Workgroup_Size"], "lds": row["LDS_Block_Size"], "vgpr": row["VGPR_Count"]}
-    out[f"pass{i}"] = {"dispatches": len(disp), **meta, "sum_over_dispatches": sums}
+        k = per.setdefault(row["Kernel_Name"], {"dispatches": set(), "wg": row["Workgroup_Size"], "lds": row["LDS_Block_Size"], "vgpr": row["VGPR_Count"], "sum": {}})
+        k["dispatches"].add(row["Dispatch_Id"])
+        k["sum"][row["Counter_Name"]] = k["sum"].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    for k in per.values():
+        k["dispatches"] = len(k["dispatches"])
+    out[f"pass{i}"] = {"dispatches": len(disp), "sum_over_dispatches": sums, "per_kernel": per}
 bench = None
 try:
     for line in open(os.path.join(root, "bench_under_rocprof.json")):
@@ -24,12 +30,11 @@ try:
 except OSError:
     pass
 if "pass3" in out and "pass4" in out and bench:
-    n3, n4 = out["pass3"]["dispatches"], out["pass4"]["dispatches"]
-    fetch = out["pass3"]["sum_over_dispatches"]["FETCH_SIZE"] * 1024 / n3
-    write = out["pass4"]["sum_over_dispatches"]["WRITE_SIZE"] * 1024 / n4
-    cells = bench["roofline"]["cells_per_launch"]
-    out["hbm_per_launch"] = {"fetch_bytes_reported": fetch, "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write, "traffic_bytes": 2 * fetch + write,
-                             "band_cells_per_launch": cells, "traffic_bytes_per_cell": (2 * fetch + write) / cells,
-                             "note": "rocprofv3 --pmc in separate passes with --kernel-trace only; FETCH_SIZE/WRITE_SIZE are KB; FETCH doubled per MI355X_MICROARCH.md "
-                                     "(gfx950 counts wide coalesced reads at half); command: bench.py --steps 2 --warmup 1 --no-cpu --pairs 1024"}
+    fetch = out["pass3"]["sum_over_dispatches"]["FETCH_SIZE"] * 1024 / passes
+    write = out["pass4"]["sum_over_dispatches"]["WRITE_SIZE"] * 1024 / passes
+    cells = bench["roofline"]["cells"]
+    out["hbm_per_pass"] = {"fetch_bytes_reported": fetch, "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write, "traffic_bytes": 2 * fetch + write,
+                           "band_cells_per_pass": cells, "traffic_bytes_per_cell": (2 * fetch + write) / cells, "family_passes_per_run": passes,
+                           "note": "DP kernels only, all launches of one pass over the family; rocprofv3 --pmc in separate passes with --kernel-trace only; FETCH_SIZE/WRITE_SIZE are KB; "
+                                   "FETCH doubled per MI355X_MICROARCH.md (gfx950 counts wide coalesced reads at half)"}
 print(json.dumps(out, indent=1))

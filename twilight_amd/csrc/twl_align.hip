@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -28,7 +29,7 @@ namespace {
 thread_local std::string g_err;
 std::mutex g_mu;
 
-static bool dbg_on() { static int v = -1; if (v < 0) v = getenv("TWL_DEBUG") ? 1 : 0; return v == 1; }
+static bool dbg_on() { static const bool v = getenv("TWL_DEBUG") != nullptr; return v; }
 #define TRACE(...) do { if (dbg_on()) { fprintf(stderr, "[twl trace] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 #define HIP_TRY(expr)                                                                                          \
@@ -105,13 +106,13 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 {
     using CfgT = twl::Cfg<P, W, RPL, PRE, REFLDS, QREG>;
     if (blocks_per_cu <= 0) {
-        static int cached = 0;      // one value per template instantiation
-        if (cached == 0) {
+        static std::atomic<int> cached{0};      // one value per template instantiation (device threads may race to fill it: same value)
+        if (cached.load() == 0) {
             int nb = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), CfgT::THREADS, 0));
-            cached = std::max(1, nb);
+            cached.store(std::max(1, nb));
         }
-        blocks_per_cu = cached;
+        blocks_per_cu = cached.load();
         if (const char *cap = getenv("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));   // development knob
     }
     if (window_out) *window_out = CfgT::WINDOW;
@@ -157,13 +158,13 @@ template <int W, int RPL, int MM, int MINW>
 int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
 {
     using CfgT = twl::NCfg<W, RPL>;
-    static int cached = 0;      // one value per template instantiation
-    if (cached == 0) {
+    static std::atomic<int> cached{0};      // one value per template instantiation
+    if (cached.load() == 0) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, MM, MINW>), CfgT::THREADS, 0));
-        cached = std::max(1, nb);
+        cached.store(std::max(1, nb));
     }
-    int blocks_per_cu = cached;
+    int blocks_per_cu = cached.load();
     if (const char *cap = getenv("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));   // development knob
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * blocks_per_cu);
@@ -434,18 +435,28 @@ int twl_init(const int *device_ids, int n_devices)
     std::vector<int> ids;
     if (!device_ids || n_devices <= 0) ids.push_back(0);
     else ids.assign(device_ids, device_ids + n_devices);
+    std::vector<Device *> devs;      // committed to g_devs only when every device came up
+    auto fail = [&](int rc) {
+        for (auto *d : devs) {
+            for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
+            if (d->stream) (void)hipStreamDestroy(d->stream);
+            delete d;
+        }
+        return rc;
+    };
     for (int id : ids) {
-        if (id < 0 || id >= count) { g_err = "device id out of range"; return TWL_ERR_BAD_ARGUMENT; }
-        HIP_TRY(hipSetDevice(id));
+        if (id < 0 || id >= count) { g_err = "device id out of range"; return fail(TWL_ERR_BAD_ARGUMENT); }
         auto *d = new Device();
         d->id = id;
+        devs.push_back(d);
         hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, id));
-        d->num_cu = prop.multiProcessorCount;
-        HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-        for (auto &e : d->ev) HIP_TRY(hipEventCreate(&e));
-        g_devs.push_back(d);
+        hipError_t e = hipSetDevice(id);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, id);
+        if (e == hipSuccess) { d->num_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking); }
+        for (auto &ev : d->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+        if (e != hipSuccess) { g_err = std::string("twl_init: ") + hipGetErrorString(e); return fail(TWL_ERR_HIP); }
     }
+    g_devs = devs;
     g_init = true;
     return TWL_OK;
 }
@@ -456,8 +467,8 @@ void twl_shutdown(void)
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->h2d_freq, &d->h2d_gop, &d->h2d_gex,
-                       &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24,
+                       &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
         if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -490,6 +501,8 @@ static int run_host_slice(Device *d, const twl_params *p, const std::vector<int3
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
     const int32_t n = (int32_t)ids.size();
+    d->stats = twl_stats{};          // a device that gets no pairs of this call must not report the previous call's counters
+    d->pair_cells.clear();
     if (n == 0) return TWL_OK;
     const size_t P = (size_t)p->P, sl = (size_t)seq_len;
     int rc;
