@@ -42,6 +42,48 @@ int main(int argc, char **argv)
         CHECK("params_protein_5xblosum62", pp.matrixSize == 21 && pp.scoringMatrix[0][0] == 20 && pp.scoringMatrix[18][18] == 55 && pp.scoringMatrix[1][3] == -20 &&
                                                pp.scoringMatrix[20][5] == 0 && pp.scoringMatrix[5][20] == 0);
     }
+    // ---- msa::Params: the other built-in tables and the user matrix file (scoring-matrix.cpp:112-199, blosum.hpp:31-79) ----
+    {
+        Option o80 = opt; o80.blosum = 80;
+        Params p80(o80, 'p');
+        // BLOSUM80 as shipped is not symmetric: [I][V] = 3, [V][I] = 1 (blosum.hpp:65,75)
+        CHECK("params_blosum80_asymmetric_entry", p80.scoringMatrix[7][17] == 15 && p80.scoringMatrix[17][7] == 5 && p80.scoringMatrix[0][0] == 35 && p80.scoringMatrix[18][18] == 75);
+        Option o45 = opt; o45.blosum = 45; o45.wildcard = true;
+        Params p45(o45, 'p');
+        // the X score under -w is 5 x the mean BLOSUM62 diagonal whichever table is selected (:120-122): 5 * 5.8 = 29
+        CHECK("params_blosum45_and_wildcard_X", p45.scoringMatrix[0][0] == 25 && p45.scoringMatrix[1][1] == 60 && std::fabs(p45.scoringMatrix[20][3] - 29.0f) < 1e-4f && std::fabs(p45.scoringMatrix[3][20] - 29.0f) < 1e-4f);
+        Option ob = opt; ob.blosum = 50;
+        Params pb(ob, 'p');
+        CHECK("params_invalid_blosum_falls_back_to_62", pb.scoringMatrix[0][0] == 20 && pb.scoringMatrix[18][18] == 55);
+        {   // dump every built-in protein matrix for the Python side, which holds the reference's numbers as a fixture
+            std::ofstream f(tmp + "/blosum_dump.txt");
+            for (int b : {45, 62, 80}) {
+                Option ox = opt; ox.blosum = b;
+                Params px(ox, 'p');
+                for (int i = 0; i < 20; ++i) for (int j = 0; j < 20; ++j) f << px.scoringMatrix[i][j] << (j == 19 ? '\n' : ' ');
+            }
+        }
+        if (argc > 2) {      // argv[2]: the reference's own example, dataset/substitution.txt (4 letters, no N)
+            Option ou = opt; ou.matrixFile = argv[2];
+            Params pu(ou, 'n');
+            bool ok = pu.matrixSize == 5;
+            for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) ok = ok && pu.scoringMatrix[i][j] == ((i == 4 || j == 4) ? 0.0f : (i == j ? 4.0f : -1.0f));
+            CHECK("params_user_matrix_reference_example", ok);
+            ou.wildcard = true;
+            Params pw2(ou, 'n');
+            CHECK("params_user_matrix_wildcard_mean_diagonal", pw2.scoringMatrix[4][1] == 4.0f && pw2.scoringMatrix[3][4] == 4.0f && pw2.scoringMatrix[0][1] == -1.0f);
+        }
+        {   // letters in another order, ambiguity letter listed, asymmetric values: scoringMatrix[row letter][column letter]
+            std::ofstream f(tmp + "/m5.txt");
+            f << "T G C A N\n 1 2 3 4 5\n 6 7 8 9 10\n 11 12 13 14 15\n 16 17 18 19 20\n 21 22 23 24 25\n";
+            f.close();
+            Option ou = opt; ou.matrixFile = tmp + "/m5.txt";
+            Params pu(ou, 'n');
+            // row T = {T:1, G:2, C:3, A:4, N:5} -> M[3][3] = 1, M[3][2] = 2, M[3][1] = 3, M[3][0] = 4, M[3][4] = 5; row A = 16..20
+            CHECK("params_user_matrix_letter_order_and_N", pu.scoringMatrix[3][3] == 1 && pu.scoringMatrix[3][2] == 2 && pu.scoringMatrix[3][0] == 4 && pu.scoringMatrix[3][4] == 5 &&
+                                                           pu.scoringMatrix[0][3] == 16 && pu.scoringMatrix[0][0] == 19 && pu.scoringMatrix[4][4] == 25 && pu.scoringMatrix[2][3] == 6);
+        }
+    }
     // ---- getConsensus (alignment-helper.cpp:221-241): first strict maximum; all-zero -> N ----
     {
         float prof[3 * 6] = {0, 2, 2, 0, 0, 1, /*col1: C and G tie -> C*/ 0, 0, 0, 0, 0, 3, /*all zero -> N*/ 1, 0, 0, 0.5f, 9, 0 /*N count ignored: argmax over first 4 -> A*/};

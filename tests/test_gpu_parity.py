@@ -289,3 +289,53 @@ def test_retry_parameters_beyond_flen_4096(gpu):
     assert ost.max_width > 500
     # errorType 2 -> fLen = min(int(fLen * 1.2) << 1, min(R, Q)) (:116-119): 9830 for 10 kbp inputs; here capped by the lengths
     _compare(gpu, batch, flen=min(int(4096 * 1.2) << 1, minlen))
+
+
+# ---- asymmetric matrices: the DP indexes scoreMatrix[l][m] with l = reference letter, m = query letter (TALCO-XDrop.cpp:382) ----
+def _blosum(which):
+    import json
+    import os
+
+    t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "blosum_tables.json")))[which]
+    m = np.zeros((21, 21), dtype=np.float32)
+    m[:20, :20] = 5.0 * np.asarray(t, dtype=np.float32)
+    return m
+
+
+@pytest.mark.parametrize("mode", ["dense", "sparse", "presim"])
+def test_blosum80_asymmetric_entry_is_indexed_like_the_reference(gpu, mode, monkeypatch):
+    """5 x BLOSUM80 as the reference ships it has [I][V] = 15 but [V][I] = 5 (blosum.hpp:65,75).  Profiles rich in I and V make the
+    entry count; a kernel that indexed M[m][l] would score these pairs differently from the oracle (which follows the x86 order)."""
+    monkeypatch.setenv("TWL_PROT_CFG", mode)
+    m80 = _blosum("80")
+    assert m80[7, 17] == 15 and m80[17, 7] == 5
+    batch = synth.make_level_batch(6, 500, members=((1, 4), (1, 4)), seed=80, P=22, sub=0.3)
+    # bias the columns towards I (7) on the reference side and V (17) on the query side, keeping the column sums
+    rng = np.random.default_rng(1)
+    for n in range(batch.n_pairs):
+        for side, (src, dst) in enumerate(((17, 7), (7, 17))):
+            L = int(batch.len[n, side])
+            cols = rng.random(L) < 0.5
+            f = batch.freq[n, side, :L]
+            tot = f[cols, :20].sum(axis=1)
+            f[cols, :20] = 0
+            f[cols, dst] = tot * 0.75
+            f[cols, src] = tot * 0.25
+    _compare(gpu, batch, matrix=m80)
+    sw = m80.copy()
+    sw[7, 17], sw[17, 7] = sw[17, 7], sw[7, 17]
+    a1, n1, _ = gpu.align_batch(gpu.make_params(m80), batch)
+    a2, n2, _ = gpu.align_batch(gpu.make_params(sw), batch)
+    assert any(n1[i] != n2[i] or not np.array_equal(a1[i, : n1[i]], a2[i, : n2[i]]) for i in range(batch.n_pairs)), \
+        "the asymmetric entry did not influence any path: the test would not notice a transposed matrix"
+
+
+def test_random_asymmetric_nucleotide_matrix(gpu):
+    """General 5 x 5 matrix with every entry different (matrix mode 0 of the nucleotide kernel): transposition would show."""
+    rng = np.random.default_rng(3)
+    mat = rng.integers(-12, 20, size=(5, 5)).astype(np.float32)
+    mat[np.arange(5), np.arange(5)] = 18 + np.arange(5)
+    assert not np.array_equal(mat, mat.T)
+    batch = synth.make_level_batch(8, 900, members=((1, 6), (1, 6)), seed=15)
+    _compare(gpu, batch, matrix=mat)
+    _compare(gpu, batch, matrix=mat.T.copy())

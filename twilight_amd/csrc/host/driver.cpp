@@ -56,6 +56,7 @@ bool parseCommandLine(int argc, char **argv, Option &o)
         else if (flag(a, nullptr, "--gap-ends")) { o.gapEnds = (float)atof(val()); o.hasGapEnds = true; }
         else if (flag(a, nullptr, "--xdrop")) o.xdrop = (float)atof(val());
         else if (flag(a, "-b", "--blosum")) o.blosum = atoi(val());
+        else if (flag(a, "-x", "--matrix")) o.matrixFile = val();
         else if (flag(a, nullptr, "--length-deviation")) o.lenDev = (float)atof(val());
         else if (flag(a, nullptr, "--max-ambig")) o.maxAmbig = (float)atof(val());
         else if (flag(a, nullptr, "--max-len")) o.maxLen = atoi(val());
@@ -69,6 +70,10 @@ bool parseCommandLine(int argc, char **argv, Option &o)
         else { std::cerr << "ERROR: unsupported option " << a << " (this build covers the tree+sequences alignment mode only)\n"; exit(1); }
     }
     if (o.treeFile.empty() || o.seqFile.empty() || o.outFile.empty()) return false;
+    if (o.cpuOnly) {       // the reference's GPU builds route to their CPU kernel here (hip/alignment-gpu.hip.cpp:19-21); this build has no CPU alignment path
+        std::cerr << "ERROR: --cpu-only is not available: twilight-mi355x has no CPU alignment path (the CPU checker oracle/e2e_oracle is test infrastructure).\n";
+        exit(1);
+    }
     if (o.gappyVertical > 1 || o.gappyVertical <= 0) { std::cerr << "ERROR: Invalid value for --remove-gappy. The value of --remove-gappy should be in (0,1]\n"; exit(1); }
     if (o.gpuIdx.empty() && o.gpuNum > 0) for (int g = 0; g < o.gpuNum; ++g) o.gpuIdx.push_back(g);
     if (!typeGiven) o.type = io::detectType(o.seqFile);

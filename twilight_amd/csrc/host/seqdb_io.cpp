@@ -44,7 +44,30 @@ int letterIdx(char type, char c)
 
 namespace msa {
 
-// BLOSUM62 in ACDEFGHIKLMNPQRSTVWY order (public NCBI table; reference blosum.hpp holds the same values)
+// The built-in substitution tables, ACDEFGHIKLMNPQRSTVWY order, as the reference ships them (blosum.hpp:9-79; data, not code).
+// BLOSUM80 is NOT symmetric there: [V][I] = 1 but [I][V] = 3 (blosum.hpp:65,75), which makes the DP's matrix indexing
+// scoreMatrix[l][m] with l = reference letter, m = query letter (TALCO-XDrop.cpp:382) observable.
+static const int8_t kBlosum45[20][20] = {
+    /*A*/ {5, -1, -2, -1, -2, 0, -2, -1, -1, -1, -1, -1, -1, -1, -2, 1, 0, 0, -2, -2},
+    /*C*/ {-1, 12, -3, -3, -3, -3, -3, -3, -2, -2, -2, -2, -4, -2, -3, -3, -1, -1, -5, -3},
+    /*D*/ {-2, -3, 7, 2, -4, -1, 0, -4, 0, -3, -3, 2, -1, 0, -1, -1, -1, -3, -4, -3},
+    /*E*/ {-1, -3, 2, 6, -3, -2, 0, -3, 1, -2, -2, 0, -1, 2, 0, 0, 0, -2, -3, -3},
+    /*F*/ {-2, -3, -4, -3, 8, -3, 0, 0, -3, 1, 1, -2, -4, -2, -3, -2, -2, -1, 0, 1},
+    /*G*/ {0, -3, -1, -2, -3, 7, -2, -2, -2, -3, -2, -1, -2, -2, -2, 0, -1, -2, -2, -2},
+    /*H*/ {-2, -3, 0, 0, 0, -2, 10, -3, -1, -2, -2, 1, 1, -3, 1, 0, -1, -2, -3, -2},
+    /*I*/ {-1, -3, -4, -3, 0, -2, -3, 5, -3, 5, 2, -2, -3, -2, -3, -3, -2, 3, -2, -2},
+    /*K*/ {-1, -2, 0, 1, -3, -2, -1, -3, 5, -3, -1, 0, -1, 0, 1, 3, -1, -2, -2, -2},
+    /*L*/ {-1, -2, -3, -2, 1, -3, -2, 5, -3, 5, 3, -3, -2, -3, -2, -2, -2, 1, -2, -1},
+    /*M*/ {-1, -2, -3, -2, 1, -2, -2, 2, -1, 3, 6, -3, -2, -2, -1, -2, -2, 1, -1, -1},
+    /*N*/ {-1, -2, 2, 0, -2, -1, 1, -2, 0, -3, -3, 6, -2, -2, -2, 1, 0, -3, -4, -2},
+    /*P*/ {-1, -4, -1, -1, -4, -2, 1, -3, -1, -2, -2, -2, 9, -2, -2, -1, -1, -2, -3, -3},
+    /*Q*/ {-1, -2, 0, 2, -2, -2, -3, -2, 0, -3, -2, -2, -2, 6, 2, 0, -1, -2, -2, -2},
+    /*R*/ {-2, -3, -1, 0, -3, -2, 1, -3, 1, -2, -1, -2, -2, 2, 7, -1, -1, -3, -2, -2},
+    /*S*/ {1, -3, -1, 0, -2, 0, 0, -3, 3, -2, -2, 1, -1, 0, -1, 4, 2, -2, -4, -2},
+    /*T*/ {0, -1, -1, 0, -2, -1, -1, -2, -1, -2, -2, 0, -1, -1, -1, 2, 5, 0, -3, -1},
+    /*V*/ {0, -1, -3, -2, -1, -2, -2, 3, -2, 1, 1, -3, -2, -2, -3, -2, 0, 5, -3, -1},
+    /*W*/ {-2, -5, -4, -3, 0, -2, -3, -2, -2, -2, -1, -4, -3, -2, -2, -4, -3, -3, 15, 3},
+    /*Y*/ {-2, -3, -3, -3, 1, -2, -2, -2, -2, -1, -1, -2, -3, -2, -2, -2, -1, -1, 3, 8}};
 static const int8_t kBlosum62[20][20] = {
     /*A*/ {4, 0, -2, -1, -2, 0, -2, -1, -1, -1, -1, -2, -1, -1, -1, 1, 0, 0, -3, -2},
     /*C*/ {0, 9, -3, -4, -2, -3, -3, -1, -3, -1, -1, -3, -3, -3, -3, -1, -1, -1, -2, -2},
@@ -66,8 +89,47 @@ static const int8_t kBlosum62[20][20] = {
     /*V*/ {0, -1, -3, -2, -1, -3, -3, 3, -2, 1, 1, -3, -2, -2, -3, -2, 0, 4, -3, -1},
     /*W*/ {-3, -2, -4, -3, 1, -2, -2, -3, -3, -2, -1, -4, -4, -2, -3, -3, -2, -3, 11, 2},
     /*Y*/ {-2, -2, -3, -2, 3, -3, 2, -1, -2, -1, -1, -2, -3, -1, -2, -2, -2, -1, 2, 7}};
+static const int8_t kBlosum80[20][20] = {
+    /*A*/ {7, -1, -3, -3, -4, -1, -4, -2, -1, -2, -2, -3, -3, -2, -3, 1, 0, -1, -6, -4},
+    /*C*/ {-1, 13, -6, -7, -3, -4, -5, -3, -5, -3, -3, -5, -4, -5, -5, -1, -1, -3, -5, -4},
+    /*D*/ {-3, -6, 10, 1, -7, -3, -1, -7, -1, -7, -6, 2, -5, 0, -4, -1, -2, -6, -8, -7},
+    /*E*/ {-3, -7, 1, 7, -6, -4, 0, -5, 1, -5, -4, -1, -3, 2, -1, -2, -3, -4, -8, -6},
+    /*F*/ {-4, -3, -7, -6, 8, -5, -4, 0, -6, 1, 0, -6, -6, -5, -5, -4, -3, -1, 0, 4},
+    /*G*/ {-1, -4, -3, -4, -5, 8, -4, -6, -3, -6, -5, -2, -5, -4, -5, -2, -3, -5, -7, -6},
+    /*H*/ {-4, -5, -1, 0, -4, -4, 12, -6, -1, -5, -3, 1, -3, 1, 0, -2, -3, -5, -4, 2},
+    /*I*/ {-2, -3, -7, -5, 0, -6, -6, 5, -5, 2, 2, -6, -5, -5, -5, -4, -2, 3, -5, -4},
+    /*K*/ {-1, -5, -1, 1, -6, -3, -1, -5, 8, -4, -3, 0, -2, 2, 1, -1, -1, -4, -6, -4},
+    /*L*/ {-2, -3, -7, -5, 1, -6, -5, 2, -4, 5, 3, -6, -4, -4, -4, -3, -2, 1, -4, -3},
+    /*M*/ {-2, -3, -6, -4, 0, -5, -3, 2, -3, 3, 7, -4, -4, -2, -3, -3, -1, 1, -4, -3},
+    /*N*/ {-3, -5, 2, -1, -6, -2, 1, -6, 0, -6, -4, 9, -4, 0, -1, 0, -1, -5, -7, -6},
+    /*P*/ {-3, -4, -5, -3, -6, -5, -3, -5, -2, -4, -4, -4, 10, -3, -3, -2, -3, -4, -7, -6},
+    /*Q*/ {-2, -5, 0, 2, -5, -4, 1, -5, 2, -4, -2, 0, -3, 8, 1, -1, -1, -4, -7, -4},
+    /*R*/ {-3, -5, -4, -1, -5, -5, 0, -5, 1, -4, -3, -1, -3, 1, 8, -1, -1, -4, -7, -6},
+    /*S*/ {1, -1, -1, -2, -4, -2, -2, -4, -1, -3, -3, 0, -2, -1, -1, 6, 2, -1, -6, -4},
+    /*T*/ {0, -1, -2, -3, -3, -3, -3, -2, -1, -2, -1, -1, -3, -1, -1, 2, 7, 0, -6, -3},
+    /*V*/ {-1, -3, -6, -4, -1, -5, -5, 1, -4, 1, 1, -5, -4, -4, -4, -1, 0, 6, -5, -4},
+    /*W*/ {-6, -5, -8, -8, 0, -7, -4, -5, -6, -4, -4, -7, -7, -7, -7, -6, -6, -5, 15, 3},
+    /*Y*/ {-4, -4, -7, -6, 4, -6, 2, -4, -4, -3, -3, -6, -6, -4, -6, -4, -3, -4, 3, 9}};
 
-// scoring-matrix.cpp:81-135 (built-in matrices; BLOSUM62 only for proteins in this build)
+// One letter of a user matrix file -> matrix index (scoring-matrix.cpp:26-79)
+static int matrixLetter(char type, const std::string &word) { return letterIdx(type, (char)toupper((unsigned char)word[0])); }
+
+static bool isNumberToken(const std::string &w)
+{
+    try {
+        size_t pos = 0;
+        (void)std::stod(w, &pos);
+        return pos == w.size();
+    } catch (...) {
+        return false;
+    }
+}
+
+// scoring-matrix.cpp:81-199.  Built-in: nucleotide match / transition / mismatch with a zero (or, with -w, match) N row and column;
+// 5 x BLOSUM45/62/80 with a zero (or, with -w, 5 x the mean BLOSUM62 diagonal) X row and column.  User matrix (-x file): the
+// letters first -- matrixSize-1 of them, or matrixSize when the token after them is not a number (then the last letter is the
+// ambiguity letter) -- then the scores row by row in the order of those letters; without an ambiguity letter its row and column
+// are 0 or, with -w, the mean of the diagonal.
 Params::Params(const Option &o, char type)
 {
     gapOpen = o.gapOpen;
@@ -79,8 +141,37 @@ Params::Params(const Option &o, char type)
     xdrop = (gapExtend == 0) ? xd : -1 * xd * gapExtend;
     matrixSize = (type == 'n') ? 5 : 21;
     scoringMatrix = new float *[matrixSize];
-    for (int i = 0; i < matrixSize; ++i) scoringMatrix[i] = new float[matrixSize];
-    if (type == 'n') {
+    for (int i = 0; i < matrixSize; ++i) { scoringMatrix[i] = new float[matrixSize]; std::fill(scoringMatrix[i], scoringMatrix[i] + matrixSize, 0.0f); }
+    if (!o.matrixFile.empty()) {
+        std::ifstream in(o.matrixFile);
+        if (!in) { fprintf(stderr, "ERROR: can't open %s\n", o.matrixFile.c_str()); exit(1); }
+        std::vector<std::string> tok;
+        for (std::string w; in >> w;) tok.push_back(w);
+        int nLetters = matrixSize - 1;
+        if ((int)tok.size() > nLetters && !isNumberToken(tok[nLetters])) nLetters = matrixSize;      // the ambiguity letter is listed too
+        const int ambig = matrixSize - 1;
+        std::vector<int> idx;
+        for (int t = 0; t < nLetters && t < (int)tok.size(); ++t) {
+            const int li = matrixLetter(type, tok[t]);
+            if (li == ambig && t < matrixSize - 1 && nLetters == matrixSize - 1) {
+                std::cerr << "Unrecognized letter \"" << (char)toupper((unsigned char)tok[t][0]) << "\"" << (type == 'n' ? " for nucleotide sequences.\n" : " for protein sequences.\n");
+                exit(1);
+            }
+            idx.push_back(li);
+        }
+        for (size_t t = (size_t)nLetters; t < tok.size(); ++t) {
+            const size_t k = t - (size_t)nLetters;
+            const size_t x = k / (size_t)nLetters, y = k % (size_t)nLetters;
+            if (x >= idx.size()) break;
+            scoringMatrix[idx[x]][idx[y]] = std::stof(tok[t]);
+        }
+        if (nLetters == matrixSize - 1) {
+            float Nscore = 0;
+            for (int i = 0; i < nLetters; ++i) Nscore += scoringMatrix[i][i];
+            Nscore = o.wildcard ? (Nscore / nLetters) : 0.0f;
+            for (int i = 0; i < matrixSize; ++i) { scoringMatrix[i][matrixSize - 1] = Nscore; scoringMatrix[matrixSize - 1][i] = Nscore; }
+        }
+    } else if (type == 'n') {
         for (int i = 0; i < 5; ++i)
             for (int j = 0; j < 5; ++j) {
                 if (i == 4 || j == 4) scoringMatrix[i][j] = o.wildcard ? o.match : 0.0f;
@@ -89,16 +180,21 @@ Params::Params(const Option &o, char type)
                 else scoringMatrix[i][j] = o.mismatch;
             }
     } else {
-        if (o.blosum != 62) std::cerr << "WARNING: only BLOSUM62 is built in; using BLOSUM62.\n";
+        int blosumType = o.blosum;
+        if (blosumType != 45 && blosumType != 62 && blosumType != 80) {
+            std::cerr << "WARNING: Invalid BLOSUM matrix \"" << blosumType << "\". Please choose from 45, 62, or 80.\nUsing default: BLOSUM62.\n";
+            blosumType = 62;
+        }
         float Nscore = 0;
-        for (int i = 0; i < 20; ++i) Nscore += kBlosum62[i][i];
+        for (int i = 0; i < 20; ++i) Nscore += kBlosum62[i][i];      // (the reference takes the BLOSUM62 diagonal whichever table is selected, :120-122)
         Nscore /= 20;
         for (int i = 0; i < 21; ++i) {
             scoringMatrix[i][20] = o.wildcard ? 5 * Nscore : 0.0f;
             scoringMatrix[20][i] = o.wildcard ? 5 * Nscore : 0.0f;
         }
+        const int8_t(*tab)[20] = (blosumType == 45) ? kBlosum45 : (blosumType == 80) ? kBlosum80 : kBlosum62;
         for (int i = 0; i < 20; ++i)
-            for (int j = 0; j < 20; ++j) scoringMatrix[i][j] = 5 * kBlosum62[i][j];
+            for (int j = 0; j < 20; ++j) scoringMatrix[i][j] = 5.0f * tab[i][j];
     }
 }
 

@@ -126,9 +126,10 @@ struct Option {
     float gapEnds = 0;
     bool wildcard = false;
     int blosum = 62;
+    std::string matrixFile;      // -x / --matrix: user-defined substitution matrix (scoring-matrix.cpp:137-199)
 };
 
-// reference msa.hpp:98-109, ctor scoring-matrix.cpp:81-236 (built-in matrices only)
+// reference msa.hpp:98-109, ctor scoring-matrix.cpp:81-199
 struct Params {
     float gapOpen, gapExtend, gapBoundary, xdrop, scaleFactor = 1;
     float **scoringMatrix;
