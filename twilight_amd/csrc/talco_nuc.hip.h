@@ -47,6 +47,7 @@ struct NArgs {
     float gap_open, gap_extend, gap_char;
     int32_t xdrop, flen, marker;
     float M[25];              // scoreMatrix[l][m] row-major 5x5
+    unsigned long long *team; // speculative tile start (SPEC kernels): [n_items][16] mailbox words, zeroed by the host
 };
 
 typedef float nuc_f4 __attribute__((ext_vector_type(4)));
@@ -115,6 +116,41 @@ __device__ __forceinline__ bool div_guard_bad(float x)
     return (x != 0.0f) && !(ax >= 9.5367431640625e-07f && ax <= 1073741824.0f);
 }
 
+// ---- speculative tile start (SPEC = true) ----
+// A tile runs ~1450 diagonals: 1024 up to the marker and ~420 more until every surviving cell agrees on the cell of the marker
+// diagonal all paths run through (TALCO-XDrop.cpp:585-612); the next tile starts there with scores at zero (:615-655, :77-106), so it
+// depends on the POSITION of that cell only.  With fewer pairs than compute units, two workgroups work on one pair: they take the tiles
+// in turn, and the one whose turn is next starts as soon as the other reaches its marker, from the best-scoring cell of the marker
+// diagonals (the guess).  When the running tile has converged its workgroup publishes the true position: the partner carries on if the
+// guess was right and restarts from the true position otherwise -- a wrong guess costs nothing but the idle workgroup's time, and
+// the result is the same either way.  Mailbox words (global memory, one 8-byte agent-scope atomic each, tag = tile + 1):
+//   guess[t & 3], truth[t & 3] = tag:16 | flags:16 | ref_idx:16 | qry_idx:16      pos[t & 3] = tag:16 | 0:16 | output offset:32
+constexpr unsigned kTeamLast = 1u, kTeamErr = 2u;
+constexpr int kTeamWords = 16, kTeamGuess = 0, kTeamTruth = 4, kTeamPos = 8, kTeamStat = 12;
+__device__ __forceinline__ unsigned long long team_word(unsigned tag, unsigned flags, unsigned hi, unsigned lo)
+{
+    return ((unsigned long long)(tag & 0xFFFFu) << 48) | ((unsigned long long)(flags & 0xFFFFu) << 32) | ((unsigned long long)(hi & 0xFFFFu) << 16) | (lo & 0xFFFFu);
+}
+__device__ __forceinline__ unsigned long long team_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void team_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane waits (bounded: ~2 s) until the word carries the tag; 0 = gave up (the caller turns that into errorType 3)
+__device__ __forceinline__ unsigned long long team_wait(const unsigned long long *p, unsigned tag, const unsigned long long *alt = nullptr)
+{
+    for (int spin = 0; spin < (1 << 21); ++spin) {
+        const unsigned long long v = team_load(p);
+        if ((unsigned)(v >> 48) == tag) return v;
+        if (alt) { const unsigned long long u = team_load(alt); if ((unsigned)(u >> 48) == tag) return u | (1ull << 47); }      // bit 47: "this is the guess"
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return 0ull;
+}
+// order-preserving key of a score for an integer maximum (the guess only: never part of a result)
+__device__ __forceinline__ unsigned score_key(float f)
+{
+    const unsigned b = (unsigned)__float_as_int(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 template <int W, int RPL>
 struct NCfg {
     static constexpr int NV = W * RPL;          // 64-row blocks resident at once
@@ -126,7 +162,7 @@ struct NCfg {
 
 // MM = matrix mode (host-selected from the matrix values, see talco_kernel): 0 general 5x5, 1 zero N row/column (4x4 core),
 // 2 mode 1 with the match / transition / transversion structure (three products per row letter).
-template <int W, int RPL, int MM, int MINW>
+template <int W, int RPL, int MM, int MINW, bool SPEC = false>
 __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
 {
     using C = NCfg<W, RPL>;
@@ -146,6 +182,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
     __shared__ ParBuf s_par[2];
     __shared__ int s_misc[4];
     __shared__ int8_t s_rev[2 * kMaxMarker + 16];
+    __shared__ unsigned long long s_team[4];      // SPEC: {broadcast word, decision of the last poll, best cell of diagonal marker-1, of diagonal marker}
     constexpr unsigned O_CD = (unsigned)offsetof(ParBuf, cd), O_EXCH = (unsigned)offsetof(ParBuf, exch), O_RED = (unsigned)offsetof(ParBuf, red),
                        O_CONV = (unsigned)offsetof(ParBuf, conv), O_TRASH = (unsigned)offsetof(ParBuf, trash);
 
@@ -157,10 +194,18 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
     const float xdropf = (float)a.xdrop;
     const float gc = a.gap_char;
 
+    int specRound = 0;
     for (;;) {
-        if (threadIdx.x == 0) s_misc[0] = atomicAdd(a.queue, 1);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        int item;
+        if constexpr (SPEC) {         // two workgroups per pair, no queue: workgroups 2t and 2t+1 are the team of item t
+            if (specRound++) break;
+            item = (int)(blockIdx.x >> 1);
+            __syncthreads();
+        } else {
+            if (threadIdx.x == 0) s_misc[0] = atomicAdd(a.queue, 1);
+            __syncthreads();
+            item = __builtin_amdgcn_readfirstlane(s_misc[0]);
+        }
         if (item >= a.n_items) break;
         const int pair = __builtin_amdgcn_readfirstlane(a.items[item]);
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
@@ -181,12 +226,53 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
         if (!last_tile && (R + Q > 65000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
         bool guardBad = false;
+        // SPEC: this workgroup runs the tiles of its parity; `confirmed` = the start of the tile in flight is the true one
+        unsigned long long *team = SPEC ? a.team + (size_t)item * kTeamWords : nullptr;
+        const int role = SPEC ? (int)(blockIdx.x & 1) : 0;
+        bool confirmed = true, teamExit = false, redo = false, iEnded = false;
+        if constexpr (SPEC) tile = role;
+        // broadcast of a 64-bit word from thread 0 to the workgroup
+        auto bcast = [&](unsigned long long v) __attribute__((always_inline)) -> unsigned long long {
+            if (threadIdx.x == 0) s_team[0] = v;
+            __syncthreads();
+            const unsigned long long r = s_team[0];
+            __syncthreads();
+            return (unsigned long long)__builtin_amdgcn_readfirstlane((int)(r & 0xFFFFFFFFu)) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32);
+        };
+        // SPEC: wait for the true start of tile `tile` and compare it with the start in use.  Returns 0 confirmed, 1 restart from
+        // (ref_idx, qry_idx) as updated here, 2 the alignment is over (the partner finished or failed)
+        auto settle = [&]() __attribute__((always_inline)) -> int {
+            unsigned long long v = 0ull;
+            if (threadIdx.x == 0) v = team_wait(&team[kTeamTruth + (tile & 3)], (unsigned)(tile + 1));
+            v = bcast(v);
+            if (v == 0ull) { err = 3; return 2; }
+            const unsigned fl = (unsigned)(v >> 32) & 0xFFFFu;
+            if (fl & (kTeamLast | kTeamErr)) return 2;
+            const int tr = (int)((v >> 16) & 0xFFFFu), tq = (int)(v & 0xFFFFu);
+            if (tr == ref_idx && tq == qry_idx) { if (threadIdx.x == 0) atomicAdd(&team[kTeamStat + 1], 1ull); return 0; }
+            ref_idx = tr; qry_idx = tq;
+            return 1;
+        };
 #ifdef TWL_KERNEL_STAMPS
         unsigned long long st_slots = 0, st_bar = 0, st_post = 0, st_n = 0, st_act = 0, st_exit = 0, st_setup = 0;
         const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
+            if constexpr (SPEC) {
+                if (!redo && tile > 0) {       // the start of this tile: the true one if it is known already, else the partner's guess
+                    unsigned long long v = 0ull;
+                    if (threadIdx.x == 0) v = team_wait(&team[kTeamTruth + (tile & 3)], (unsigned)(tile + 1), &team[kTeamGuess + (tile & 3)]);
+                    v = bcast(v);
+                    const unsigned fl = (unsigned)(v >> 32) & 0x7FFFu;
+                    if (v == 0ull) { err = 3; teamExit = true; }
+                    else if (!(v & (1ull << 47)) && (fl & (kTeamLast | kTeamErr))) teamExit = true;
+                    else { ref_idx = (int)((v >> 16) & 0xFFFFu); qry_idx = (int)(v & 0xFFFFu); confirmed = !(v & (1ull << 47)); }
+                }
+                redo = false;
+                if (teamExit) { last_tile = true; }
+            }
+            if (!(SPEC && teamExit)) {
             const int refLen = R - ref_idx, qLen = Q - qry_idx;
             const int fLen = min(a.flen, min(refLen, qLen));                          // :258
             // one unsigned compare per step covers "band empty", "wider than fLen" and (conservatively) "outgrew the window"
@@ -201,7 +287,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             uint32_t tbacc[RPL];
             bool q5any[RPL];
 
-            auto load_q = [&](int r) {
+            auto load_q = [&](int r) __attribute__((always_inline)) {
                 const int i = 64 * blk[r] + lane;
                 float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
                 if (qry_idx + i < Q) { c0 = colsQ[2 * (size_t)(qry_idx + i)]; c1 = colsQ[2 * (size_t)(qry_idx + i) + 1]; }
@@ -228,7 +314,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                                  div_guard_bad(c1.y);
                 guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
             };
-            auto load_ring_block = [&](int B) {
+            auto load_ring_block = [&](int B) __attribute__((always_inline)) {
                 const int col = 64 * B + lane;
                 const int slot = (B % NB) * 64 + lane;
                 float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
@@ -239,7 +325,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                                  div_guard_bad(c1.y);
                 guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
             };
-            auto ring_addr = [&](int r, int k) {      // ((k - 64*blk - lane) mod CAP) * 16
+            auto ring_addr = [&](int r, int k) __attribute__((always_inline)) {      // ((k - 64*blk - lane) mod CAP) * 16
                 int rs = (k - 64 * blk[r] - lane) % CAP;
                 rs += (rs < 0) ? CAP : 0;
                 ra[r] = (unsigned)rs * 16u + lds_off(s_ring);
@@ -261,6 +347,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 s_par[0].red[0] = s_par[1].red[0] = (unsigned)__float_as_int(-inf);
                 s_par[0].red[1] = s_par[0].red[2] = s_par[1].red[1] = s_par[1].red[2] = 0u;
                 for (int t = 0; t < 2; ++t) { s_par[t].conv[0] = 0x7fffffff; s_par[t].conv[1] = (int)0x80000000; s_par[t].conv[2] = 0; }
+                s_team[1] = 0ull; s_team[2] = 0ull; s_team[3] = 0ull;
             }
             __syncthreads();
 
@@ -281,7 +368,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             const int kEnd = refLen + qLen - 1;
             int k = 0;
             int tile_err = 0;
-            bool go = true, conv_logic = false;
+            bool go = true, conv_logic = false, aborted = false;
             bool spec = true;                            // the next diagonal may be a "special" one (k == 0, or tile 0's first row/column)
             bool tbPending = false;
             unsigned tbOff = (unsigned)lane * 4u;        // byte offset of this lane's word in the current group of 8 diagonals (slot 0)
@@ -303,7 +390,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
 
             // One diagonal.  PH: 0 = A (k < marker-1), 1 = B (k == marker-1 or marker), 2 = C (k > marker).
             // Ends the loops by clearing `go`: tile_err on a stop condition, conv_logic when the tile ended by convergence (:609-612).
-            auto step = [&](auto PHtag) {
+            auto step = [&](auto PHtag) __attribute__((always_inline)) {
                 constexpr int PH = decltype(PHtag)::value;
                 constexpr bool TB = (PH != 2), CONV = (PH != 0);
                 TWL_STAMP(t_head);
@@ -438,6 +525,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                             if (PH == 2 || k == marker) { if (inband) lds_st<int>(vcur + 4u * (unsigned)(i - vL) + O_CD, CDn); }
                         }
                         S1[r] = Sv; I1[r] = Iv; D1[r] = Dv;
+                        if constexpr (SPEC && PH == 1) {      // the guess for the next tile's start: best cell of diagonal marker-1 / marker
+                            if (inband && Sv > -inf) {
+                                const unsigned long long key = ((unsigned long long)score_key(Sv) << 32) | (unsigned)i;
+                                asm volatile("ds_max_u64 %0, %1" ::"v"(lds_off(&s_team[(k == marker) ? 3 : 2])), "v"(key) : "memory");
+                            }
+                        }
                         // ---- reductions of this diagonal (:501-503, :563-583), all lanes issuing, see vTrash ----
                         const float Sin = inband ? Sv : -inf;             // out-of-band lanes take no part
                         lds_max_f32_off<O_RED>((Sin > msp) ? vcur : vTrashRed, Sin);
@@ -466,7 +559,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                     if (ra[r] == lds_off(s_ring) + CAP * 16u) ra[r] = lds_off(s_ring);
                 }
                 if constexpr (TB) tbPending = true;
-                if ((k & 7) == 7 || (PH == 1 && k == marker)) {
+                const bool hook = ((k & 7) == 7 || (PH == 1 && k == marker));
+                if (hook) {
                     if constexpr (TB) {
 #pragma unroll
                         for (int r = 0; r < RPL; ++r) {
@@ -576,14 +670,75 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             {
                 using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
                 const int kA = min(kEnd, marker - 1);
+                // SPEC, while the tile runs on a guess: every 32 diagonals one lane looks whether the partner has published the true start;
+                // the verdict goes through LDS so that every wave leaves the loop at the same diagonal
+                auto poll = [&]() __attribute__((always_inline)) {
+                    if (threadIdx.x == 0) {
+                        const unsigned long long pv = team_load(&team[kTeamTruth + (tile & 3)]);
+                        unsigned long long d = 0ull;
+                        if ((unsigned)(pv >> 48) == (unsigned)(tile + 1)) {
+                            const unsigned fl = (unsigned)(pv >> 32) & 0xFFFFu;
+                            d = ((fl & (kTeamLast | kTeamErr)) || (int)((pv >> 16) & 0xFFFFu) != ref_idx || (int)(pv & 0xFFFFu) != qry_idx) ? 2ull : 1ull;
+                        }
+                        s_team[1] = d;
+                        if (d == 1ull) atomicAdd(&team[kTeamStat + 1], 1ull);
+                    }
+                    __syncthreads();
+                    const int d = __builtin_amdgcn_readfirstlane((int)s_team[1]);
+                    __syncthreads();
+                    if (d == 1) confirmed = true;
+                    else if (d == 2) { go = false; aborted = true; }
+                };
+                if constexpr (SPEC) {
+                    while (go && k < kA) {
+                        const int kc = confirmed ? kA : min(kA, (k | 31) + 1);
+                        while (go && k < kc) step(T0{});
+                        if (go && !confirmed) poll();
+                    }
+                } else
                 while (go && k < kA) step(T0{});
                 const int kB = min(kEnd, marker + 1);
                 // (set here rather than with the tile: through phase A these are constants, not live registers; :306-308)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) { CS1[r] = -1; CI1[r] = kIB; CD1[r] = kDB; LCS2[r] = -1; }
+                int sres = -1;
+                if constexpr (SPEC) {          // the marker is not passed on a guess: the guess for the NEXT tile must rest on a true start
+                    if (go && !confirmed && k < kB) {
+                        sres = settle();
+                        if (sres == 0) confirmed = true; else { go = false; aborted = true; }
+                    }
+                }
                 while (go && k < kB) step(T1{});
+                if constexpr (SPEC) {
+                    if (go && k == marker + 1 && k < kEnd) {     // both marker diagonals are done: tell the partner where the next tile probably starts
+                        if (threadIdx.x == 0) {
+                            const unsigned long long b0 = s_team[2], b1 = s_team[3];      // best cell of diagonal marker-1, marker
+                            // a run of matches touches the diagonals of one parity only: the cell all paths will agree on lies on the
+                            // marker diagonal or on the one before it (state 3, :520-524), whichever holds the better score
+                            const bool onMarker = (unsigned)(b1 >> 32) >= (unsigned)(b0 >> 32);
+                            const int gq = (int)((onMarker ? b1 : b0) & 0xFFFFFFFFu), gr = (onMarker ? marker : marker - 1) - gq;
+#ifdef TWL_SPEC_DEBUG
+                            printf("tile %d start %d %d: best(marker-1) key %x row %d, best(marker) key %x row %d -> guess +%d +%d\n", tile, ref_idx, qry_idx, (unsigned)(b0 >> 32), (int)(b0 & 0xFFFFFFFFu), (unsigned)(b1 >> 32), (int)(b1 & 0xFFFFFFFFu), gr, gq);
+#endif
+                            if ((b0 | b1) != 0ull && gr >= 0 && ref_idx + gr < 65536 && qry_idx + gq < 65536) {
+                                team_store(&team[kTeamGuess + ((tile + 1) & 3)], team_word((unsigned)(tile + 2), 0u, (unsigned)(ref_idx + gr), (unsigned)(qry_idx + gq)));
+                                atomicAdd(&team[kTeamStat + 0], 1ull);
+                            }
+                        }
+                    }
+                }
                 while (go && k < kEnd) step(T2{});
+                if constexpr (SPEC) {
+                    if (aborted || !confirmed) {
+                        if (sres < 0 || sres == 0) sres = settle();
+                        if (sres == 1) { redo = true; confirmed = true; }          // run this tile again, from the true start
+                        else if (sres == 2) { teamExit = true; last_tile = true; }   // the alignment is over
+                        else confirmed = true;
+                    } else sres = 0;
+                    aborted = (sres != 0);
+                }
             }
+            if (!(SPEC && aborted)) {
             const int last_k = conv_logic ? k : k - 1;
             steps_left -= (long long)(last_k + 1);
             const unsigned tile_cells = (unsigned)__builtin_amdgcn_readfirstlane((int)vcells);
@@ -628,15 +783,30 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                 conv_q = qLen - 1; conv_r = refLen - 1; start_k = last_k; tb_state = 0; last_tile = true;
             }
             if (bad) { err = 3; break; }
+#ifdef TWL_SPEC_DEBUG
+            if (threadIdx.x == 0) printf("tile %d start %d %d: true +%d +%d state %d last_k %d conv_logic %d\n", tile, ref_idx, qry_idx, conv_r, conv_q, tb_state, last_k, (int)conv_logic);
+#endif
             ref_idx += conv_r; qry_idx += conv_q;                             // :654-655
             if (R - ref_idx < 0 || Q - qry_idx < 0) { err = 3; break; }       // :659-668
             int tailDir = 0, tailLen = 0;
             if (ref_idx == R - 1 && qry_idx < Q - 1) { tailDir = 1; tailLen = Q - qry_idx - 1; last_tile = true; }   // :671-674
             if (qry_idx == Q - 1 && ref_idx < R - 1) { tailDir = 2; tailLen = R - ref_idx - 1; last_tile = true; }   // :675-678
             if (ref_idx == R - 1 && qry_idx == Q - 1) last_tile = true;       // :679
+            if constexpr (SPEC) {       // the true start of the next tile (or: there is none), before the traceback: the partner is waiting for it
+                if (threadIdx.x == 0)
+                    team_store(&team[kTeamTruth + ((tile + 1) & 3)], team_word((unsigned)(tile + 2), last_tile ? kTeamLast : 0u, (unsigned)ref_idx, (unsigned)qry_idx));
+            }
 
             __syncthreads();   // all traceback-pointer stores of this tile are complete and visible
             if (w == 0) {
+                if constexpr (SPEC) {   // where this tile's segment goes: after the previous tile's, which the partner wrote
+                    if (tile > 0) {
+                        unsigned long long pv = 0ull;
+                        if (lane == 0) pv = team_wait(&team[kTeamPos + (tile & 3)], (unsigned)(tile + 1));
+                        pos = __builtin_amdgcn_readfirstlane((int)(pv & 0xFFFFFFFFu));
+                        if (__builtin_amdgcn_readfirstlane((int)(pv >> 32)) == 0) err = 3;
+                    }
+                }
                 int n = 0;
                 if (lane == 0) {   // Traceback, :134-231, addressed by (diagonal, row) instead of a ragged offset
                     int kk2 = start_k, ii = conv_q, qi = conv_q, ri = conv_r, st = tb_state % 3;
@@ -675,13 +845,29 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                     pos += cnt + tailLen;
                 }
                 if (lane == 0) { s_misc[2] = err; s_misc[3] = pos; }
+                if constexpr (SPEC) {
+                    if (lane == 0 && err == 0 && !last_tile) team_store(&team[kTeamPos + ((tile + 1) & 3)], ((unsigned long long)(unsigned)(tile + 2) << 48) | (unsigned)pos);
+                }
             }
             __syncthreads();
             err = __builtin_amdgcn_readfirstlane(s_misc[2] == 3 ? 3 : err);
             pos = __builtin_amdgcn_readfirstlane(s_misc[3]);
+            iEnded = last_tile;
             if (err != 0) break;
-            ++tile;
+            tile += SPEC ? 2 : 1;
+            }      // (tile not thrown away)
+            }      // (tile started)
         }
+        if constexpr (SPEC) {
+            if (err != 0 && !teamExit) {       // this workgroup fails the pair: tell the partner (it may be waiting for a start)
+                iEnded = true;
+                if (threadIdx.x == 0) {
+                    team_store(&team[kTeamTruth + ((tile + 1) & 3)], team_word((unsigned)(tile + 2), kTeamErr, 0u, 0u));
+                    team_store(&team[kTeamTruth + ((tile + 2) & 3)], team_word((unsigned)(tile + 3), kTeamErr, 0u, 0u));      // (whichever tile it is about to ask for)
+                }
+            }
+            if (R <= 0 || Q <= 0) iEnded = (role == 0);
+        } else iEnded = true;
 
 #ifdef TWL_KERNEL_STAMPS
         if (a.dbg && lane == 0 && pair == 0) {      // per wave of the workgroup that aligned pair 0: cycle sums per segment
@@ -693,9 +879,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
 #endif
         __syncthreads();
         if (threadIdx.x == 0) {
-            a.err[pair] = (int16_t)err;
-            a.aln_len[pair] = (err == 0) ? pos : 0;
-            a.cells[pair] = cells;
+            if (iEnded || err != 0) {
+                a.err[pair] = (int16_t)err;
+                a.aln_len[pair] = (err == 0) ? pos : 0;
+            }
+            if constexpr (SPEC) atomicAdd(&a.cells[pair], cells);       // (zeroed by the host) both workgroups add their tiles
+            else a.cells[pair] = cells;
             if (a.dbg) {
                 int32_t *g = a.dbg + 16 * (size_t)pair;
                 g[0] = tile; g[1] = dbg_lastk; g[2] = dbg_conv; g[3] = dbg_L; g[4] = dbg_U; g[5] = ref_idx; g[6] = qry_idx;

@@ -68,6 +68,7 @@ struct Device {
     int num_cu = 0;
     Buf cols, tb, cells, queue, items, errs, dbg;
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
+    Buf team;                                                                    // mailboxes of the speculative tile start
     std::vector<int32_t> dbg_host;
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
@@ -154,14 +155,14 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 }
 
 // The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
-template <int W, int RPL, int MM, int MINW>
+template <int W, int RPL, int MM, int MINW, bool SPEC = false>
 int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};      // one value per template instantiation
     if (cached.load() == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, MM, MINW>), CfgT::THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, MM, MINW, SPEC>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
     int blocks_per_cu = cached.load();
@@ -169,6 +170,10 @@ int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t 
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * blocks_per_cu);
     if (grid < 1) grid = 1;
+    if (SPEC) {      // two workgroups per pair that wait for each other: all of them must be resident at once
+        grid = 2 * n_items;
+        if (grid > d->num_cu * blocks_per_cu) { g_err = "speculative launch larger than the device"; return TWL_ERR_BAD_ARGUMENT; }
+    }
     const size_t tbw = ((size_t)(base.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
     int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
@@ -180,9 +185,23 @@ int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t 
     a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
     for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
     HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    if (SPEC) {
+        if ((rc = d->team.ensure((size_t)n_items * twl::kTeamWords * sizeof(unsigned long long)))) return rc;
+        HIP_TRY(hipMemsetAsync(d->team.p, 0, (size_t)n_items * twl::kTeamWords * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(a.cells, 0, (size_t)base.n_pairs_total * sizeof(unsigned long long), st));
+        a.team = (unsigned long long *)d->team.p;
+    }
     TRACE("launch nuc W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
-    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, MM, MINW>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, MM, MINW, SPEC>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
+    if (SPEC && (dbg_on() || getenv("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
+        std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
+        HIP_TRY(hipMemcpyAsync(tw.data(), d->team.p, tw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long g = 0, h = 0;
+        for (int t = 0; t < n_items; ++t) { g += tw[(size_t)t * twl::kTeamWords + twl::kTeamStat]; h += tw[(size_t)t * twl::kTeamWords + twl::kTeamStat + 1]; }
+        fprintf(stderr, "[twl spec] %d pairs: %llu tile starts guessed, %llu confirmed\n", n_items, g, h);
+    }
     *grid_out = grid;
     return TWL_OK;
 }
@@ -332,7 +351,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const bool lean = (c != "w8r2") && divOk;
         // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
         const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu && !getenv("TWL_NO_FEW"));
-        if (lean && few) {
+        // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
+        const bool spec = lean && few && mm == 2 && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC");
+        if (spec) rc = launch_nuc<16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
+        else if (lean && few) {
             if (mm == 2) rc = launch_nuc<16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
             else if (mm == 1) rc = launch_nuc<16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
             else rc = launch_nuc<16, 1, 0, 1>(d, st, a, items, n_pairs, &grid, &window);
@@ -467,7 +489,7 @@ void twl_shutdown(void)
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24,
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
