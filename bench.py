@@ -201,9 +201,16 @@ def wallclock_to_msa(tree, fasta, typ, d):
 
 
 def variant_of(pairs, num_cu, P):
+    """The DP kernel instantiation the library launches for a level of `pairs` pairs (twl_align.hip, run_device): two workgroups per pair
+    with speculative tile start up to CUs/2 pairs, one 16-wave workgroup per pair up to CUs (nucleotide) / CUs/2 (protein, precomputed
+    scores), the throughput geometry beyond."""
     if P == 22:
-        return "talco_kernel<22, 8, 2, ..., 4> (precomputed column scores)" if pairs <= max(1, num_cu // 2) else "talco_kernel<22, 8, 2, ..., 3> (sparse column scores)"
-    return "talco_nuc_kernel<16, 1, 2, 1>" if pairs <= num_cu else "talco_nuc_kernel<8, 2, 2, 4>"
+        if pairs <= max(1, num_cu // 2):
+            return "talco_lean_kernel<22, 16, 1, 4, 1, true> (precomputed column scores, speculative tile start)"
+        return "talco_lean_kernel<22, 16, 1, 3, 1, false> (sparse column scores)"
+    if 2 * pairs <= num_cu:
+        return "talco_lean_kernel<6, 16, 1, 2, 1, true> (speculative tile start)"
+    return "talco_lean_kernel<6, 16, 1, 2, 1, false>" if pairs <= num_cu else "talco_lean_kernel<6, 8, 2, 2, 4, false>"
 
 
 def main():

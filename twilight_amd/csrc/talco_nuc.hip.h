@@ -28,7 +28,7 @@
 namespace twl {
 
 struct NArgs {
-    const float *cols;        // packed columns [pair][2][seq_len][8]: f0..f5, gapOpen, gapExtend
+    const float *cols;        // packed columns [pair][2][seq_len][P+2]: f0..f(P-1), gapOpen, gapExtend (32 B for P = 6, 96 B for P = 22)
     const int32_t *len;       // [pair][2]
     const int32_t *num;       // [pair][2]
     int8_t *aln;              // [pair][2*seq_len]
@@ -46,7 +46,12 @@ struct NArgs {
     int32_t step_slack;       // watchdog: a pair may run at most (R+Q+2)*((R+Q)/(marker-1)+4) + step_slack diagonals in total
     float gap_open, gap_extend, gap_char;
     int32_t xdrop, flen, marker;
-    float M[25];              // scoreMatrix[l][m] row-major 5x5
+    float M[25];              // nucleotide scoreMatrix[l][m] row-major 5x5 (the protein matrix comes through M24)
+    const float *M24;         // protein: [21][24] matrix rows padded to 24 floats (device memory)
+    // protein, few pairs (matrix mode 4): column scores precomputed by score_matrix_kernel, diagonal-major per pair:
+    // sim[sim_off[pair] + (i + j) * pitch + i] with i = query row, j = reference column, pitch = (Q + 63) & ~63
+    const float *sim;
+    const long long *sim_off;
     unsigned long long *team; // speculative tile start (SPEC kernels): [n_items][16] mailbox words, zeroed by the host
 };
 
@@ -160,16 +165,25 @@ struct NCfg {
     static constexpr int THREADS = 64 * W;
 };
 
-// MM = matrix mode (host-selected from the matrix values, see talco_kernel): 0 general 5x5, 1 zero N row/column (4x4 core),
-// 2 mode 1 with the match / transition / transversion structure (three products per row letter).
-template <int W, int RPL, int MM, int MINW, bool SPEC = false>
-__global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
+// P = 6 (nucleotide) or 22 (protein).  MM = column-score mode, host-selected (every mode of an alphabet computes the same sums, see
+// talco_kernel): nucleotide 0 general 5x5, 1 zero N row/column (4x4 core), 2 mode 1 with the match / transition / transversion
+// structure (three products per row letter); protein 3 loop over the non-zero letters of the reference column, 4 scores
+// precomputed by score_matrix_kernel for the whole R x Q matrix (launches with few pairs: the other CUs are idle anyway).
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false>
+__global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 {
+    static_assert((P == 6 && MM >= 0 && MM <= 2) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
     using C = NCfg<W, RPL>;
     constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
-    constexpr int NQM = (MM == 2) ? 12 : (MM == 1 ? 16 : 25);
+    constexpr int NQM = (MM == 2) ? 12 : (MM == 1 ? 16 : (MM == 0 ? 25 : 1));
+    constexpr int F4 = (P + 2) / 4;                       // float4 per packed column: 2 or 6
+    constexpr bool SPARSE = (MM == 3), PRESIM = (MM == 4);
+    constexpr int RP = PRESIM ? 1 : F4;                  // ring planes: presim keeps only {X letter, gap, gapOpen, gapExtend}
+    constexpr int QN = PRESIM ? 1 : P;                   // query letters kept per row
 
-    __shared__ float4 s_ring[2 * CAP];        // plane-major: [0][slot] = f0..f3, [1][slot] = f4, f5(gap), gapOpen, gapExtend
+    __shared__ float4 s_ring[RP * CAP];       // plane-major: plane t of a column = its floats 4t .. 4t+3; the last plane = {.., gap letter, gapOpen, gapExtend}
+    __shared__ uint32_t s_rmask[SPARSE ? CAP : 1];        // protein sparse: non-zero-letter bitmask of every ring column
+    __shared__ float4 s_M4[SPARSE ? 21 * 6 : 1];          // protein sparse: matrix rows padded to 24 floats
     // everything that alternates with the parity of the diagonal sits in one struct per parity, so that ONE register
     // (vcur / vprev: the LDS address of the current / previous diagonal's struct) selects it and the rest is an immediate offset
     struct ParBuf {
@@ -193,6 +207,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
     const float gc = a.gap_char;
+    if constexpr (SPARSE) {
+        for (int t = threadIdx.x; t < 21 * 6; t += C::THREADS) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
+    }
 
     int specRound = 0;
     for (;;) {
@@ -212,8 +229,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
         const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
         const bool denomOne = (denom == 1.0f);
         const float rden = refined_rcp(denom);
-        const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * 8);
-        const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * 8);
+        const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * (P + 2));
+        const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * (P + 2));
+        const float *simP = PRESIM ? a.sim + a.sim_off[pair] : nullptr;
+        const int simPitch = (Q + 63) & ~63;
         int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
 
         // NOTE on control flow (as in talco_kernel): no `continue`, and every single-lane block is followed by a workgroup
@@ -281,7 +300,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
             // ---- per-slot state ----
             float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
             int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
-            float qv[RPL][6], gopq[RPL], gexq[RPL], qM[RPL][NQM];
+            float qv[RPL][QN], gopq[RPL], gexq[RPL], qM[RPL][NQM];
+            float simNext[RPL];            // presim: the score of this row on the NEXT diagonal, loaded one diagonal ahead
+            int simFor[RPL];               // ... and the diagonal it belongs to
+            const int simK0 = ref_idx + qry_idx;   // global anti-diagonal of the tile's first cell
             int blk[RPL];
             unsigned ra[RPL];              // byte address of this lane's reference column in plane 0 of the ring
             uint32_t tbacc[RPL];
@@ -289,41 +311,73 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
 
             auto load_q = [&](int r) __attribute__((always_inline)) {
                 const int i = 64 * blk[r] + lane;
-                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-                if (qry_idx + i < Q) { c0 = colsQ[2 * (size_t)(qry_idx + i)]; c1 = colsQ[2 * (size_t)(qry_idx + i) + 1]; }
-                qv[r][0] = c0.x; qv[r][1] = c0.y; qv[r][2] = c0.z; qv[r][3] = c0.w; qv[r][4] = c1.x; qv[r][5] = c1.y;
-                gopq[r] = c1.z; gexq[r] = c1.w;
-                // first rounding of (q[m]*M[l][m])*r[l], :386
-                if constexpr (MM == 2) {
-                    const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) { qM[r][m] = qv[r][m] * mA; qM[r][4 + m] = qv[r][m] * mB; qM[r][8 + m] = qv[r][m] * mC; }
-                } else if constexpr (MM == 1) {
-#pragma unroll
-                    for (int l = 0; l < 4; ++l)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) qM[r][4 * l + m] = qv[r][m] * a.M[5 * l + m];
+                const bool ok = qry_idx + i < Q;
+                if constexpr (PRESIM) {
+                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) c = colsQ[F4 * (size_t)(qry_idx + i) + (F4 - 1)];
+                    gopq[r] = c.z; gexq[r] = c.w;
+                    q5any[r] = false;
+                    simFor[r] = -1;
                 } else {
+                    float cb[4 * F4];
 #pragma unroll
-                    for (int l = 0; l < 5; ++l)
+                    for (int t = 0; t < F4; ++t) {
+                        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) c = colsQ[F4 * (size_t)(qry_idx + i) + t];
+                        cb[4 * t] = c.x; cb[4 * t + 1] = c.y; cb[4 * t + 2] = c.z; cb[4 * t + 3] = c.w;
+                    }
 #pragma unroll
-                        for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = qv[r][m] * a.M[5 * l + m];
+                    for (int t = 0; t < P; ++t) qv[r][t] = cb[t];
+                    gopq[r] = cb[P]; gexq[r] = cb[P + 1];
+                    // first rounding of (q[m]*M[l][m])*r[l], :386
+                    if constexpr (MM == 2) {
+                        const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) { qM[r][m] = qv[r][m] * mA; qM[r][4 + m] = qv[r][m] * mB; qM[r][8 + m] = qv[r][m] * mC; }
+                    } else if constexpr (MM == 1) {
+#pragma unroll
+                        for (int l = 0; l < 4; ++l)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) qM[r][4 * l + m] = qv[r][m] * a.M[5 * l + m];
+                    } else if constexpr (MM == 0) {
+#pragma unroll
+                        for (int l = 0; l < 5; ++l)
+#pragma unroll
+                            for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = qv[r][m] * a.M[5 * l + m];
+                    }
+                    q5any[r] = __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
+                    bool bad = false;
+#pragma unroll
+                    for (int t = 0; t < P; ++t) bad = bad | div_guard_bad(cb[t]);
+                    guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
                 }
-                q5any[r] = __builtin_amdgcn_ballot_w64(c1.y != 0.0f) != 0ull;
-                const bool bad = div_guard_bad(c0.x) | div_guard_bad(c0.y) | div_guard_bad(c0.z) | div_guard_bad(c0.w) | div_guard_bad(c1.x) |
-                                 div_guard_bad(c1.y);
-                guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
             };
             auto load_ring_block = [&](int B) __attribute__((always_inline)) {
                 const int col = 64 * B + lane;
                 const int slot = (B % NB) * 64 + lane;
-                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-                if (col < refLen) { c0 = colsR[2 * (size_t)(ref_idx + col)]; c1 = colsR[2 * (size_t)(ref_idx + col) + 1]; }
-                s_ring[slot] = c0;
-                s_ring[CAP + slot] = c1;
-                const bool bad = div_guard_bad(c0.x) | div_guard_bad(c0.y) | div_guard_bad(c0.z) | div_guard_bad(c0.w) | div_guard_bad(c1.x) |
-                                 div_guard_bad(c1.y);
-                guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
+                const bool ok = col < refLen;
+                if constexpr (PRESIM) {
+                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) c = colsR[F4 * (size_t)(ref_idx + col) + (F4 - 1)];
+                    s_ring[slot] = c;
+                } else {
+                    bool bad = false;
+                    uint32_t mk = 0;
+#pragma unroll
+                    for (int t = 0; t < F4; ++t) {
+                        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) c = colsR[F4 * (size_t)(ref_idx + col) + t];
+                        s_ring[t * CAP + slot] = c;
+                        const float f[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (4 * t + u < P) bad = bad | div_guard_bad(f[u]);
+                            if (SPARSE && 4 * t + u < 21) mk |= (f[u] != 0.0f) ? (1u << (4 * t + u)) : 0u;
+                        }
+                    }
+                    if constexpr (SPARSE) s_rmask[slot] = mk;
+                    guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
+                }
             };
             auto ring_addr = [&](int r, int k) __attribute__((always_inline)) {      // ((k - 64*blk - lane) mod CAP) * 16
                 int rs = (k - 64 * blk[r] - lane) % CAP;
@@ -426,51 +480,109 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_nuc_kernel(NArgs a)
                             const nuc_i2 e = lds_ld<nuc_i2>(vprev + exRel[r]);
                             eS = __int_as_float(e.x); eI = __int_as_float(e.y);
                         }
-                        const float4 c0 = lds_ld128(ra[r]);
-                        const float4 c1 = lds_ld128(ra[r] + CAP * 16);
-                        const float rc[5] = {c0.x, c0.y, c0.z, c0.w, c1.x};
-                        const float rg = c1.y, gopr = c1.z, gexr = c1.w;
-                        // ---- column score, :378-395 (order: per l the products summed left to right, accumulated over l) ----
-                        float numer;
-                        if constexpr (MM == 2) {
+                        const bool inband = (unsigned)(i - vL) <= vwidth1;
+                        float numer = 0.0f, rg, gopr, gexr;
+                        if constexpr (P == 6) {
+                            const float4 c0 = lds_ld128(ra[r]);
+                            const float4 c1 = lds_ld128(ra[r] + CAP * 16);
+                            const float rc[5] = {c0.x, c0.y, c0.z, c0.w, c1.x};
+                            rg = c1.y; gopr = c1.z; gexr = c1.w;
+                            // ---- column score, :378-395 (order: per l the products summed left to right, accumulated over l) ----
+                            if constexpr (MM == 2) {
 #pragma unroll
-                            for (int l = 0; l < 4; ++l) {
-                                float t[4];
+                                for (int l = 0; l < 4; ++l) {
+                                    float t[4];
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) t[m] = qM[r][((l == m) ? 0 : (((l ^ m) == 2) ? 4 : 8)) + m] * rc[l];
-                                const float sl = ((t[0] + t[1]) + t[2]) + t[3];
-                                numer = (l == 0) ? sl : numer + sl;
+                                    for (int m = 0; m < 4; ++m) t[m] = qM[r][((l == m) ? 0 : (((l ^ m) == 2) ? 4 : 8)) + m] * rc[l];
+                                    const float sl = ((t[0] + t[1]) + t[2]) + t[3];
+                                    numer = (l == 0) ? sl : numer + sl;
+                                }
+                            } else if constexpr (MM == 1) {
+#pragma unroll
+                                for (int l = 0; l < 4; ++l) {
+                                    float t[4];
+#pragma unroll
+                                    for (int m = 0; m < 4; ++m) t[m] = qM[r][4 * l + m] * rc[l];
+                                    const float sl = ((t[0] + t[1]) + t[2]) + t[3];
+                                    numer = (l == 0) ? sl : numer + sl;
+                                }
+                            } else {
+#pragma unroll
+                                for (int l = 0; l < 5; ++l) {
+                                    float t[5];
+#pragma unroll
+                                    for (int m = 0; m < 5; ++m) t[m] = qM[r][5 * l + m] * rc[l];
+                                    const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
+                                    numer = (l == 0) ? sl : numer + sl;
+                                }
                             }
-                        } else if constexpr (MM == 1) {
+                            if (q5any[r]) {
 #pragma unroll
-                            for (int l = 0; l < 4; ++l) {
-                                float t[4];
+                                for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
+                            }
+                            if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) t[m] = qM[r][4 * l + m] * rc[l];
-                                const float sl = ((t[0] + t[1]) + t[2]) + t[3];
-                                numer = (l == 0) ? sl : numer + sl;
+                                for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
+                            }
+                        } else if constexpr (SPARSE) {
+                            // protein column score, :409-433, over the NON-ZERO letters of the reference column only: a skipped letter has r[l] == 0,
+                            // so each of its products and their block sum are +-0, and adding +-0 to a running sum that started at +0 changes
+                            // nothing.  Letters in ascending order (the reference's order); per letter the tail m = 16..20 first, then the two
+                            // 8-lane blocks v[t] = (q[t]*M[l][t])*r[l] + (q[8+t]*M[l][8+t])*r[l] summed left to right.
+                            const float4 cl = lds_ld128(ra[r] + (F4 - 1) * CAP * 16);                    // {X letter, gap, gapOpen, gapExtend}
+                            rg = cl.y; gopr = cl.z; gexr = cl.w;
+                            const unsigned slotOff = ra[r] - lds_off(s_ring);                             // 16 * ring slot
+                            const uint32_t rmask = inband ? lds_ld<uint32_t>(lds_off(s_rmask) + (slotOff >> 2)) : 0u;
+                            uint32_t mk = rmask;
+                            while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+                                if (mk != 0u) {
+                                    const int l = __builtin_ctz(mk);
+                                    mk &= mk - 1u;
+                                    const float rl = lds_ld<float>(ra[r] + (unsigned)(l >> 2) * (CAP * 16) + (unsigned)(l & 3) * 4u);
+                                    float Mr[24];
+#pragma unroll
+                                    for (int t = 0; t < 6; ++t) {
+                                        const float4 c = s_M4[l * 6 + t];
+                                        Mr[4 * t] = c.x; Mr[4 * t + 1] = c.y; Mr[4 * t + 2] = c.z; Mr[4 * t + 3] = c.w;
+                                    }
+#pragma unroll
+                                    for (int m = 16; m < 21; ++m) numer += (rl * qv[r][m]) * Mr[m];
+                                    float v[8];
+#pragma unroll
+                                    for (int t = 0; t < 8; ++t) v[t] = (qv[r][t] * Mr[t]) * rl + (qv[r][8 + t] * Mr[8 + t]) * rl;
+                                    numer += ((((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) + v[5]) + v[6]) + v[7];
+                                }
+                            }
+                            if (q5any[r]) {              // (r[l]*q[gap])*gc is +-0 for the skipped letters, :432
+                                mk = rmask;
+                                while (__builtin_amdgcn_ballot_w64(mk != 0u) != 0ull) {
+                                    if (mk != 0u) {
+                                        const int l = __builtin_ctz(mk);
+                                        mk &= mk - 1u;
+                                        numer += (lds_ld<float>(ra[r] + (unsigned)(l >> 2) * (CAP * 16) + (unsigned)(l & 3) * 4u) * qv[r][P - 1]) * gc;
+                                    }
+                                }
+                            }
+                            if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
+#pragma unroll
+                                for (int m = 0; m < P - 1; ++m) numer += (rg * qv[r][m]) * gc;        // :433
                             }
                         } else {
-#pragma unroll
-                            for (int l = 0; l < 5; ++l) {
-                                float t[5];
-#pragma unroll
-                                for (int m = 0; m < 5; ++m) t[m] = qM[r][5 * l + m] * rc[l];
-                                const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
-                                numer = (l == 0) ? sl : numer + sl;
-                            }
-                        }
-                        const bool inband = (unsigned)(i - vL) <= vwidth1;
-                        if (q5any[r]) {
-#pragma unroll
-                            for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
-                        }
-                        if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
-#pragma unroll
-                            for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
+                            const float4 cl = lds_ld128(ra[r]);                                          // {X letter, gap, gapOpen, gapExtend}
+                            rg = cl.y; gopr = cl.z; gexr = cl.w;
+                            (void)rg;
                         }
                         float sim = numer;                                                         // :444
-                        if (!denomOne) sim = fast_div(numer, denom, rden);
+                        if constexpr (PRESIM) {
+                            // the score was computed ahead by score_matrix_kernel (same arithmetic); this row's value for THIS diagonal was requested
+                            // one diagonal ago, the one for the next diagonal is requested now and arrives while the workgroup synchronises
+                            const size_t col = (size_t)(qry_idx + i);
+                            const bool colOk = (qry_idx + i) < simPitch;
+                            if (simFor[r] == k) sim = simNext[r];
+                            else sim = colOk ? simP[(size_t)(k + simK0) * (size_t)simPitch + col] : 0.0f;
+                            simNext[r] = (colOk && k + 1 < kEnd) ? simP[(size_t)(k + 1 + simK0) * (size_t)simPitch + col] : 0.0f;
+                            simFor[r] = k + 1;
+                        } else if (!denomOne) sim = fast_div(numer, denom, rden);
 
                         // ---- neighbours ----
                         const float LS1 = dpp_shr1_f(eS, S1[r]);

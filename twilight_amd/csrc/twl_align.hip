@@ -155,14 +155,14 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 }
 
 // The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
-template <int W, int RPL, int MM, int MINW, bool SPEC = false>
-int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false>
+int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};      // one value per template instantiation
     if (cached.load() == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_nuc_kernel<W, RPL, MM, MINW, SPEC>), CfgT::THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
     int blocks_per_cu = cached.load();
@@ -184,6 +184,7 @@ int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t 
     a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char;
     a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
     for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
+    a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
     HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
     if (SPEC) {
         if ((rc = d->team.ensure((size_t)n_items * twl::kTeamWords * sizeof(unsigned long long)))) return rc;
@@ -191,8 +192,8 @@ int launch_nuc(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t 
         HIP_TRY(hipMemsetAsync(a.cells, 0, (size_t)base.n_pairs_total * sizeof(unsigned long long), st));
         a.team = (unsigned long long *)d->team.p;
     }
-    TRACE("launch nuc W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
-    hipLaunchKernelGGL((twl::talco_nuc_kernel<W, RPL, MM, MINW, SPEC>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    TRACE("launch lean P=%d W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", P, W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (SPEC && (dbg_on() || getenv("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
         std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
@@ -287,7 +288,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else if (prot) {
         // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
         const char *pc = getenv("TWL_PROT_CFG");      // development knob
-        const std::string pcs = pc ? pc : "auto";          // auto | dense | sparse | presim | r1
+        const std::string pcs = pc ? pc : "auto";          // auto | dense | sparse | presim | r1 (round-1 kernels) | lean_sparse | lean_presim
+        // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]
+        bool divOk = true;
+        auto inRange = [](float x) { const float ax = std::fabs(x); return x == 0.0f || (ax >= 0.0009765625f && ax <= 1024.0f); };
+        for (int t = 0; t < 441; ++t) divOk = divOk && inRange(a.M[t]);
+        divOk = divOk && inRange(p->gap_char);
+        const bool lean = divOk && (pcs == "auto" || pcs == "lean_sparse" || pcs == "lean_presim");
         if (pcs == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
         else if (pcs == "dense") rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
         else {
@@ -308,16 +315,18 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             }
             const bool few = n_pairs <= std::max(1, d->num_cu / 2);      // measured break-even vs the sparse in-kernel path: ~150 pairs of 2 kaa
             const bool fits = simFloats * sizeof(float) <= ((size_t)16 << 30) && blk[n_pairs] > 0;
-            if ((pcs == "presim" || (pcs == "auto" && few)) && fits) {
+            if ((rc = d->m24.ensure(21 * 24 * sizeof(float)))) return rc;
+            std::vector<float> m24(21 * 24, 0.0f);
+            for (int l = 0; l < 21; ++l) for (int m = 0; m < 21; ++m) m24[24 * l + m] = a.M[21 * l + m];
+            HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
+            const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few)) && fits;
+            if (presim) {
                 if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
                 if ((rc = d->sim_off.ensure(off.size() * sizeof(long long)))) return rc;
                 if ((rc = d->blk_off.ensure(blk.size() * sizeof(int32_t)))) return rc;
-                if ((rc = d->m24.ensure(21 * 24 * sizeof(float)))) return rc;
-                std::vector<float> m24(21 * 24, 0.0f);
-                for (int l = 0; l < 21; ++l) for (int m = 0; m < 21; ++m) m24[24 * l + m] = a.M[21 * l + m];
                 HIP_TRY(hipMemcpyAsync(d->sim_off.p, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, st));
                 HIP_TRY(hipMemcpyAsync(d->blk_off.p, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
                 HIP_TRY(hipStreamSynchronize(st));      // the host vectors above go out of scope
                 twl::ScoreArgs sa{};
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
@@ -327,7 +336,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
-                rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
+                if (lean && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_pairs, &grid, &window);
+                else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_pairs, &grid, &window);
+                else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
+            } else if (lean) {
+                rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, items, n_pairs, &grid, &window);
             } else {
                 rc = launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, items, n_pairs, 0, &grid, &window);
             }
@@ -353,15 +366,15 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu && !getenv("TWL_NO_FEW"));
         // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
         const bool spec = lean && few && mm == 2 && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC");
-        if (spec) rc = launch_nuc<16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
+        if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
         else if (lean && few) {
-            if (mm == 2) rc = launch_nuc<16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 1) rc = launch_nuc<16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
-            else rc = launch_nuc<16, 1, 0, 1>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
+            else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_pairs, &grid, &window);
         } else if (lean) {
-            if (mm == 2) rc = launch_nuc<8, 2, 2, 4>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 1) rc = launch_nuc<8, 2, 1, 4>(d, st, a, items, n_pairs, &grid, &window);
-            else rc = launch_nuc<8, 2, 0, 2>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, n_pairs, &grid, &window);
+            else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, n_pairs, &grid, &window);
         }
         else if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
         else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
