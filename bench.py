@@ -259,8 +259,9 @@ def main():
 
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or os.environ.get("TWL_BENCH_FORCE_SHARD"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()          # rank 0 has written the family
     twl.init([local_rank])
@@ -275,12 +276,13 @@ def main():
     peak = pk_batch = None
     if family:
         # ---- K + W fresh handles, opened and made resident in HBM before the clock starts ----
-        exchange = tdist.make_exchange(dev) if world > 1 else None
+        force_shard = bool(os.environ.get("TWL_BENCH_FORCE_SHARD"))      # development: a 1-rank world still goes through the RCCL all-gather
+        exchange = tdist.make_exchange(dev) if (world > 1 or force_shard) else None
         handles = []
         t0 = time.perf_counter()
         for i in range(args.warmup + args.steps):
             m = msa.Msa(["-t", tree, "-i", fasta, "-o", os.path.join(base, f"out_r{rank}_{i}.aln"), "--type", cfg["type"], "--gpu-index", str(local_rank)])
-            if world > 1:
+            if exchange is not None:
                 m.shard(rank, world, exchange)
             m.upload()
             handles.append(m)
@@ -410,7 +412,7 @@ def main():
             except OSError:
                 pass
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     twl.shutdown()
