@@ -70,6 +70,11 @@ int  twl_store_drop_cache(twl_store *s, int32_t id);
 int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, int32_t n_pairs, const twl_side *sides,
                       const int32_t *members, const float *member_weight, int32_t seq_len, int32_t *len_out, uint8_t *colinfo_out);
 
+/* The column info of ONE side of the prepared level (its original `len` bytes, format as colinfo_out of twl_level_prepare), or with
+   pair < 0 of the whole level ([n_pairs][2][seq_len]): for callers that pass colinfo_out = NULL and fetch it only when some side's
+   length shrank (len_out < len: a column was removed). */
+int twl_level_read_colinfo(twl_store *s, int32_t pair, int32_t side, uint8_t *out);
+
 /*
  * Run the DP on the prepared level.  run_mask[i] != 0 selects pair i (NULL = all); other pairs get aln_len 0, err 0.
  * May be called repeatedly (other gap_char group, retries with a larger xdrop/flen).  Outputs as in twl_align_batch,

@@ -24,6 +24,18 @@ namespace gpu {
 LevelTotals g_totals;
 static std::vector<int> g_devices;
 
+char *RunCtx::Raw::get(size_t n)
+{
+    if (n > cap) {
+        free(p);
+        cap = n + n / 8 + 64;
+        p = static_cast<char *>(malloc(cap));
+        if (!p) { std::cerr << "ERROR: out of host memory for the level staging (" << cap << " bytes)\n"; exit(1); }
+    }
+    return p;
+}
+RunCtx::Raw::~Raw() { free(p); }
+
 RunCtx::~RunCtx()
 {
     for (twl_store *st : stores) twl_store_destroy(st);

@@ -39,6 +39,11 @@ namespace {
 #define g_finished (ctx.finished)
 #define g_nextCacheId (ctx.nextCacheId)
 
+// Grow-only, never zero-filled staging shared by the runs of a process (one run aligns at a time): a level of 3 000 pairs x 10 kbp
+// moves ~70 MB per array and first-touch page faults cost more than the copies.
+std::vector<RunCtx::Raw> g_alnStage;      // per replica: paths as the DP wrote them
+RunCtx::Raw g_finalStage, g_infoStage;    // final paths as the commit reads them; column info
+
 void die(const char *what, int rc)
 {
     std::cerr << "ERROR: " << what << " failed (" << rc << "): " << twl_last_error() << '\n';
@@ -174,6 +179,11 @@ void uploadSequences(SequenceDB *database, Option *option)
     database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
 }
 
+void downloadRows(SequenceDB *database, Tree *T)
+{
+    if (database->afterMainPass) { database->afterMainPass(T); database->afterMainPass = nullptr; }
+}
+
 void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database, Option *option, Params &param)
 {
     RunCtx &ctx = ctxOf(database);
@@ -243,23 +253,45 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     // ---- device: profiles, consensus, gappy-column removal, gap penalties ----
     twl_params tp = baseParams(param);
     std::vector<int32_t> lens(2 * (size_t)n);
-    std::vector<uint8_t> colinfo((size_t)2 * n * stride);
     const int nd = (int)g_stores.size();
     std::vector<std::vector<int32_t>> lensOf(nd);
     onAllStores(ctx, "twl_level_prepare", [&](int d) {
-        lensOf[d].resize(2 * (size_t)n);       // every replica prepares the whole level; column info is fetched from the first only
+        lensOf[d].resize(2 * (size_t)n);       // every replica prepares the whole level; column info is fetched from the first only, below
         return twl_level_prepare(g_stores[d], &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride,
-                                 d == 0 ? lens.data() : lensOf[d].data(), d == 0 ? colinfo.data() : nullptr);
+                                 d == 0 ? lens.data() : lensOf[d].data(), nullptr);
     });
     for (int d = 1; d < nd; ++d)
         if (lensOf[d] != lens) { std::cerr << "ERROR: device replicas disagree on the prepared level.\n"; exit(1); }
     const bool removal = !(option->gappyVertical == 1.0);
-#pragma omp parallel for schedule(dynamic, 4)
+    // The column info (consensus letter + gappy flag per original column) only matters for addGappyColumnsBack, i.e. for pairs in
+    // which some column was removed: fetch it for those (at the leaf level none: single sequences have no gap columns).
+    std::vector<int> needInfo;
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
         s.lens = {lens[2 * i], lens[2 * i + 1]};
-        runsAndConsensus(&colinfo[((size_t)2 * i) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
-        runsAndConsensus(&colinfo[((size_t)2 * i + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
+        if (s.lens.first != s.refLen || s.lens.second != s.qryLen) needInfo.push_back(i);
+    }
+    if (needInfo.size() * 8 > (size_t)n) {        // most pairs: one transfer of the level's block
+        uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * n * stride));
+        const int rc = twl_level_read_colinfo(g_store, -1, 0, info);
+        if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int t = 0; t < (int)needInfo.size(); ++t) {
+            PairState &s = ps[needInfo[t]];
+            runsAndConsensus(&info[((size_t)2 * needInfo[t]) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
+            runsAndConsensus(&info[((size_t)2 * needInfo[t] + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
+        }
+    } else {
+        for (int i : needInfo) {
+            PairState &s = ps[i];
+            std::vector<uint8_t> info((size_t)std::max(s.refLen, s.qryLen) + 1);
+            int rc = twl_level_read_colinfo(g_store, i, 0, info.data());
+            if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
+            runsAndConsensus(info.data(), s.refLen, removal, letters, s.gappy.first, s.consensus.first);
+            rc = twl_level_read_colinfo(g_store, i, 1, info.data());
+            if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
+            runsAndConsensus(info.data(), s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
+        }
     }
     g_totals.prepare_ms += nowMs() - tPrep;
 
@@ -285,10 +317,11 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     const int meBase = procs ? ctx.shard.rank : 0;       // replica d of this process aligns the pairs of owner meBase + d
     twl_params tz = tp;
     tz.gap_char = 0;
+    if (g_alnStage.size() < (size_t)nd) g_alnStage.resize((size_t)nd);
     std::vector<double> callMs(nd, 0), kernMs(nd, 0), totMs(nd, 0);
     std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
     onAllStores(ctx, "twl_level_align", [&](int d) {
-        std::vector<int8_t> aln((size_t)n * 2 * stride);
+        int8_t *aln = reinterpret_cast<int8_t *>(g_alnStage[d].get((size_t)n * 2 * stride));
         std::vector<int32_t> alnLen(n);
         std::vector<int16_t> err(n);
         for (int grp = 0; grp < 2; ++grp) {
@@ -298,7 +331,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             for (int i = 0; i < n; ++i) if (all[i] && owner[i] == meBase + d) { mask[i] = 1; ++cnt; }
             if (!cnt) continue;
             const double tCall = nowMs();
-            const int r = twl_level_align(g_stores[d], grp ? &tz : &tp, mask.data(), aln.data(), alnLen.data(), err.data());
+            const int r = twl_level_align(g_stores[d], grp ? &tz : &tp, mask.data(), aln, alnLen.data(), err.data());
             if (r != TWL_OK) return r;
             callMs[d] += nowMs() - tCall;
             twl_stats st{};
@@ -332,7 +365,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     const double tFin = nowMs();
     int pathStride = 1;
     for (int i = 0; i < n; ++i) pathStride = std::max(pathStride, ps[i].refLen + ps[i].qryLen);
-    std::vector<int8_t> finalPaths((size_t)n * pathStride);
+    int8_t *finalPaths = reinterpret_cast<int8_t *>(g_finalStage.get((size_t)n * pathStride));
     std::vector<int32_t> finalLen(n, 0);
     std::vector<char> deferred(n, 0);
 #pragma omp parallel for schedule(dynamic, 4)
@@ -353,7 +386,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
         finalLen[i] = (int32_t)full.size();
     }
-    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit(g_stores[d], finalPaths.data(), finalLen.data(), pathStride); });
+    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit(g_stores[d], finalPaths, finalLen.data(), pathStride); });
     for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
         if (finalLen[i] == 0) continue;
         Node *a = nodes[i].first, *b = nodes[i].second;

@@ -39,6 +39,7 @@ int twl_msa_open(int argc, const char *const *argv, twl_msa **out)
     m->hostStaged = m->option.hostStaged;
     msa::progressive::gpu::beginInit(&m->option);
     m->db = new msa::SequenceDB();
+    m->db->lazyRows = true;        // the rows stay in HBM after the main pass until twl_msa_write (or a deferred pass) needs them
     m->param = new msa::Params(m->option, m->option.type);
     m->T = new msa::Tree(m->option.treeFile);                                     // twilight-main.cpp:122
     phylogeny::assignSinglePartition(m->T->root);                                 // :129-130 with maxSubtree = INT32_MAX
@@ -74,6 +75,7 @@ int twl_msa_align(twl_msa *m)
     const double t0 = nowS();
     msa::progressive::msaOnSubtree(m->subT, m->db, &m->option, *m->param, kernel, kernel);   // :148
     m->alignS = nowS() - t0;
+    if (m->option.debug) msa::progressive::gpu::downloadRows(m->db, m->subT);
     if (m->option.debug && !m->db->debug()) std::cerr << "WARNING: --check found an illegal alignment row.\n";
     m->alnLen = m->subT->root->getAlnLen(m->db->currentTask);
     m->aligned = true;
@@ -102,6 +104,7 @@ int twl_msa_report(twl_msa *m, twl_msa_totals *t, twl_msa_level *levels, int32_t
 int twl_msa_write(twl_msa *m, const char *path)
 {
     if (!m || !m->aligned) { g_msaErr = "not aligned yet"; return -2; }
+    msa::progressive::gpu::downloadRows(m->db, m->subT);
     const std::string keep = m->option.outFile;
     if (path) m->option.outFile = path;
     msa::io::writeFinalMSA(m->db, &m->option, m->alnLen);                          // :165

@@ -180,7 +180,8 @@ void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, 
         T->root->alnWeight = last->alnWeight;
         last->seqsIncluded.clear();
         last->msaFreq.clear();
-        if (database->afterMainPass) { database->afterMainPass(T); database->afterMainPass = nullptr; }
+        // device-resident mode: the rows come back now, unless nothing on the host needs them yet (no deferred pass, library caller)
+        if (database->afterMainPass && !(database->lazyRows && database->fallback_nodes.empty())) { database->afterMainPass(T); database->afterMainPass = nullptr; }
     }
     if (database->fallback_nodes.empty()) updateAlignment(T->root, database);
     auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::high_resolution_clock::now() - t0).count();

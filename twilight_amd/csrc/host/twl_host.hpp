@@ -168,6 +168,7 @@ struct SequenceDB {
     void *gpuCtx = nullptr;                        // per-run state of the GPU level kernels (progressive::gpu::RunCtx), freed through gpuCtxFree
     void (*gpuCtxFree)(void *) = nullptr;
     std::function<void(Tree *)> afterMainPass;    // set by the device-resident level kernel: bring rows/caches back to the host
+    bool lazyRows = false;                         // library use (twl_msa.h): leave the rows in HBM after the main pass until somebody needs them
     void addSequence(int id, const std::string &name, std::string &seq, int subtreeIdx, float weight, bool debug);
     bool debug();      // --check: true when every aligned row reproduces its input sequence and all rows are equally long
     ~SequenceDB();
@@ -266,6 +267,8 @@ const std::vector<LevelRecord> &levelRecords(SequenceDB *database);
 const LevelTotals &runTotals(SequenceDB *database);
 // Device-resident mode: create the store (sequences into HBM) ahead of the first level, e.g. before a timed region.
 void uploadSequences(SequenceDB *database, Option *option);
+// Rows (and the root's cached profile) back to the host, if they are still in HBM.
+void downloadRows(SequenceDB *database, Tree *T);
 }
 
 }  // namespace progressive

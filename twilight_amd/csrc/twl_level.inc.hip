@@ -335,6 +335,22 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     return TWL_OK;
 }
 
+int twl_level_read_colinfo(twl_store *s, int32_t pair, int32_t side, uint8_t *out)
+{
+    if (!s || !s->prepared || !out || pair >= s->n_pairs || side < 0 || side > 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    if (pair < 0) {      // the whole level: [n_pairs][2][seq_len]
+        HIP_TRY(hipMemcpy(out, s->d_colinfo.p, (size_t)s->n_pairs * 2 * (size_t)s->seq_len, hipMemcpyDeviceToHost));
+        return TWL_OK;
+    }
+    const size_t idx = (size_t)pair * 2 + (size_t)side;
+    const size_t len = (size_t)std::max(0, s->sides[idx].len);
+    if (len) HIP_TRY(hipMemcpy(out, (const uint8_t *)s->d_colinfo.p + idx * (size_t)s->seq_len, len, hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
 int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out)
 {
     if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
