@@ -347,6 +347,16 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         return (int)TWL_OK;
     });
     (void)nPlain; (void)nZero;
+    if (const char *dump = getenv("TWL_DUMP_SCHEDULE")) {      // development: one line per pair for tools/sim_schedule.py
+        if (FILE *f = fopen(dump, "a")) {
+            std::vector<uint64_t> pc(n, 0);
+            if (nd == 1) (void)twl_get_pair_cells(g_storeDev[0], pc.data(), n);
+            for (int i = 0; i < n; ++i)
+                fprintf(f, "%d %d %d %d %d %d %d %llu\n", (int)ctx.levels.size(), i, nodes[i].first->seqsIncluded.empty() ? -1 : nodes[i].first->seqsIncluded[0],
+                        nodes[i].second->seqsIncluded.empty() ? -1 : nodes[i].second->seqsIncluded[0], ps[i].lens.first, ps[i].lens.second, (int)errs[i], (unsigned long long)pc[i]);
+            fclose(f);
+        }
+    }
     g_totals.call_ms += *std::max_element(callMs.begin(), callMs.end());           // the replicas run concurrently
     g_totals.total_ms += *std::max_element(totMs.begin(), totMs.end());
     rec.kernel_ms = *std::max_element(kernMs.begin(), kernMs.end());

@@ -278,6 +278,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #endif
 
         while (!last_tile) {   // ---- Align_freq tile loop, TALCO-XDrop.cpp:77-106 ----
+#ifdef TWL_KERNEL_STAMPS
+            const unsigned long long st_tile0 = __builtin_amdgcn_s_memtime();
+#endif
             if constexpr (SPEC) {
                 if (!redo && tile > 0) {       // the start of this tile: the true one if it is known already, else the partner's guess
                     unsigned long long v = 0ull;
@@ -752,6 +755,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
                     st_slots += t_slots - t_head; st_bar += t_bar - t_slots; st_post += t_end - t_bar; st_n += 1;
                     st_act += (64 * blk[0] <= Uk + 1 && 64 * blk[0] + 63 >= Lk) ? 1 : 0;
+                    // timeline (tools/step_timeline.py): raw stamps of 96 diagonals of tile 4 from k = 600 (phase A) and from k = marker + 100 (phase C)
+                    const int tlw = (k >= 600 && k < 696) ? k - 600 : ((k >= a.marker + 100 && k < a.marker + 196) ? 96 + k - a.marker - 100 : -1);
+                    if (a.dbg && pair == 0 && tile == 4 && tlw >= 0 && lane == 0) {
+                        long long *g = reinterpret_cast<long long *>(a.dbg + 16 * (size_t)a.n_pairs_total) + 256 + ((size_t)w * 192 + tlw) * 4;
+                        g[0] = (long long)t_head; g[1] = (long long)t_slots; g[2] = (long long)t_bar; g[3] = (long long)t_end;
+                    }
                 }
 #endif
                 bool ended = false;
@@ -779,6 +788,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             };
 
             if (steps_left < 0) { tile_err = 3; go = false; }
+#ifdef TWL_KERNEL_STAMPS
+            st_setup += __builtin_amdgcn_s_memtime() - st_tile0;
+#endif
             {
                 using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
                 const int kA = min(kEnd, marker - 1);
@@ -850,6 +862,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     aborted = (sres != 0);
                 }
             }
+#ifdef TWL_KERNEL_STAMPS
+            const unsigned long long st_exit0 = __builtin_amdgcn_s_memtime();
+#endif
             if (!(SPEC && aborted)) {
             const int last_k = conv_logic ? k : k - 1;
             steps_left -= (long long)(last_k + 1);
@@ -920,29 +935,57 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     }
                 }
                 int n = 0;
-                if (lane == 0) {   // Traceback, :134-231, addressed by (diagonal, row) instead of a ragged offset
+                {   // Traceback, :134-231, addressed by (diagonal, row) instead of a ragged offset.  One lane walks the pointers; a walk
+                    // straight out of HBM costs a dependent L2 round trip per step, so the wave fetches the pointer words in patches of
+                    // 64 rows x 16 groups of 8 diagonals (a path of matches crosses exactly that) into the reference ring, which is dead
+                    // until the next tile, and the walk reads LDS.
+                    constexpr int PG = 16;
+                    static_assert(sizeof(s_ring) >= PG * 64 * sizeof(uint32_t), "traceback patch lives in the ring");
+                    static_assert((WINDOW & (WINDOW - 1)) == 0, "window rows wrap by a mask");
+                    uint32_t *s_patch = reinterpret_cast<uint32_t *>(s_ring);
                     int kk2 = start_k, ii = conv_q, qi = conv_q, ri = conv_r, st = tb_state % 3;
                     const bool first = (tile == 0);
-                    while (kk2 >= 0) {
-                        const uint32_t word = __hip_atomic_load(&tb[(size_t)(kk2 >> 3) * WINDOW + (ii % WINDOW)], __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-                        const int v = (int)((word >> (4 * (kk2 & 7))) & 0xFu);
-                        int dir;
-                        if (st == 0) {
-                            st = v & 3;
-                            if (st == 0) dir = 0;
-                            else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
-                            else { dir = 2; st = (v & 8) ? 2 : 0; }
-                        } else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
-                        else { dir = 2; st = (v & 8) ? 2 : 0; }
-                        if (dir == 0) { kk2 -= 2; ii -= 1; qi--; ri--; }
-                        else if (dir == 1) { kk2 -= 1; ii -= 1; qi--; }
-                        else { kk2 -= 1; ri--; }
-                        s_rev[n++] = (int8_t)dir;
-                        if (first && (ri < 0 || qi < 0)) break;
-                        if (ii < 0) break;   // defensive: a pointer chain left the tile (never on valid data)
+                    bool done = (kk2 < 0);
+                    while (!done) {
+                        const int g0 = kk2 >> 3, i0 = ii;
+                        const int row = i0 - 63 + lane;
+#pragma unroll
+                        for (int t = 0; t < PG; ++t) {
+                            uint32_t word = 0u;
+                            if (g0 - t >= 0 && row >= 0)
+                                word = __hip_atomic_load(&tb[(size_t)(g0 - t) * WINDOW + (size_t)(row & (WINDOW - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_patch[t * 64 + lane] = word;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order)
+                        if (lane == 0) {
+                            for (;;) {
+                                const int t = g0 - (kk2 >> 3), l = 63 - (i0 - ii);
+                                if (t >= PG || l < 0) break;                      // the path left the patch
+                                const uint32_t word = s_patch[t * 64 + l];
+                                const int v = (int)((word >> (4 * (kk2 & 7))) & 0xFu);
+                                int dir;
+                                if (st == 0) {
+                                    st = v & 3;
+                                    if (st == 0) dir = 0;
+                                    else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
+                                    else { dir = 2; st = (v & 8) ? 2 : 0; }
+                                } else if (st == 1) { dir = 1; st = (v & 4) ? 1 : 0; }
+                                else { dir = 2; st = (v & 8) ? 2 : 0; }
+                                if (dir == 0) { kk2 -= 2; ii -= 1; qi--; ri--; }
+                                else if (dir == 1) { kk2 -= 1; ii -= 1; qi--; }
+                                else { kk2 -= 1; ri--; }
+                                s_rev[n++] = (int8_t)dir;
+                                if (kk2 < 0) { done = true; break; }
+                                if (first && (ri < 0 || qi < 0)) { done = true; break; }
+                                if (ii < 0) { done = true; break; }   // defensive: a pointer chain left the tile (never on valid data)
+                            }
+                        }
+                        kk2 = __builtin_amdgcn_readfirstlane(kk2);
+                        ii = __builtin_amdgcn_readfirstlane(ii);
+                        done = __builtin_amdgcn_readfirstlane((int)done) != 0;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the walk's reads, before the next patch overwrites them
                     }
-                    if (first) {
+                    if (lane == 0 && first) {
                         while (ri > -1) { s_rev[n++] = 2; ri--; }
                         while (qi > -1) { s_rev[n++] = 1; qi--; }
                     }
@@ -965,6 +1008,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             err = __builtin_amdgcn_readfirstlane(s_misc[2] == 3 ? 3 : err);
             pos = __builtin_amdgcn_readfirstlane(s_misc[3]);
             iEnded = last_tile;
+#ifdef TWL_KERNEL_STAMPS
+            st_exit += __builtin_amdgcn_s_memtime() - st_exit0;
+#endif
             if (err != 0) break;
             tile += SPEC ? 2 : 1;
             }      // (tile not thrown away)
