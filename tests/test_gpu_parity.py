@@ -339,3 +339,19 @@ def test_random_asymmetric_nucleotide_matrix(gpu):
     batch = synth.make_level_batch(8, 900, members=((1, 6), (1, 6)), seed=15)
     _compare(gpu, batch, matrix=mat)
     _compare(gpu, batch, matrix=mat.T.copy())
+
+
+@pytest.mark.parametrize("where", ["query_row_700", "ref_col_300", "first_row"])
+def test_one_profile_entry_outside_the_fast_division_range(gpu, where):
+    # The hoisted-reciprocal division of the round-2 kernels is exact only for entries in [2^-20, 2^30]; anything else re-runs on the
+    # IEEE-division kernel.  ONE such entry, seen by one wave of the workgroup only, must send the whole pair there -- same result.
+    batch = synth.make_level_batch(6, 1400, members=((2, 6), (2, 6)), seed=77)
+    f = batch.freq.copy()
+    pairs = (1, 4)
+    for n in pairs:
+        if where == "query_row_700": f[n, 1, 700, 2] = np.float32(3e-9)
+        elif where == "ref_col_300": f[n, 0, 300, 1] = np.float32(7e11)
+        else: f[n, 1, 0, 0] = np.float32(1e-12)
+    b2 = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=f, gap_open=batch.gap_open, gap_extend=batch.gap_extend, len=batch.len, num=batch.num)
+    _compare(gpu, b2)
+    assert gpu.get_stats(0).n_relaunched == len(pairs)

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         int4 trash[64];              // per-lane trash slots: single-lane LDS side effects without touching EXEC
     };
     __shared__ ParBuf s_par[2];
-    __shared__ int s_misc[4];
+    __shared__ int s_misc[8];      // queue item, CS[last_k][0], err, pos of the traceback wave; [4] some wave met an entry outside fast_div's range
     __shared__ int8_t s_rev[2 * kMaxMarker + 16];
     __shared__ unsigned long long s_team[4];      // SPEC: {broadcast word, decision of the last poll, best cell of diagonal marker-1, of diagonal marker}
     constexpr unsigned O_CD = (unsigned)offsetof(ParBuf, cd), O_EXCH = (unsigned)offsetof(ParBuf, exch), O_RED = (unsigned)offsetof(ParBuf, red),
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 s_par[0].red[1] = s_par[0].red[2] = s_par[1].red[1] = s_par[1].red[2] = 0u;
                 for (int t = 0; t < 2; ++t) { s_par[t].conv[0] = 0x7fffffff; s_par[t].conv[1] = (int)0x80000000; s_par[t].conv[2] = 0; }
                 s_team[1] = 0ull; s_team[2] = 0ull; s_team[3] = 0ull;
+                s_misc[4] = 0;
             }
             __syncthreads();
 
@@ -874,7 +875,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             cells += tile_cells;
             dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
             if (tile_err != 0) { err = tile_err; break; }
-            if (guardBad && !denomOne) { err = kErrOverflow; break; }   // a profile entry outside fast_div's range: the IEEE-division kernel re-runs the pair
+            // a profile entry outside fast_div's range: the IEEE-division kernel re-runs the pair (every wave saw different columns:
+            // the verdict goes through LDS so that all of them leave together)
+            if (!denomOne) {
+                if (guardBad) s_misc[4] = 1;
+                __syncthreads();
+                guardBad = __builtin_amdgcn_readfirstlane(s_misc[4]) != 0;
+                if (guardBad) { err = kErrOverflow; break; }
+            }
 
             // a tile that ends before the marker leaves its last (partial) group of 8 diagonals unflushed
             if (tbPending) {
