@@ -56,6 +56,7 @@ struct NArgs {
 };
 
 typedef float nuc_f4 __attribute__((ext_vector_type(4)));
+typedef float nuc_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 lds_ld128(unsigned addr)      // one ds_read_b128 at a byte address kept in a register
 {
     const nuc_f4 v = *reinterpret_cast<const __attribute__((address_space(3))) nuc_f4 *>((const __attribute__((address_space(3))) char *)nullptr + addr);
@@ -175,7 +176,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     static_assert((P == 6 && MM >= 0 && MM <= 2) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
     using C = NCfg<W, RPL>;
     constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
-    constexpr int NQM = (MM == 2) ? 12 : (MM == 1 ? 16 : (MM == 0 ? 25 : 1));
+    // first products q[m]*M[l][m] kept per row as PAIRS over two matrix rows, {l = 2h, l = 2h+1}, so that the second product and the
+    // sums of two rows are one packed instruction each with every operand in an aligned register pair: NQP pairs (+ row 4 in mode 0)
+    constexpr int NQP = (MM == 2 || MM == 1) ? 8 : (MM == 0 ? 10 : 1);
+    constexpr int NQM = (MM == 0) ? 5 : 1;
     constexpr int F4 = (P + 2) / 4;                       // float4 per packed column: 2 or 6
     constexpr bool SPARSE = (MM == 3), PRESIM = (MM == 4);
     constexpr int RP = PRESIM ? 1 : F4;                  // ring planes: presim keeps only {X letter, gap, gapOpen, gapExtend}
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
             int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
             float qv[RPL][QN], gopq[RPL], gexq[RPL], qM[RPL][NQM];
+            nuc_f2 qP[RPL][NQP];           // qP[2*m + h] = {q[m]*M[2h][m], q[m]*M[2h+1][m]}
             float simNext[RPL];            // presim: the score of this row on the NEXT diagonal, loaded one diagonal ahead
             int simFor[RPL];               // ... and the diagonal it belongs to
             const int simK0 = ref_idx + qry_idx;   // global anti-diagonal of the tile's first cell
@@ -336,17 +341,24 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if constexpr (MM == 2) {
                         const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) { qM[r][m] = qv[r][m] * mA; qM[r][4 + m] = qv[r][m] * mB; qM[r][8 + m] = qv[r][m] * mC; }
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int l0 = 2 * h, l1 = 2 * h + 1;
+                                qP[r][2 * m + h] = nuc_f2{qv[r][m] * ((l0 == m) ? mA : (((l0 ^ m) == 2) ? mB : mC)), qv[r][m] * ((l1 == m) ? mA : (((l1 ^ m) == 2) ? mB : mC))};
+                            }
                     } else if constexpr (MM == 1) {
 #pragma unroll
-                        for (int l = 0; l < 4; ++l)
+                        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) qM[r][4 * l + m] = qv[r][m] * a.M[5 * l + m];
+                            for (int h = 0; h < 2; ++h) qP[r][2 * m + h] = nuc_f2{qv[r][m] * a.M[5 * (2 * h) + m], qv[r][m] * a.M[5 * (2 * h + 1) + m]};
                     } else if constexpr (MM == 0) {
 #pragma unroll
-                        for (int l = 0; l < 5; ++l)
+                        for (int m = 0; m < 5; ++m) {
 #pragma unroll
-                            for (int m = 0; m < 5; ++m) qM[r][5 * l + m] = qv[r][m] * a.M[5 * l + m];
+                            for (int h = 0; h < 2; ++h) qP[r][2 * m + h] = nuc_f2{qv[r][m] * a.M[5 * (2 * h) + m], qv[r][m] * a.M[5 * (2 * h + 1) + m]};
+                            qM[r][m] = qv[r][m] * a.M[20 + m];
+                        }
                     }
                     q5any[r] = __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
                     bool bad = false;
@@ -492,33 +504,18 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             const float rc[5] = {c0.x, c0.y, c0.z, c0.w, c1.x};
                             rg = c1.y; gopr = c1.z; gexr = c1.w;
                             // ---- column score, :378-395 (order: per l the products summed left to right, accumulated over l) ----
-                            if constexpr (MM == 2) {
+                            // rows {0,1} and {2,3} side by side: t[l][m] = (q[m]*M[l][m]) * r[l]; s_l = ((t0 + t1) + t2) + t3 (+ t4)
+                            constexpr int NM = (MM == 0) ? 5 : 4;
+                            const nuc_f2 r01 = nuc_f2{c0.x, c0.y}, r23 = nuc_f2{c0.z, c0.w};
+                            nuc_f2 s01 = qP[r][0] * r01, s23 = qP[r][1] * r23;
 #pragma unroll
-                                for (int l = 0; l < 4; ++l) {
-                                    float t[4];
+                            for (int m = 1; m < NM; ++m) { s01 = s01 + qP[r][2 * m] * r01; s23 = s23 + qP[r][2 * m + 1] * r23; }
+                            numer = ((s01.x + s01.y) + s23.x) + s23.y;
+                            if constexpr (MM == 0) {
+                                float s4 = qM[r][0] * rc[4];
 #pragma unroll
-                                    for (int m = 0; m < 4; ++m) t[m] = qM[r][((l == m) ? 0 : (((l ^ m) == 2) ? 4 : 8)) + m] * rc[l];
-                                    const float sl = ((t[0] + t[1]) + t[2]) + t[3];
-                                    numer = (l == 0) ? sl : numer + sl;
-                                }
-                            } else if constexpr (MM == 1) {
-#pragma unroll
-                                for (int l = 0; l < 4; ++l) {
-                                    float t[4];
-#pragma unroll
-                                    for (int m = 0; m < 4; ++m) t[m] = qM[r][4 * l + m] * rc[l];
-                                    const float sl = ((t[0] + t[1]) + t[2]) + t[3];
-                                    numer = (l == 0) ? sl : numer + sl;
-                                }
-                            } else {
-#pragma unroll
-                                for (int l = 0; l < 5; ++l) {
-                                    float t[5];
-#pragma unroll
-                                    for (int m = 0; m < 5; ++m) t[m] = qM[r][5 * l + m] * rc[l];
-                                    const float sl = (((t[0] + t[1]) + t[2]) + t[3]) + t[4];
-                                    numer = (l == 0) ? sl : numer + sl;
-                                }
+                                for (int m = 1; m < 5; ++m) s4 = s4 + qM[r][m] * rc[4];
+                                numer = numer + s4;
                             }
                             if (q5any[r]) {
 #pragma unroll
@@ -586,7 +583,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             else sim = colOk ? simP[(size_t)(k + simK0) * (size_t)simPitch + col] : 0.0f;
                             simNext[r] = (colOk && k + 1 < kEnd) ? simP[(size_t)(k + 1 + simK0) * (size_t)simPitch + col] : 0.0f;
                             simFor[r] = k + 1;
-                        } else if (!denomOne) sim = fast_div(numer, denom, rden);
+                        } else if (!denomOne) {      // (a real branch: leaf pairs, a third of all cells, have refNum * qryNum == 1)
+                            sim = fast_div(numer, denom, rden);
+                            asm volatile("" : "+v"(sim));
+                        }
 
                         // ---- neighbours ----
                         const float LS1 = dpp_shr1_f(eS, S1[r]);
