@@ -101,6 +101,11 @@ int twl_align_batch_device(int device, void *stream, const twl_params *p, int32_
                            const int32_t *d_len, const int32_t *d_num,
                            int8_t *d_aln_out, int32_t *d_aln_len_out, int16_t *d_err_out);
 
+/* Page-locked host memory for a caller's staging buffers (paths out, final paths in): copies to and from it run at link speed instead of
+   through the runtime's bounce buffers.  twl_host_alloc returns NULL when the allocation fails (the caller may fall back to malloc). */
+void *twl_host_alloc(uint64_t bytes);
+void  twl_host_free(void *p);
+
 int twl_get_stats(int device, twl_stats *out);
 
 /* Per-pair band-cell counts of the last call on `device` (n entries, host buffer). */

@@ -41,6 +41,8 @@ int twl_align_batch(const twl_params *p, int32_t n_pairs, int32_t seq_len, const
 int twl_get_stats(int, twl_stats *out) { *out = g_stats; return TWL_OK; }
 int twl_align_batch_device(int, void *, const twl_params *, int32_t, int32_t, const float *, const float *, const float *, const int32_t *,
                            const int32_t *, int8_t *, int32_t *, int16_t *) { return TWL_ERR_UNSUPPORTED; }
+void *twl_host_alloc(uint64_t) { return nullptr; }      // (callers fall back to malloc)
+void twl_host_free(void *) {}
 int twl_get_pair_cells(int, uint64_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_column_scores(const twl_params *, int32_t, const float *, const int32_t *, const int32_t *, float *) { return TWL_ERR_UNSUPPORTED; }
 

@@ -31,7 +31,7 @@ class TwlStats(C.Structure):
 
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
-            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores"]
+            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_host_alloc", "twl_host_free"]
 
 
 def exported_symbols():

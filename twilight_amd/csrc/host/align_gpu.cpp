@@ -24,17 +24,21 @@ namespace gpu {
 LevelTotals g_totals;
 static std::vector<int> g_devices;
 
+// Page-locked when the library can give it (copies at link speed), else plain memory.  Pinned blocks are not returned at process exit:
+// the staging objects are process-wide statics and the HIP runtime may be gone before their destructors run.
 char *RunCtx::Raw::get(size_t n)
 {
     if (n > cap) {
-        free(p);
+        if (pinned) twl_host_free(p); else free(p);
         cap = n + n / 8 + 64;
-        p = static_cast<char *>(malloc(cap));
+        p = static_cast<char *>(twl_host_alloc(cap));
+        pinned = (p != nullptr);
+        if (!p) p = static_cast<char *>(malloc(cap));
         if (!p) { std::cerr << "ERROR: out of host memory for the level staging (" << cap << " bytes)\n"; exit(1); }
     }
     return p;
 }
-RunCtx::Raw::~Raw() { free(p); }
+RunCtx::Raw::~Raw() { if (!pinned) free(p); }
 
 RunCtx::~RunCtx()
 {

@@ -21,7 +21,7 @@ struct RunCtx {
     LevelTotals totals;
     std::vector<LevelRecord> levels;
     Shard shard;
-    struct Raw { char *p = nullptr; size_t cap = 0; char *get(size_t n); ~Raw(); Raw() = default; Raw(Raw &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; } Raw(const Raw &) = delete; };      // grow-only, never zero-filled host buffer
+    struct Raw { char *p = nullptr; size_t cap = 0; bool pinned = false; char *get(size_t n); ~Raw(); Raw() = default; Raw(Raw &&o) noexcept : p(o.p), cap(o.cap), pinned(o.pinned) { o.p = nullptr; o.cap = 0; } Raw(const Raw &) = delete; };      // grow-only, never zero-filled host buffer
     ~RunCtx();
 };
 // Longest-processing-time deal of a level's pairs to `parts` owners (deterministic: every rank computes the same answer).

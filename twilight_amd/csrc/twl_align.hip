@@ -718,6 +718,19 @@ int twl_debug_read(int device, long long *out, int32_t n)
     return hipMemcpy(out, (const char *)d->dbg.p + base, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? TWL_OK : TWL_ERR_HIP;
 }
 
+void *twl_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (!g_init || bytes == 0) return nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void twl_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)
 {
     if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
