@@ -281,7 +281,7 @@ def main():
         handles = []
         t0 = time.perf_counter()
         for i in range(args.warmup + args.steps):
-            m = msa.Msa(["-t", tree, "-i", fasta, "-o", os.path.join(base, f"out_r{rank}_{i}.aln"), "--type", cfg["type"], "--gpu-index", str(local_rank)])
+            m = msa.Msa(["-t", tree, "-i", fasta, "-o", os.path.join(base, f"out_r{rank}_{i}.aln"), "--type", cfg["type"], "--gpu-index", str(local_rank)] + (["-v"] if os.environ.get("TWL_BENCH_VERBOSE") else []))
             if exchange is not None:
                 m.shard(rank, world, exchange)
             m.upload()

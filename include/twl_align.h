@@ -116,6 +116,13 @@ int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n);
    freq is [2][seq_len][P] (0 = reference, 1 = query), len = {R, Q}, num = {refNum, qryNum}. */
 int twl_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const int32_t *len, const int32_t *num, float *out);
 
+/* Diagnostics: the same column scores as the DP KERNEL ITSELF evaluated them while aligning this ONE pair -- a diagnostics instantiation of
+   the round-2 kernel (nucleotide: the matrix mode the parameters select, 0 general 5x5 / 1 zero N row and column / 2 match-transition-
+   transversion; protein: the sparse in-kernel loop) that also stores the score of every cell the band visits.  out[len[1]][len[0]]; cells
+   the band never visited hold NaN.  Arrays as one pair of twl_align_batch. */
+int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const float *gap_open, const float *gap_extend,
+                         const int32_t *len, const int32_t *num, float *out);
+
 #ifdef __cplusplus
 }
 #endif

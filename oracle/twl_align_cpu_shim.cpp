@@ -45,6 +45,7 @@ void *twl_host_alloc(uint64_t) { return nullptr; }      // (callers fall back to
 void twl_host_free(void *) {}
 int twl_get_pair_cells(int, uint64_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_column_scores(const twl_params *, int32_t, const float *, const int32_t *, const int32_t *, float *) { return TWL_ERR_UNSUPPORTED; }
+int twl_dp_column_scores(const twl_params *, int32_t, const float *, const float *, const float *, const int32_t *, const int32_t *, float *) { return TWL_ERR_UNSUPPORTED; }
 
 int twl_store_create(int, char, int32_t, const char *const *, const int32_t *, twl_store **) { return TWL_ERR_UNSUPPORTED; }
 void twl_store_destroy(twl_store *) {}

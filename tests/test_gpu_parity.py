@@ -270,6 +270,45 @@ def test_column_scores_match_oracle(gpu, kind):
             assert got.shape == want.shape and np.array_equal(got, want), f"{kind} pair {i}: {int((got != want).sum())} of {got.size} cells differ"
 
 
+@pytest.mark.parametrize("kind", ["nuc_mode2", "nuc_mode2_leaf", "nuc_mode1", "nuc_mode0_wildcard", "nuc_mode0_random", "prot_sparse"])
+def test_scores_inside_the_dp_kernel_match_oracle(gpu, kind):
+    """The column score of every cell the band visits, written out by a diagnostics instantiation of the DP kernel itself (same code:
+    hoisted-reciprocal division, row-pair packed products, sparse protein loop), against twlo_column_score -- equal as floats."""
+    rng = np.random.default_rng(5)
+    P = 22 if kind == "prot_sparse" else 6
+    if kind == "prot_sparse": mat = synth.protein_matrix().copy()
+    elif kind in ("nuc_mode2", "nuc_mode2_leaf"): mat = synth.nucleotide_matrix().copy()
+    elif kind == "nuc_mode1":
+        mat = rng.integers(-9, 19, size=(5, 5)).astype(np.float32)
+        mat[4, :] = 0
+        mat[:, 4] = 0
+    elif kind == "nuc_mode0_wildcard":
+        mat = synth.nucleotide_matrix().copy()
+        mat[4, :] = 18.0
+        mat[:, 4] = 18.0
+    else: mat = rng.integers(-9, 19, size=(5, 5)).astype(np.float32)
+    members = (1, 1) if kind == "nuc_mode2_leaf" else ((2, 7), (1, 5))
+    b = synth.make_level_batch(2, 700, members=members, seed=37, P=P, sub=0.1, gap_col_rate=0.1)
+    for gap_char in (None, 0.0):
+        pk = dict(marker=128)          # several tiles: the tile offsets of the dump are exercised too
+        if gap_char is not None: pk["gap_char"] = gap_char
+        p, op = gpu.make_params(mat, **pk), O.make_params(mat, **pk)
+        for i in range(b.n_pairs):
+            R, Q = int(b.len[i, 0]), int(b.len[i, 1])
+            got = gpu.dp_column_scores(p, b, i)
+            seen = ~np.isnan(got)
+            assert seen.sum() > 20 * (R + Q), f"{kind}: the band visited only {int(seen.sum())} cells"
+            denom = float(np.float32(b.num[i, 0]) * np.float32(b.num[i, 1]))
+            ref, qry = b.freq[i, 0, :R], b.freq[i, 1, :Q]
+            ii, jj = np.nonzero(seen)
+            step = max(1, len(ii) // 6000)          # every visited cell of short pairs, an even sample of long ones
+            bad = 0
+            for t in range(0, len(ii), step):
+                want = np.float32(O.column_score(op, ref[jj[t]], qry[ii[t]], denom))
+                bad += int(got[ii[t], jj[t]] != want)
+            assert bad == 0, f"{kind} pair {i}: {bad} sampled cells differ"
+
+
 @pytest.mark.timeout(900)
 def test_long_pairs_100k(gpu):
     """Two pairs of ~100 kbp profiles (~100 tiles each, ~10^8 band cells): index arithmetic, step budget and tile stitching at a length

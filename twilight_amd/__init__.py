@@ -13,6 +13,7 @@ from .api import (  # noqa: F401
     align_batch,
     align_batch_device,
     column_scores,
+    dp_column_scores,
     exported_symbols,
     get_pair_cells,
     get_stats,

@@ -31,7 +31,7 @@ class TwlStats(C.Structure):
 
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
-            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_host_alloc", "twl_host_free"]
+            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_dp_column_scores", "twl_host_alloc", "twl_host_free"]
 
 
 def exported_symbols():
@@ -59,6 +59,7 @@ def load_library():
         lib.twl_get_stats.restype = C.c_int
         lib.twl_get_pair_cells.restype = C.c_int
         lib.twl_column_scores.restype = C.c_int
+        lib.twl_dp_column_scores.restype = C.c_int
         lib.twl_shutdown.restype = None
         _lib = lib
     return _lib
@@ -159,4 +160,19 @@ def column_scores(params: TwlParams, ref: np.ndarray, qry: np.ndarray, ref_num: 
     nm = np.array([ref_num, qry_num], dtype=np.int32)
     out = np.zeros((Q, R), dtype=np.float32)
     _check(load_library().twl_column_scores(C.byref(params), C.c_int32(sl), _ptr(freq, C.c_float), _ptr(ln, C.c_int32), _ptr(nm, C.c_int32), _ptr(out, C.c_float)))
+    return out
+
+
+def dp_column_scores(params: TwlParams, batch, pair: int = 0) -> np.ndarray:
+    """twl_dp_column_scores: the column scores the DP kernel itself evaluated while aligning pair `pair` of `batch`, shape [Q][R], NaN where
+    the band never went."""
+    sl = batch.seq_len
+    freq = np.ascontiguousarray(batch.freq[pair], dtype=np.float32)
+    gop = np.ascontiguousarray(batch.gap_open[pair], dtype=np.float32)
+    gex = np.ascontiguousarray(batch.gap_extend[pair], dtype=np.float32)
+    ln = np.ascontiguousarray(batch.len[pair], dtype=np.int32)
+    nm = np.ascontiguousarray(batch.num[pair], dtype=np.int32)
+    out = np.zeros((int(ln[1]), int(ln[0])), dtype=np.float32)
+    _check(load_library().twl_dp_column_scores(C.byref(params), C.c_int32(sl), _ptr(freq, C.c_float), _ptr(gop, C.c_float), _ptr(gex, C.c_float),
+                                               _ptr(ln, C.c_int32), _ptr(nm, C.c_int32), _ptr(out, C.c_float)))
     return out

@@ -53,6 +53,7 @@ struct NArgs {
     const float *sim;
     const long long *sim_off;
     unsigned long long *team; // speculative tile start (SPEC kernels): [n_items][16] mailbox words, zeroed by the host
+    float *simdump;           // DUMP kernels (diagnostics, one pair): [Q][R] column scores as the DP evaluated them
 };
 
 typedef float nuc_f4 __attribute__((ext_vector_type(4)));
@@ -170,7 +171,7 @@ struct NCfg {
 // talco_kernel): nucleotide 0 general 5x5, 1 zero N row/column (4x4 core), 2 mode 1 with the match / transition / transversion
 // structure (three products per row letter); protein 3 loop over the non-zero letters of the reference column, 4 scores
 // precomputed by score_matrix_kernel for the whole R x Q matrix (launches with few pairs: the other CUs are idle anyway).
-template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false>
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
 __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 {
     static_assert((P == 6 && MM >= 0 && MM <= 2) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
@@ -588,6 +589,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             asm volatile("" : "+v"(sim));
                         }
 
+                        if constexpr (DUMP) {      // diagnostics build of the same code: the score of every cell the band visits
+                            if (inband) a.simdump[(size_t)(qry_idx + i) * (size_t)R + (size_t)(ref_idx + k - i)] = sim;
+                        }
                         // ---- neighbours ----
                         const float LS1 = dpp_shr1_f(eS, S1[r]);
                         const float LI1 = dpp_shr1_f(eI, I1[r]);

@@ -69,6 +69,8 @@ struct Device {
     Buf cols, tb, cells, queue, items, errs, dbg;
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
     Buf team;                                                                    // mailboxes of the speculative tile start
+    Buf simdump;                                                                 // twl_dp_column_scores: [Q][R] scores written by the DUMP kernels
+    bool dump_on = false;
     std::vector<int32_t> dbg_host;
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
@@ -155,14 +157,14 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 }
 
 // The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
-template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false>
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
 int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};      // one value per template instantiation
     if (cached.load() == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC>), CfgT::THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
     int blocks_per_cu = cached.load();
@@ -193,7 +195,8 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
         a.team = (unsigned long long *)d->team.p;
     }
     TRACE("launch lean P=%d W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", P, W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    a.simdump = DUMP ? (float *)d->simdump.p : nullptr;
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (SPEC && (dbg_on() || getenv("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
         std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
@@ -320,7 +323,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             for (int l = 0; l < 21; ++l) for (int m = 0; m < 21; ++m) m24[24 * l + m] = a.M[21 * l + m];
             HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
-            const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few)) && fits;
+            const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few)) && fits && !d->dump_on;
             if (presim) {
                 if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
                 if ((rc = d->sim_off.ensure(off.size() * sizeof(long long)))) return rc;
@@ -339,6 +342,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 if (lean && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_pairs, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_pairs, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
+            } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
+                if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
+                rc = launch_lean<22, 16, 1, 3, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
             } else if (lean) {
                 rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, items, n_pairs, &grid, &window);
             } else {
@@ -366,7 +372,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu && !getenv("TWL_NO_FEW"));
         // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
         const bool spec = lean && few && mm == 2 && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC");
-        if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
+        if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
+            if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
+            if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+            else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+        }
+        else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
         else if (lean && few) {
             if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
@@ -504,7 +516,7 @@ void twl_shutdown(void)
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team,
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -704,6 +716,34 @@ int twl_column_scores(const twl_params *p, int32_t seq_len, const float *freq, c
     HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < Q; ++i)
         for (int j = 0; j < R; ++j) out[(size_t)i * R + j] = diag[(size_t)(i + j) * pitch + i];
+    return TWL_OK;
+}
+
+int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const float *gap_open, const float *gap_extend,
+                         const int32_t *len, const int32_t *num, float *out)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (seq_len < 1 || !freq || !gap_open || !gap_extend || !len || !num || !out || len[0] < 1 || len[1] < 1 || len[0] > seq_len || len[1] > seq_len) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = g_devs[0];
+    const size_t cells = (size_t)len[0] * (size_t)len[1];
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        HIP_TRY(hipSetDevice(d->id));
+        if ((rc = d->simdump.ensure(cells * sizeof(float)))) return rc;
+        HIP_TRY(hipMemset(d->simdump.p, 0xff, cells * sizeof(float)));      // NaN: a cell the band never visited
+        d->dump_on = true;
+    }
+    std::vector<int8_t> aln(2 * (size_t)seq_len);
+    int32_t alen = 0;
+    int16_t aerr = 0;
+    rc = twl_align_batch(p, 1, seq_len, freq, gap_open, gap_extend, len, num, aln.data(), &alen, &aerr);
+    std::lock_guard<std::mutex> lk(d->mu);
+    d->dump_on = false;
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(d->id));
+    HIP_TRY(hipMemcpy(out, d->simdump.p, cells * sizeof(float), hipMemcpyDeviceToHost));
     return TWL_OK;
 }
 
