@@ -815,8 +815,11 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     __syncthreads();
                     const int d = __builtin_amdgcn_readfirstlane((int)s_team[1]);
                     __syncthreads();
-                    if (d == 1) confirmed = true;
-                    else if (d == 2) { go = false; aborted = true; }
+                    // (no if / else if here: with that form the compiler stops treating the loop around it as uniform -- the loop counter and
+                    // the band limits moved to vector registers and every branch of the step became an EXEC-mask branch)
+                    confirmed = confirmed | (d == 1);
+                    go = go & (d != 2);
+                    aborted = aborted | (d == 2);
                 };
                 if constexpr (SPEC) {
                     while (go && k < kA) {
