@@ -206,11 +206,11 @@ def variant_of(pairs, num_cu, P):
     scores), the throughput geometry beyond."""
     if P == 22:
         if pairs <= max(1, num_cu // 2):
-            return "talco_lean_kernel<22, 16, 1, 4, 1, true> (precomputed column scores, speculative tile start)"
-        return "talco_lean_kernel<22, 16, 1, 3, 1, false> (sparse column scores)"
+            return "talco_lean_kernel<22, 16, 1, 4, 1, true, false> (precomputed column scores, speculative tile start)"
+        return "talco_lean_kernel<22, 16, 1, 3, 1, false, false> (sparse column scores)"
     if 2 * pairs <= num_cu:
-        return "talco_lean_kernel<6, 16, 1, 2, 1, true> (speculative tile start)"
-    return "talco_lean_kernel<6, 16, 1, 2, 1, false>" if pairs <= num_cu else "talco_lean_kernel<6, 8, 2, 2, 4, false>"
+        return "talco_lean_kernel<6, 16, 1, 2, 1, true, false> (speculative tile start)"
+    return "talco_lean_kernel<6, 16, 1, 2, 1, false, false>" if pairs <= num_cu else "talco_lean_kernel<6, 8, 2, 2, 4, false, false>"
 
 
 def main():
