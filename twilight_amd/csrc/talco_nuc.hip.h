@@ -246,8 +246,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         bool last_tile = (R <= 0 || Q <= 0);
         unsigned long long cells = 0;
         long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
-        // the row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits
-        if (!last_tile && (R + Q > 65000 || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
+        // The row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits -- TILE-local values, so sequences of any length pass
+        // (a tile that has not converged after 65 534 diagonals goes to the round-1 kernel, below); the mailbox words of the speculative
+        // start carry absolute positions in 16 bits each (the host does not pick that kernel for longer sequences).
+        if (!last_tile && ((SPEC && (R > 65535 || Q > 65535)) || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
         bool guardBad = false;
         // SPEC: this workgroup runs the tiles of its parity; `confirmed` = the start of the tile in flight is the true one
@@ -859,7 +861,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         }
                     }
                 }
-                while (go && k < kEnd) step(T2{});
+                const int kCap = min(kEnd, 65534);      // k + 1 must fit the 16-bit tag
+                while (go && k < kCap) step(T2{});
+                if (go && k < kEnd) { tile_err = kErrOverflow; go = false; }      // (never seen: tiles converge within ~1.5 markers)
                 if constexpr (SPEC) {
                     if (aborted || !confirmed) {
                         if (sres < 0 || sres == 0) sres = settle();

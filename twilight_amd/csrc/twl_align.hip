@@ -316,6 +316,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 simFloats += live ? (size_t)((R + Q) * pitch) : 0;
                 blk[t + 1] = blk[t] + (live ? (int32_t)(((R + Q - 1 + 63) / 64) * ((Q + 63) / 64)) : 0);
             }
+            int32_t maxLenP = 0;
+            for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLenP = std::max(maxLenP, h_len[t]);
             const bool few = n_pairs <= std::max(1, d->num_cu / 2);      // measured break-even vs the sparse in-kernel path: ~150 pairs of 2 kaa
             const bool fits = simFloats * sizeof(float) <= ((size_t)16 << 30) && blk[n_pairs] > 0;
             if ((rc = d->m24.ensure(21 * 24 * sizeof(float)))) return rc;
@@ -339,7 +341,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
-                if (lean && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_pairs, &grid, &window);
+                if (lean && 2 * n_pairs <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_pairs, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_pairs, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
             } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
@@ -371,7 +373,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
         const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu && !getenv("TWL_NO_FEW"));
         // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
-        const bool spec = lean && few && mm == 2 && 2 * n_pairs <= d->num_cu && !getenv("TWL_NO_SPEC");
+        int32_t maxLen = 0;
+        for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLen = std::max(maxLen, h_len[t]);
+        // (the mailbox words of the speculative start carry absolute positions in 16 bits each)
+        const bool spec = lean && few && mm == 2 && 2 * n_pairs <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
             if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
