@@ -78,9 +78,13 @@ int twl_level_read_colinfo(twl_store *s, int32_t pair, int32_t side, uint8_t *ou
 /*
  * Run the DP on the prepared level.  run_mask[i] != 0 selects pair i (NULL = all); other pairs get aln_len 0, err 0.
  * May be called repeatedly (other gap_char group, retries with a larger xdrop/flen).  Outputs as in twl_align_batch,
- * aln_out is [n_pairs][2*seq_len].
+ * aln_out is [n_pairs][2*seq_len]; aln_out == NULL leaves the paths in HBM (lengths and error codes still come back): a caller
+ * fetches the few it has to edit with twl_level_read_path and commits the others in place with twl_level_commit_from_dp.
  */
 int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out);
+
+/* The first `len` path codes of pair `pair` as the level's last DP run over that pair left them. */
+int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len);
 
 /*
  * Apply the final paths (gappy columns restored) to the rows of both nodes of every pair and merge cached profiles.
@@ -89,6 +93,14 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
  * merged profile replaces the reference side's cache and the query side's id is dropped (updateFrequency :506-539).
  */
 int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride);
+
+/*
+ * Same, with the paths of the pairs marked in from_dp[] taken from the level's own DP output in HBM (path_len[i] = the length
+ * twl_level_align returned): for pairs in which no gappy column was removed addGappyColumnsBack (alignment-helper.cpp:243-289) is the
+ * identity, so their paths never have to leave the device.  Rows of `paths` of marked pairs are ignored; paths may be NULL when every
+ * pair with path_len > 0 is marked.  from_dp == NULL is twl_level_commit.
+ */
+int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride, const uint8_t *from_dp);
 
 /* Diagnostics: the packed DP columns [len][P+2] (P frequencies, gapOpen, gapExtend) of one side of the prepared level. */
 int twl_level_read_columns(twl_store *s, int32_t pair, int32_t side, float *out, int32_t max_cols);

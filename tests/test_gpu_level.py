@@ -219,3 +219,39 @@ def test_level_edge_cases(gpu):
     with pytest.raises(twl.TwlError):
         st.prepare(twl.make_params(LC.matrix_of("p")), [[L.Side([4], one, 64, 1, 1.0), L.Side([5], one, 64, 1, 1.0)]])
     st.close()
+
+
+@pytest.mark.parametrize("seq_type", ["n", "p"])
+def test_commit_from_dp_output_equals_commit_of_downloaded_paths(gpu, seq_type):
+    """Pairs in which no gappy column was removed keep their DP path in HBM: twl_level_align without a path buffer, twl_level_commit_from_dp
+    with those pairs marked (one pair fetched with twl_level_read_path and brought back by the caller, one left out like a deferred
+    pair) must leave exactly the rows and lengths that the download / upload form leaves."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    cases = [LC.make_case(seq_type, seed, cached=0, length=90 + 53 * seed) for seed in range(6)]
+    seqs, pairs, ids = _level(cases)
+    p = twl.make_params(LC.matrix_of(seq_type))
+    # gappy threshold 1: nothing is removed, so every DP path is a final path
+    a = L.Store(seqs, seq_type)
+    a.prepare(p, pairs, gappy_threshold=1.0)
+    aln, n, err = a.align(p)
+    assert np.all(err == 0) and np.all(n > 0)
+    full = [aln[i, : n[i]].copy() for i in range(len(cases))]
+    full[3] = np.zeros(0, dtype=np.int8)
+    a.commit(full)
+    want = a.rows()
+    a.close()
+
+    b = L.Store(seqs, seq_type)
+    b.prepare(p, pairs, gappy_threshold=1.0)
+    n2, err2 = b.align_in_hbm(p)
+    assert np.array_equal(n2, n) and np.array_equal(err2, err)
+    fetched = b.read_path(1, int(n2[1]))
+    assert np.array_equal(fetched, aln[1, : n[1]])
+    plen = [int(x) for x in n2]
+    plen[3] = 0
+    b.commit_from_dp([None, fetched, None, None, None, None], plen)
+    got = b.rows()
+    b.close()
+    assert got == want

@@ -320,8 +320,15 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (g_alnStage.size() < (size_t)nd) g_alnStage.resize((size_t)nd);
     std::vector<double> callMs(nd, 0), kernMs(nd, 0), totMs(nd, 0);
     std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
+    // One device, one process, and few pairs lost columns: the paths of all the others never leave HBM (addGappyColumnsBack is the
+    // identity for them): the DP output is committed in place, only the pairs that need editing are fetched.
+    const bool inPlace = (nd == 1 && !procs && !ctx.shard.exchange && needInfo.size() * 4 <= (size_t)n && !getenv("TWL_NO_INPLACE_COMMIT"));
+    std::vector<char> needsHost(n, 0);
+    for (int i : needInfo) needsHost[i] = 1;
+    std::vector<uint8_t> fromDp(n, 0);
+    std::vector<int32_t> dpLen(n, 0);
     onAllStores(ctx, "twl_level_align", [&](int d) {
-        int8_t *aln = reinterpret_cast<int8_t *>(g_alnStage[d].get((size_t)n * 2 * stride));
+        int8_t *aln = inPlace ? nullptr : reinterpret_cast<int8_t *>(g_alnStage[d].get((size_t)n * 2 * stride));
         std::vector<int32_t> alnLen(n);
         std::vector<int16_t> err(n);
         for (int grp = 0; grp < 2; ++grp) {
@@ -341,7 +348,13 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             for (int i = 0; i < n; ++i) {
                 if (!mask[i]) continue;
                 errs[i] = err[i];
-                paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + (err[i] == 0 ? alnLen[i] : 0));
+                const int32_t len = (err[i] == 0) ? alnLen[i] : 0;
+                if (!inPlace) paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + len);
+                else if (needsHost[i]) {
+                    paths[i].resize((size_t)len);
+                    const int r2 = twl_level_read_path(g_stores[d], i, paths[i].data(), len);
+                    if (r2 != TWL_OK) return r2;
+                } else if (len > 0) { fromDp[i] = 1; dpLen[i] = len; }
             }
         }
         return (int)TWL_OK;
@@ -368,6 +381,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         if (errs[i] == 0) continue;
         if (errs[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
         paths[i].clear();                       // currentTask == 0: a failed pair is deferred (alignment-cpu.cpp:108-115)
+        fromDp[i] = 0;
         fallbackPairs.push_back(i);
     }
 
@@ -382,7 +396,8 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
         deferred[i] = ((s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144
-        if (deferred[i]) paths[i].clear();
+        if (deferred[i]) { paths[i].clear(); fromDp[i] = 0; }
+        if (fromDp[i]) { finalLen[i] = dpLen[i]; continue; }      // no column was removed: the DP path is the final path, and it is in HBM
         if (paths[i].empty()) continue;
         alnPath full;
         int alnRef = 0, alnQry = 0;
@@ -396,7 +411,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
         finalLen[i] = (int32_t)full.size();
     }
-    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit(g_stores[d], finalPaths, finalLen.data(), pathStride); });
+    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit_from_dp(g_stores[d], finalPaths, finalLen.data(), pathStride, inPlace ? fromDp.data() : nullptr); });
     for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
         if (finalLen[i] == 0) continue;
         Node *a = nodes[i].first, *b = nodes[i].second;
@@ -422,7 +437,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (option->printDetail)
         std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << g_totals.call_ms - before.call_ms
                   << " (kernel " << rec.kernel_ms << ", exchange " << rec.exchange_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
-                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << '\n';
+                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << '\n';
 }
 
 }  // namespace gpu

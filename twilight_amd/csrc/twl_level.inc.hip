@@ -359,7 +359,7 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     if (p->P != s->P) { g_err = "params.P does not match the store's sequence type"; return TWL_ERR_BAD_ARGUMENT; }
     const int32_t n = s->n_pairs;
     if (n == 0) return TWL_OK;
-    if (!aln_out || !aln_len_out || !err_out) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (!aln_len_out || !err_out) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     Device *d = s->d;
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
@@ -382,7 +382,8 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     // paths: bulk when most pairs ran, else one copy per pair that has a path
     int32_t ran = 0;
     for (int32_t i = 0; i < n; ++i) ran += aln_len_out[i] > 0;
-    if (ran * 2 >= n) HIP_TRY(hipMemcpyAsync(aln_out, s->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
+    if (!aln_out) {}                            // the paths stay in HBM (twl_level_read_path / twl_level_commit_from_dp)
+    else if (ran * 2 >= n) HIP_TRY(hipMemcpyAsync(aln_out, s->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
     else
         for (int32_t i = 0; i < n; ++i)
             if (aln_len_out[i] > 0)
@@ -395,13 +396,34 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     return TWL_OK;
 }
 
+int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len)
+{
+    if (!s || !s->prepared || !out || pair < 0 || pair >= s->n_pairs || len < 0 || len > 2 * s->seq_len || !s->d_aln.p) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    if (len) HIP_TRY(hipMemcpy(out, (const int8_t *)s->d_aln.p + (size_t)pair * 2 * (size_t)s->seq_len, (size_t)len, hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
 int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride)
+{
+    return twl_level_commit_from_dp(s, paths, path_len, path_stride, nullptr);
+}
+
+int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride, const uint8_t *from_dp)
 {
     if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
     const int32_t n = s->n_pairs;
     s->prepared = false;
     if (n == 0) return TWL_OK;
-    if (!paths || !path_len || path_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if ((!paths && !from_dp) || !path_len || path_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (from_dp) {
+        for (int32_t i = 0; i < n; ++i) {
+            if (from_dp[i] && (!s->d_aln.p || path_len[i] > 2 * s->seq_len)) { g_err = "from_dp without a DP output of this level"; return TWL_ERR_BAD_ARGUMENT; }
+            if (!from_dp[i] && path_len[i] > 0 && !paths) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+        }
+    }
     Device *d = s->d;
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
@@ -450,7 +472,15 @@ int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len,
 
     HIP_TRY(hipEventRecord(d->ev[0], st));
     if ((rc = s->d_paths.ensure((size_t)n * (size_t)path_stride))) return rc;
-    HIP_TRY(hipMemcpyAsync(s->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
+    if (!from_dp) HIP_TRY(hipMemcpyAsync(s->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
+    else {
+        // the DP output of this level, row by row, inside HBM; then the (few) rows the caller brought
+        const size_t width = std::min((size_t)path_stride, 2 * (size_t)s->seq_len);
+        HIP_TRY(hipMemcpy2DAsync(s->d_paths.p, (size_t)path_stride, s->d_aln.p, 2 * (size_t)s->seq_len, width, (size_t)n, hipMemcpyDeviceToDevice, st));
+        for (int32_t i = 0; i < n; ++i)
+            if (!from_dp[i] && path_len[i] > 0)
+                HIP_TRY(hipMemcpyAsync((int8_t *)s->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
+    }
     { std::vector<int32_t> pl(path_len, path_len + n); if ((rc = upload(s->d_pathlen, pl, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
     if ((rc = s->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
     if ((rc = upload(s->d_work, work, st))) return rc;

@@ -17,7 +17,7 @@ class TwlSide(C.Structure):
 
 
 _SYMBOLS = ["twl_store_create", "twl_store_destroy", "twl_store_read_rows", "twl_store_read_cache", "twl_store_drop_cache",
-            "twl_level_prepare", "twl_level_read_colinfo", "twl_level_align", "twl_level_commit", "twl_level_read_columns", "twl_level_timing"]
+            "twl_level_prepare", "twl_level_read_colinfo", "twl_level_align", "twl_level_read_path", "twl_level_commit", "twl_level_commit_from_dp", "twl_level_read_columns", "twl_level_timing"]
 
 
 def exported_symbols():
@@ -130,6 +130,36 @@ class Store:
         api._check(_lib().twl_level_align(self._h, C.byref(params), mask, aln.ctypes.data_as(C.POINTER(C.c_int8)),
                                           aln_len.ctypes.data_as(C.POINTER(C.c_int32)), err.ctypes.data_as(C.POINTER(C.c_int16))))
         return aln, aln_len, err
+
+    def align_in_hbm(self, params: api.TwlParams, run_mask: Optional[np.ndarray] = None):
+        """twl_level_align with aln_out = NULL: lengths and error codes only, the paths stay on the device."""
+        n = self._n_pairs
+        aln_len = np.zeros(n, dtype=np.int32)
+        err = np.zeros(n, dtype=np.int16)
+        mask = None
+        if run_mask is not None:
+            m = np.ascontiguousarray(run_mask, dtype=np.uint8)
+            mask = m.ctypes.data_as(C.POINTER(C.c_uint8))
+        api._check(_lib().twl_level_align(self._h, C.byref(params), mask, None, aln_len.ctypes.data_as(C.POINTER(C.c_int32)), err.ctypes.data_as(C.POINTER(C.c_int16))))
+        return aln_len, err
+
+    def read_path(self, pair: int, length: int) -> np.ndarray:
+        out = np.zeros(max(1, length), dtype=np.int8)
+        api._check(_lib().twl_level_read_path(self._h, C.c_int32(pair), out.ctypes.data_as(C.POINTER(C.c_int8)), C.c_int32(length)))
+        return out[:length]
+
+    def commit_from_dp(self, paths: Sequence[Optional[np.ndarray]], path_len: Sequence[int]):
+        """twl_level_commit_from_dp: paths[i] is None -> pair i's path is the DP output in HBM, path_len[i] long."""
+        n = self._n_pairs
+        stride = max([1] + [int(x) for x in path_len])
+        flat = np.zeros((n, stride), dtype=np.int8)
+        plen = np.asarray(path_len, dtype=np.int32).copy()
+        from_dp = np.zeros(n, dtype=np.uint8)
+        for i, p in enumerate(paths):
+            if p is None: from_dp[i] = 1 if plen[i] > 0 else 0
+            else: flat[i, : len(p)] = p
+        api._check(_lib().twl_level_commit_from_dp(self._h, flat.ctypes.data_as(C.POINTER(C.c_int8)), plen.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(stride),
+                                                   from_dp.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def commit(self, paths: Sequence[np.ndarray]):
         n = self._n_pairs
