@@ -397,8 +397,6 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
         else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_pairs, 0, &grid, &window);
     }
-    else if (c == "nuc4") rc = launch_lean<6, 4, 4, 2, 1>(d, st, a, items, n_pairs, &grid, &window);        // experiments: one wave per SIMD, four blocks each
-    else if (c == "nuc8w") rc = launch_lean<6, 8, 2, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
     else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_pairs, 0, &grid, &window);
     else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
