@@ -74,6 +74,8 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
    pair < 0 of the whole level ([n_pairs][2][seq_len]): for callers that pass colinfo_out = NULL and fetch it only when some side's
    length shrank (len_out < len: a column was removed). */
 int twl_level_read_colinfo(twl_store *s, int32_t pair, int32_t side, uint8_t *out);
+/* The column info of BOTH sides of the n_sel pairs listed in pairs[]: out[n_sel][2][seq_len], one synchronisation for all of them. */
+int twl_level_read_colinfo_many(twl_store *s, int32_t n_sel, const int32_t *pairs, uint8_t *out);
 
 /*
  * Run the DP on the prepared level.  run_mask[i] != 0 selects pair i (NULL = all); other pairs get aln_len 0, err 0.
@@ -85,6 +87,8 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
 
 /* The first `len` path codes of pair `pair` as the level's last DP run over that pair left them. */
 int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len);
+/* The same for the n_sel pairs listed in pairs[] (lens[t] codes of pair pairs[t] into out + t * out_stride), one synchronisation. */
+int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, int8_t *out, int32_t out_stride);
 
 /*
  * Apply the final paths (gappy columns restored) to the rows of both nodes of every pair and merge cached profiles.

@@ -58,6 +58,8 @@ int twl_level_align(twl_store *, const twl_params *, const uint8_t *, int8_t *, 
 int twl_level_commit(twl_store *, const int8_t *, const int32_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_commit_from_dp(twl_store *, const int8_t *, const int32_t *, int32_t, const uint8_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_read_path(twl_store *, int32_t, int8_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_read_paths(twl_store *, int32_t, const int32_t *, const int32_t *, int8_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_read_colinfo_many(twl_store *, int32_t, const int32_t *, uint8_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_read_columns(twl_store *, int32_t, int32_t, float *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_timing(twl_store *, double *, double *) { return TWL_ERR_UNSUPPORTED; }
 

@@ -281,16 +281,15 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             runsAndConsensus(&info[((size_t)2 * needInfo[t]) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
             runsAndConsensus(&info[((size_t)2 * needInfo[t] + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
         }
-    } else {
-        for (int i : needInfo) {
-            PairState &s = ps[i];
-            std::vector<uint8_t> info((size_t)std::max(s.refLen, s.qryLen) + 1);
-            int rc = twl_level_read_colinfo(g_store, i, 0, info.data());
-            if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
-            runsAndConsensus(info.data(), s.refLen, removal, letters, s.gappy.first, s.consensus.first);
-            rc = twl_level_read_colinfo(g_store, i, 1, info.data());
-            if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
-            runsAndConsensus(info.data(), s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
+    } else if (!needInfo.empty()) {             // a few pairs: their blocks only, one synchronisation
+        uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * needInfo.size() * stride));
+        const int rc = twl_level_read_colinfo_many(g_store, (int32_t)needInfo.size(), needInfo.data(), info);
+        if (rc != TWL_OK) die("twl_level_read_colinfo_many", rc);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int t = 0; t < (int)needInfo.size(); ++t) {
+            PairState &s = ps[needInfo[t]];
+            runsAndConsensus(&info[((size_t)2 * t) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
+            runsAndConsensus(&info[((size_t)2 * t + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
         }
     }
     g_totals.prepare_ms += nowMs() - tPrep;
@@ -345,16 +344,20 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
                 if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; }
             }
+            std::vector<int32_t> fetch, fetchLen;
             for (int i = 0; i < n; ++i) {
                 if (!mask[i]) continue;
                 errs[i] = err[i];
                 const int32_t len = (err[i] == 0) ? alnLen[i] : 0;
                 if (!inPlace) paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + len);
-                else if (needsHost[i]) {
-                    paths[i].resize((size_t)len);
-                    const int r2 = twl_level_read_path(g_stores[d], i, paths[i].data(), len);
-                    if (r2 != TWL_OK) return r2;
-                } else if (len > 0) { fromDp[i] = 1; dpLen[i] = len; }
+                else if (needsHost[i]) { if (len > 0) { fetch.push_back(i); fetchLen.push_back(len); } else paths[i].clear(); }
+                else if (len > 0) { fromDp[i] = 1; dpLen[i] = len; }
+            }
+            if (!fetch.empty()) {               // the pairs the host has to edit: their paths only, one synchronisation
+                int8_t *blk = reinterpret_cast<int8_t *>(g_alnStage[d].get(fetch.size() * (size_t)2 * stride));
+                const int r2 = twl_level_read_paths(g_stores[d], (int32_t)fetch.size(), fetch.data(), fetchLen.data(), blk, 2 * stride);
+                if (r2 != TWL_OK) return r2;
+                for (size_t t = 0; t < fetch.size(); ++t) paths[fetch[t]].assign(&blk[t * (size_t)2 * stride], &blk[t * (size_t)2 * stride] + fetchLen[t]);
             }
         }
         return (int)TWL_OK;

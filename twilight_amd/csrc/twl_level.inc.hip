@@ -65,14 +65,31 @@ void build_lut(char type, uint8_t *lut)
     }
 }
 
-int grow_rows(twl_store *s, int64_t need)
+// Room for the rows.  Re-pitching costs two allocations of n_seqs x cap bytes, a copy and two frees (hundreds of ms for 100 000 sequences),
+// and the final alignment is several times longer than the sequences (6.6x at 10 000 x 10 kbp, 22x at 100 000 x 1.6 kbp), so the planes
+// start at 8x the longest sequence and double when they have to -- within a budget of a sixth of the device memory for both planes
+// (288 GB of HBM are there to be used), never below what is needed.
+int64_t rows_budget_cap(twl_store *s)
+{
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return INT64_MAX; }
+    const int64_t budget = (int64_t)(totalB / 6);
+    return std::max<int64_t>(256, budget / (2 * std::max<int64_t>(1, s->n_seqs)));
+}
+
+int grow_rows(twl_store *s, int64_t need, int64_t want = 0)
 {
     if (need <= s->cap) return TWL_OK;
     Device *d = s->d;
-    int64_t ncap = (need + need / 4 + 255) & ~(int64_t)255;
+    int64_t ncap = std::max(need, std::min(std::max(want, 2 * need), rows_budget_cap(s)));
+    ncap = (ncap + 255) & ~(int64_t)255;
     for (int pl = 0; pl < 2; ++pl) {
         Buf nb;
         int rc = nb.ensure((size_t)s->n_seqs * (size_t)ncap);
+        if (rc && ncap > ((need + 255) & ~(int64_t)255)) {      // not that much room: take what is needed
+            ncap = (need + 255) & ~(int64_t)255;
+            rc = nb.ensure((size_t)s->n_seqs * (size_t)ncap);
+        }
         if (rc) return rc;
         if (s->rows[pl].p)
             HIP_TRY(hipMemcpy2DAsync(nb.p, (size_t)ncap, s->rows[pl].p, (size_t)s->cap, (size_t)s->cap, (size_t)s->n_seqs, hipMemcpyDeviceToDevice, d->stream));
@@ -118,12 +135,14 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
         if (lens[i] < 0) { delete s; g_err = "negative sequence length"; return TWL_ERR_BAD_ARGUMENT; }
         maxLen = std::max<int64_t>(maxLen, lens[i]);
     }
-    // room for the alignment to grow before the first re-allocation (rows are re-pitched when a commit outgrows them)
-    if ((rc = grow_rows(s, maxLen + maxLen / 2 + 256))) { twl_store_destroy(s); return rc; }
-    // upload plane 0 through one pitched host image
-    std::vector<char> img((size_t)n_seqs * (size_t)s->cap, '-');
-    for (int32_t i = 0; i < n_seqs; ++i) memcpy(&img[(size_t)i * (size_t)s->cap], seqs[i], (size_t)lens[i]);
-    if (!img.empty()) HIP_TRY(hipMemcpy(s->rows[0].p, img.data(), img.size(), hipMemcpyHostToDevice));
+    // room for the alignment to grow (see grow_rows); the sequences go up through a tight host image with its own pitch
+    if ((rc = grow_rows(s, maxLen + 1, 8 * maxLen + 256))) { twl_store_destroy(s); return rc; }
+    if (n_seqs > 0) {
+        const size_t hp = (size_t)maxLen;
+        std::unique_ptr<char[]> img(new char[(size_t)n_seqs * hp]);
+        for (int32_t i = 0; i < n_seqs; ++i) { memcpy(&img[(size_t)i * hp], seqs[i], (size_t)lens[i]); memset(&img[(size_t)i * hp + (size_t)lens[i]], '-', hp - (size_t)lens[i]); }
+        HIP_TRY(hipMemcpy2D(s->rows[0].p, (size_t)s->cap, img.get(), hp, hp, (size_t)n_seqs, hipMemcpyHostToDevice));
+    }
     uint8_t lut[256];
     build_lut(type, lut);
     if ((rc = s->lut.ensure(256))) { twl_store_destroy(s); return rc; }
@@ -403,6 +422,36 @@ int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len)
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
     if (len) HIP_TRY(hipMemcpy(out, (const int8_t *)s->d_aln.p + (size_t)pair * 2 * (size_t)s->seq_len, (size_t)len, hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
+int twl_level_read_colinfo_many(twl_store *s, int32_t n_sel, const int32_t *pairs, uint8_t *out)
+{
+    if (!s || !s->prepared || n_sel < 0 || (n_sel > 0 && (!pairs || !out))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    const size_t sl = (size_t)s->seq_len;
+    for (int32_t t = 0; t < n_sel; ++t) {
+        if (pairs[t] < 0 || pairs[t] >= s->n_pairs) { g_err = "pair index out of range"; return TWL_ERR_BAD_ARGUMENT; }
+        HIP_TRY(hipMemcpyAsync(out + (size_t)t * 2 * sl, (const uint8_t *)s->d_colinfo.p + (size_t)pairs[t] * 2 * sl, 2 * sl, hipMemcpyDeviceToHost, d->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return TWL_OK;
+}
+
+int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, int8_t *out, int32_t out_stride)
+{
+    if (!s || !s->prepared || n_sel < 0 || (n_sel > 0 && (!pairs || !lens || !out || !s->d_aln.p)) || out_stride < 0) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    const size_t sl = (size_t)s->seq_len;
+    for (int32_t t = 0; t < n_sel; ++t) {
+        if (pairs[t] < 0 || pairs[t] >= s->n_pairs || lens[t] < 0 || lens[t] > out_stride || (size_t)lens[t] > 2 * sl) { g_err = "bad selection"; return TWL_ERR_BAD_ARGUMENT; }
+        if (lens[t]) HIP_TRY(hipMemcpyAsync(out + (size_t)t * (size_t)out_stride, (const int8_t *)s->d_aln.p + (size_t)pairs[t] * 2 * sl, (size_t)lens[t], hipMemcpyDeviceToHost, d->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream));
     return TWL_OK;
 }
 
