@@ -160,11 +160,12 @@ def test_rows_grow_past_initial_capacity(gpu):
     from twilight_amd import level as L
 
     rng = np.random.default_rng(5)
-    seqs = [bytes(rng.choice(list(b"ACGT"), size=400).astype(np.uint8)) for _ in range(4)] + [b"ACGTAC"]
-    st = L.Store(seqs, "n")                      # initial pitch 1280 columns for 400-letter sequences
+    N = 20
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=400).astype(np.uint8)) for _ in range(N)] + [b"ACGTAC"]
+    st = L.Store(seqs, "n")                      # initial pitch 16 x 400 + 256 = 6656 columns for 400-letter sequences
     p = twl.make_params(LC.matrix_of("n"))
     members, total = [0], 400
-    for nxt in (1, 2, 3):                        # end-to-end concatenation: 800, 1200, 1600 columns
+    for nxt in range(1, N):                      # end-to-end concatenation: 800, 1200, ... 8000 columns (past the pitch from 6800 on)
         k = len(members)
         st.prepare(p, [[L.Side(list(members), np.full(k, 1.0, dtype=F), total, k, float(k)), L.Side([nxt], np.asarray([1.0], dtype=F), 400, 1, 1.0)]],
                    gappy_threshold=1.0)
@@ -172,9 +173,9 @@ def test_rows_grow_past_initial_capacity(gpu):
         members.append(nxt)
         total += 400
     rows = st.rows()
-    for i in range(4):
-        assert rows[i] == b"-" * (400 * i) + seqs[i] + b"-" * (400 * (3 - i)), f"row {i}"
-    assert rows[4] == seqs[4]
+    for i in range(N):
+        assert rows[i] == b"-" * (400 * i) + seqs[i] + b"-" * (400 * (N - 1 - i)), f"row {i}"
+    assert rows[N] == seqs[N]
     st.close()
 
 

@@ -65,10 +65,11 @@ void build_lut(char type, uint8_t *lut)
     }
 }
 
-// Room for the rows.  Re-pitching costs two allocations of n_seqs x cap bytes, a copy and two frees (hundreds of ms for 100 000 sequences),
-// and the final alignment is several times longer than the sequences (6.6x at 10 000 x 10 kbp, 22x at 100 000 x 1.6 kbp), so the planes
-// start at 8x the longest sequence and double when they have to -- within a budget of a sixth of the device memory for both planes
-// (288 GB of HBM are there to be used), never below what is needed.
+// Room for the rows.  The final alignment is several times longer than the sequences (6.6x at 10 000 x 10 kbp, 22x on the synthetic
+// 100 000 x 1.6 kbp family), and re-pitching costs more than its copy: device memory the process has not touched before comes at tens of
+// ms per GB (tools/micro/alloc_cost.hip: a first 16 GB allocation 1.3 s, recycled ones < 1 ms), which a pass must not pay in its middle.
+// So the planes start at 16x the longest sequence and grow by half when they have to -- within a budget of a sixth of the device memory
+// for both planes (288 GB of HBM are there to be used), never below what is needed.
 int64_t rows_budget_cap(twl_store *s)
 {
     size_t freeB = 0, totalB = 0;
@@ -81,7 +82,7 @@ int grow_rows(twl_store *s, int64_t need, int64_t want = 0)
 {
     if (need <= s->cap) return TWL_OK;
     Device *d = s->d;
-    int64_t ncap = std::max(need, std::min(std::max(want, 2 * need), rows_budget_cap(s)));
+    int64_t ncap = std::max(need, std::min(std::max(want, need + need / 2), rows_budget_cap(s)));
     ncap = (ncap + 255) & ~(int64_t)255;
     for (int pl = 0; pl < 2; ++pl) {
         Buf nb;
@@ -136,7 +137,7 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
         maxLen = std::max<int64_t>(maxLen, lens[i]);
     }
     // room for the alignment to grow (see grow_rows); the sequences go up through a tight host image with its own pitch
-    if ((rc = grow_rows(s, maxLen + 1, 8 * maxLen + 256))) { twl_store_destroy(s); return rc; }
+    if ((rc = grow_rows(s, maxLen + 1, 16 * maxLen + 256))) { twl_store_destroy(s); return rc; }
     if (n_seqs > 0) {
         const size_t hp = (size_t)maxLen;
         std::unique_ptr<char[]> img(new char[(size_t)n_seqs * hp]);
