@@ -718,7 +718,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             if (k == marker - 1) conv_S = (sL == sU) ? ((3 << 16) | (sL & 0xFFFF)) : -1;
                             else conv_S = (sL == sU) ? (sL & 0xFFFF) : -1;
                         } else {
-                            if (threadIdx.x == 0) lds_st<nuc_i4>(vprev + O_CONV, nuc_i4{0x7fffffff, (int)0x80000000, 0, 0});
+                            if (threadIdx.x == 0) {
+                                // (made inside the branch: hoisted out of the loop these four registers were spilled to scratch in the
+                                // 128-register kernels and re-loaded by wave 0 on every diagonal of phase C)
+                                int c0 = 0x7fffffff, c1 = (int)0x80000000, c2 = 0;
+                                asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));
+                                lds_st<nuc_i4>(vprev + O_CONV, nuc_i4{c0, c1, c2, c2});
+                            }
                             const unsigned cw = (unsigned)(newU - newL);
 #pragma unroll
                             for (int r = 0; r < RPL; ++r) {
