@@ -279,6 +279,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     { const int ms = p->P - 1; for (int l = 0; l < ms; ++l) for (int m = 0; m < ms; ++m) a.M[ms * l + m] = p->matrix[ms * l + m]; }
 
     int grid = 0, window = 0;
+    bool protSmall = false;       // protein, first stage on the 512-row kernel
     const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
@@ -347,6 +348,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
                 if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
                 rc = launch_lean<22, 16, 1, 3, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+            } else if (lean && n_pairs > d->num_cu && !getenv("TWL_PROT_NO_SMALL")) {
+                // more pairs than CUs: the 512-row window (8 waves, one block each; protein bands of 2 kaa pairs are ~270 rows wide, ~400
+                // at most) keeps the ring at 61 KB, so two workgroups share a CU like in the nucleotide throughput kernel; a pair
+                // whose band outgrows it goes to the 1024-row kernel below
+                rc = launch_lean<22, 8, 1, 3, 4>(d, st, a, items, n_pairs, &grid, &window);
+                protSmall = true;
             } else if (lean) {
                 rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, items, n_pairs, &grid, &window);
             } else {
@@ -423,11 +430,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
         if (redo.empty()) break;
         if (force_wide) { g_err = "band wider than the wide window"; return TWL_ERR_UNSUPPORTED; }
-        const bool mid = (stage == 1) && !prot;
+        const bool mid = (stage == 1) && (!prot || protSmall);
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
         int grid2 = 0, w2 = 0;
-        if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
+        if (mid && prot) rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        else if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
         else rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(d->ev[4], st));
