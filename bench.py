@@ -202,12 +202,14 @@ def wallclock_to_msa(tree, fasta, typ, d):
 
 def variant_of(pairs, num_cu, P):
     """The DP kernel instantiation the library launches for a level of `pairs` pairs (twl_align.hip, run_device): two workgroups per pair
-    with speculative tile start up to CUs/2 pairs, one 16-wave workgroup per pair up to CUs (nucleotide) / CUs/2 (protein, precomputed
-    scores), the throughput geometry beyond."""
+    with speculative tile start up to CUs/2 pairs (protein: on precomputed scores), one 16-wave workgroup per pair up to CUs, the
+    throughput geometry beyond (two workgroups per CU: 8 waves x 2 blocks, protein 8 waves x 1 block on a 512-row window)."""
     if P == 22:
         if pairs <= max(1, num_cu // 2):
             return "talco_lean_kernel<22, 16, 1, 4, 1, true, false> (precomputed column scores, speculative tile start)"
-        return "talco_lean_kernel<22, 16, 1, 3, 1, false, false> (sparse column scores)"
+        if pairs <= num_cu:
+            return "talco_lean_kernel<22, 16, 1, 3, 1, false, false> (sparse column scores)"
+        return "talco_lean_kernel<22, 8, 1, 3, 4, false, false> (sparse column scores, 512-row window, two workgroups per CU)"
     if 2 * pairs <= num_cu:
         return "talco_lean_kernel<6, 16, 1, 2, 1, true, false> (speculative tile start)"
     return "talco_lean_kernel<6, 16, 1, 2, 1, false, false>" if pairs <= num_cu else "talco_lean_kernel<6, 8, 2, 2, 4, false, false>"
