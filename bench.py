@@ -200,19 +200,25 @@ def wallclock_to_msa(tree, fasta, typ, d):
             "note": "twilight-mi355x on the same family files, 1 GPU, time of the whole process (HIP start-up, read FASTA + tree, align, write MSA)"}
 
 
-def variant_of(pairs, num_cu, P):
-    """The DP kernel instantiation the library launches for a level of `pairs` pairs (twl_align.hip, run_device): two workgroups per pair
-    with speculative tile start up to CUs/2 pairs (protein: on precomputed scores), one 16-wave workgroup per pair up to CUs, the
-    throughput geometry beyond (two workgroups per CU: 8 waves x 2 blocks, protein 8 waves x 1 block on a 512-row window)."""
+def variant_of(pairs, num_cu, P, mode=-1, spec=-1):
+    """The DP kernel instantiation the library launched for a level of `pairs` pairs (twl_align.hip, run_device), as rocprofv3 names it: two
+    workgroups per pair with speculative tile start up to CUs/2 pairs (protein: on precomputed scores), one 16-wave workgroup per pair
+    up to CUs, the throughput geometry beyond (two workgroups per CU: 8 waves x 2 blocks, protein 8 waves x 1 block on a 512-row
+    window).  `mode` / `spec` are the level record's matrix_mode / speculative (nucleotide mode 5: single-sequence query sides)."""
     if P == 22:
         if pairs <= max(1, num_cu // 2):
             return "talco_lean_kernel<22, 16, 1, 4, 1, true, false> (precomputed column scores, speculative tile start)"
         if pairs <= num_cu:
             return "talco_lean_kernel<22, 16, 1, 3, 1, false, false> (sparse column scores)"
         return "talco_lean_kernel<22, 8, 1, 3, 4, false, false> (sparse column scores, 512-row window, two workgroups per CU)"
-    if 2 * pairs <= num_cu:
-        return "talco_lean_kernel<6, 16, 1, 2, 1, true, false> (speculative tile start)"
-    return "talco_lean_kernel<6, 16, 1, 2, 1, false, false>" if pairs <= num_cu else "talco_lean_kernel<6, 8, 2, 2, 4, false, false>"
+    mm = mode if mode in (0, 1, 2, 5) else 2
+    note = " (one-letter query rows)" if mm == 5 else ""
+    is_spec = (2 * pairs <= num_cu) if spec < 0 else bool(spec)
+    if is_spec:
+        return f"talco_lean_kernel<6, 16, 1, {mm}, 1, true, false> (speculative tile start)" + note
+    if pairs <= num_cu:
+        return f"talco_lean_kernel<6, 16, 1, {mm}, 1, false, false>" + note
+    return f"talco_lean_kernel<6, 8, 2, {mm}, {4 if mm in (2, 5) else 2}, false, false>" + note
 
 
 def main():
@@ -363,7 +369,7 @@ def main():
             out["levels"] = [{"pairs": int(lv.pairs), "cells": int(lv.band_cells), "kernel_ms": round(lv.kernel_ms, 3), "level_ms": round(lv.level_ms, 3)} for lv in levels]
             by = {}
             for lv in levels:
-                v = by.setdefault(variant_of(lv.pairs, num_cu, cfg["P"]), [0, 0.0, 0])
+                v = by.setdefault(variant_of(lv.pairs, num_cu, cfg["P"], int(lv.matrix_mode), int(lv.speculative)), [0, 0.0, 0])
                 v[0] += 1; v[1] += lv.kernel_ms; v[2] += lv.band_cells
             kernels = [{"kernel": k, "launches": v[0], "avg_ms": v[1] / v[0], "cells_per_launch": v[2] // v[0],
                         "frac": (v[2] * bcell / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[1] > 0 else 0.0} for k, v in by.items()]

@@ -59,6 +59,8 @@ typedef struct twl_stats {
     int32_t  n_relaunched;    /* pairs re-run with the wide-window kernel */
     int32_t  window;          /* rows of the fast-path window used */
     int32_t  grid;            /* persistent workgroups launched */
+    int32_t  matrix_mode;     /* column-score mode of the first DP launch: nucleotide 0 / 1 / 2 / 5 (one-letter query rows), protein 3 / 4 */
+    int32_t  speculative;     /* 1: two workgroups per pair with speculative tile start */
 } twl_stats;
 
 /* Select devices (HIP ordinals).  n_devices==0 or device_ids==NULL -> device 0 only.

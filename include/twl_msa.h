@@ -31,6 +31,8 @@ typedef struct twl_msa_level {
     double   kernel_ms;     /* DP kernel time (HIP events; max over the ranks / devices that ran concurrently) */
     double   level_ms;      /* host wall time of the level-kernel call */
     double   exchange_ms;   /* of which: all-gather of the paths between processes */
+    int32_t  matrix_mode;   /* column-score mode of the level's DP kernel (twl_stats.matrix_mode; -1 unknown) */
+    int32_t  speculative;   /* 1: the speculative two-workgroup kernel ran the level */
 } twl_msa_level;
 
 typedef struct twl_msa_totals {

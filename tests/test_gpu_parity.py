@@ -270,15 +270,16 @@ def test_column_scores_match_oracle(gpu, kind):
             assert got.shape == want.shape and np.array_equal(got, want), f"{kind} pair {i}: {int((got != want).sum())} of {got.size} cells differ"
 
 
-@pytest.mark.parametrize("kind", ["nuc_mode2", "nuc_mode2_leaf", "nuc_mode1", "nuc_mode0_wildcard", "nuc_mode0_random", "prot_sparse"])
-def test_scores_inside_the_dp_kernel_match_oracle(gpu, kind):
+@pytest.mark.parametrize("kind", ["nuc_mode2", "nuc_mode2_leaf", "nuc_mode5_leaf_query", "nuc_mode5_leaf_query_general_core", "nuc_mode1", "nuc_mode0_wildcard",
+                                  "nuc_mode0_random", "prot_sparse"])
+def test_scores_inside_the_dp_kernel_match_oracle(gpu, kind, monkeypatch):
     """The column score of every cell the band visits, written out by a diagnostics instantiation of the DP kernel itself (same code:
     hoisted-reciprocal division, row-pair packed products, sparse protein loop), against twlo_column_score -- equal as floats."""
     rng = np.random.default_rng(5)
     P = 22 if kind == "prot_sparse" else 6
     if kind == "prot_sparse": mat = synth.protein_matrix().copy()
-    elif kind in ("nuc_mode2", "nuc_mode2_leaf"): mat = synth.nucleotide_matrix().copy()
-    elif kind == "nuc_mode1":
+    elif kind in ("nuc_mode2", "nuc_mode2_leaf", "nuc_mode5_leaf_query"): mat = synth.nucleotide_matrix().copy()
+    elif kind in ("nuc_mode1", "nuc_mode5_leaf_query_general_core"):
         mat = rng.integers(-9, 19, size=(5, 5)).astype(np.float32)
         mat[4, :] = 0
         mat[:, 4] = 0
@@ -288,6 +289,11 @@ def test_scores_inside_the_dp_kernel_match_oracle(gpu, kind):
         mat[:, 4] = 18.0
     else: mat = rng.integers(-9, 19, size=(5, 5)).astype(np.float32)
     members = (1, 1) if kind == "nuc_mode2_leaf" else ((2, 7), (1, 5))
+    if kind.startswith("nuc_mode5"):
+        # single-sequence query sides (profiles on the reference side): the device-resident level path tells the kernels, which then take
+        # the one-letter form of the column score (matrix mode 5); through this entry the test has to say so itself
+        members = ((2, 7), 1)
+        monkeypatch.setenv("TWL_ASSUME_ONEHOT_QUERY", "1")
     b = synth.make_level_batch(2, 700, members=members, seed=37, P=P, sub=0.1, gap_col_rate=0.1)
     for gap_char in (None, 0.0):
         pk = dict(marker=128)          # several tiles: the tile offsets of the dump are exercised too

@@ -27,7 +27,7 @@ class TwlParams(C.Structure):
 class TwlStats(C.Structure):
     _fields_ = [("band_cells", C.c_uint64), ("nominal_cells", C.c_uint64), ("kernel_ms", C.c_double),
                 ("pack_ms", C.c_double), ("total_ms", C.c_double), ("n_launches", C.c_int32),
-                ("n_relaunched", C.c_int32), ("window", C.c_int32), ("grid", C.c_int32)]
+                ("n_relaunched", C.c_int32), ("window", C.c_int32), ("grid", C.c_int32), ("matrix_mode", C.c_int32), ("speculative", C.c_int32)]
 
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",

@@ -96,7 +96,7 @@ int twl_msa_report(twl_msa *m, twl_msa_totals *t, twl_msa_level *levels, int32_t
     for (int32_t i = 0; levels && i < max_levels && i < (int32_t)recs.size(); ++i) {
         levels[i].pairs = recs[i].pairs; levels[i].task = recs[i].task; levels[i].band_cells = recs[i].band_cells;
         levels[i].relaunched = recs[i].relaunched; levels[i].kernel_ms = recs[i].kernel_ms; levels[i].level_ms = recs[i].level_ms;
-        levels[i].exchange_ms = recs[i].exchange_ms;
+        levels[i].exchange_ms = recs[i].exchange_ms; levels[i].matrix_mode = recs[i].matrix_mode; levels[i].speculative = recs[i].speculative;
     }
     return 0;
 }

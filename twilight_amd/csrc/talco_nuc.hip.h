@@ -169,17 +169,17 @@ struct NCfg {
 
 // P = 6 (nucleotide) or 22 (protein).  MM = column-score mode, host-selected (every mode of an alphabet computes the same sums, see
 // talco_kernel): nucleotide 0 general 5x5, 1 zero N row/column (4x4 core), 2 mode 1 with the match / transition / transversion
-// structure (three products per row letter); protein 3 loop over the non-zero letters of the reference column, 4 scores
+// structure (three products per row letter), 5 modes 1 / 2 for query rows with one non-zero letter (single sequences); protein 3 loop over the non-zero letters of the reference column, 4 scores
 // precomputed by score_matrix_kernel for the whole R x Q matrix (launches with few pairs: the other CUs are idle anyway).
 template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
 __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 {
-    static_assert((P == 6 && MM >= 0 && MM <= 2) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
+    static_assert((P == 6 && ((MM >= 0 && MM <= 2) || MM == 5)) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
     using C = NCfg<W, RPL>;
     constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
     // first products q[m]*M[l][m] kept per row as PAIRS over two matrix rows, {l = 2h, l = 2h+1}, so that the second product and the
     // sums of two rows are one packed instruction each with every operand in an aligned register pair: NQP pairs (+ row 4 in mode 0)
-    constexpr int NQP = (MM == 2 || MM == 1) ? 8 : (MM == 0 ? 10 : 1);
+    constexpr int NQP = (MM == 2 || MM == 1) ? 8 : (MM == 0 ? 10 : (MM == 5 ? 2 : 1));
     constexpr int NQM = (MM == 0) ? 5 : 1;
     constexpr int F4 = (P + 2) / 4;                       // float4 per packed column: 2 or 6
     constexpr bool SPARSE = (MM == 3), PRESIM = (MM == 4);
@@ -355,6 +355,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         for (int m = 0; m < 4; ++m)
 #pragma unroll
                             for (int h = 0; h < 2; ++h) qP[r][2 * m + h] = nuc_f2{qv[r][m] * a.M[5 * (2 * h) + m], qv[r][m] * a.M[5 * (2 * h + 1) + m]};
+                    } else if constexpr (MM == 5) {
+                        // Query rows with ONE non-zero letter (a single sequence; the host says so): of the four products of a matrix row only
+                        // that letter's is not +-0, so s_l = ((t0 + t1) + t2) + t3 collapses to (q[m*] * M[l][m*]) * r[l] exactly.  Kept per row:
+                        // qT[l] = the row sum of the first products (= q[m*] * M[l][m*]); the score is then four products and three sums.
+                        float qT[4];
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) qT[l] = ((qv[r][0] * a.M[5 * l + 0] + qv[r][1] * a.M[5 * l + 1]) + qv[r][2] * a.M[5 * l + 2]) + qv[r][3] * a.M[5 * l + 3];
+                        qP[r][0] = nuc_f2{qT[0], qT[1]};
+                        qP[r][1] = nuc_f2{qT[2], qT[3]};
                     } else if constexpr (MM == 0) {
 #pragma unroll
                         for (int m = 0; m < 5; ++m) {
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             rg = c1.y; gopr = c1.z; gexr = c1.w;
                             // ---- column score, :378-395 (order: per l the products summed left to right, accumulated over l) ----
                             // rows {0,1} and {2,3} side by side: t[l][m] = (q[m]*M[l][m]) * r[l]; s_l = ((t0 + t1) + t2) + t3 (+ t4)
-                            constexpr int NM = (MM == 0) ? 5 : 4;
+                            constexpr int NM = (MM == 0) ? 5 : (MM == 5 ? 1 : 4);
                             const nuc_f2 r01 = nuc_f2{c0.x, c0.y}, r23 = nuc_f2{c0.z, c0.w};
                             nuc_f2 s01 = qP[r][0] * r01, s23 = qP[r][1] * r23;
 #pragma unroll

@@ -213,8 +213,10 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
-               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len, const float *d_packed = nullptr)
+               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len, const float *d_packed = nullptr, bool qry_onehot = false)
 {
+    // qry_onehot: every query row of every pair of this call has at most one non-zero letter (single sequences: the device-resident
+    // level path knows, it built the profiles) -- the nucleotide kernels then take the four-product form of the column score
     // d_packed: the level's columns already in the packed [P+2] layout (device-resident level path); no packing pass then
     HIP_TRY(hipSetDevice(d->id));
     d->stats = twl_stats{};
@@ -280,6 +282,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
+    int statMode = -1, statSpec = 0;
     const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
@@ -327,6 +330,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
             const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few)) && fits && !d->dump_on;
+            statMode = presim ? 4 : 3;
             if (presim) {
                 if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
                 if ((rc = d->sim_off.ensure(off.size() * sizeof(long long)))) return rc;
@@ -342,6 +346,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
+                statSpec = (lean && 2 * n_pairs <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) ? 1 : 0;
                 if (lean && 2 * n_pairs <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_pairs, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_pairs, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
@@ -383,20 +388,28 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         int32_t maxLen = 0;
         for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLen = std::max(maxLen, h_len[t]);
         // (the mailbox words of the speculative start carry absolute positions in 16 bits each)
-        const bool spec = lean && few && mm == 2 && 2 * n_pairs <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
+        // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
+        const bool mm5 = lean && mm >= 1 && (qry_onehot || getenv("TWL_ASSUME_ONEHOT_QUERY") != nullptr) && !getenv("TWL_NO_ONEHOT");
+        const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_pairs <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
+        statMode = mm5 ? 5 : mm;
+        statSpec = spec ? 1 : 0;
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
-            if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
         }
+        else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_pairs, &grid, &window);
         else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
         else if (lean && few) {
-            if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm5) rc = launch_lean<6, 16, 1, 5, 1>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_pairs, &grid, &window);
         } else if (lean) {
-            if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm5) rc = launch_lean<6, 8, 2, 5, 4>(d, st, a, items, n_pairs, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, n_pairs, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, n_pairs, &grid, &window);
             else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, n_pairs, &grid, &window);
         }
@@ -417,6 +430,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     d->stats.n_launches = 1;
     d->stats.grid = grid;
     d->stats.window = window;
+    d->stats.matrix_mode = statMode;
+    d->stats.speculative = statSpec;
 
     // Pairs whose band outgrew a window are re-run, bit-identically, by the next stage: 1024-row fast window ->
     // 2048-row window (16 waves x 2 blocks, LDS ring) -> 4608-row window (covers flen = 4096; columns from L2/HBM).

@@ -393,8 +393,12 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     if ((rc = s->d_alnlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
     if ((rc = s->d_err.ensure((size_t)n * sizeof(int16_t)))) return rc;
     HIP_TRY(hipEventRecord(d->ev[5], st));
+    // every selected query side a single, uncached sequence: its profile rows hold one letter each (profile_kernel built them)
+    bool qryOneHot = true;
+    for (int32_t i = 0; i < n && qryOneHot; ++i)
+        if (lm[2 * i] > 0 && lm[2 * i + 1] > 0) qryOneHot = s->sides[2 * (size_t)i + 1].n_members == 1 && s->sides[2 * (size_t)i + 1].cache_id < 0;
     rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->d_lenmask.p, (const int32_t *)s->d_num.p, (int8_t *)s->d_aln.p,
-                    (int32_t *)s->d_alnlen.p, (int16_t *)s->d_err.p, lm.data(), (const float *)s->d_cols.p);
+                    (int32_t *)s->d_alnlen.p, (int16_t *)s->d_err.p, lm.data(), (const float *)s->d_cols.p, qryOneHot);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(aln_len_out, s->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(err_out, s->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
