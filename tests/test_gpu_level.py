@@ -256,3 +256,31 @@ def test_commit_from_dp_output_equals_commit_of_downloaded_paths(gpu, seq_type):
     got = b.rows()
     b.close()
     assert got == want
+
+
+def test_geometry_follows_the_pairs_that_run(gpu):
+    """A rank of a sharded run (or one gap-character group) aligns a masked share of the level: the kernel geometry must be chosen by the
+    number of pairs that RUN -- 10 of 300 pairs take the speculative two-workgroup kernel (20 workgroups), not the throughput kernel
+    the whole level would take -- and the masked-out pairs come back with length 0 and errorType 0."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    cases = [LC.make_case("n", seed, cached=0, length=80 + (seed % 7) * 9) for seed in range(300)]
+    seqs, pairs, ids = _level(cases)
+    p = twl.make_params(LC.matrix_of("n"))
+    st = L.Store(seqs, "n")
+    st.prepare(p, pairs, gappy_threshold=0.95)
+    aln_all, n_all, err_all = st.align(p)
+    s_all = twl.get_stats(0)
+    assert s_all.speculative == 0 and s_all.grid > 256
+    mask = np.zeros(len(cases), dtype=np.uint8)
+    mask[5:15] = 1
+    aln_m, n_m, err_m = st.align(p, run_mask=mask)
+    s_m = twl.get_stats(0)
+    assert s_m.speculative == 1 and s_m.grid == 20, (s_m.speculative, s_m.grid)
+    for i in range(len(cases)):
+        if mask[i]:
+            assert err_m[i] == err_all[i] and n_m[i] == n_all[i] and np.array_equal(aln_m[i, : n_m[i]], aln_all[i, : n_all[i]]), f"pair {i}"
+        else:
+            assert n_m[i] == 0 and err_m[i] == 0, f"masked-out pair {i}"
+    st.close()

@@ -241,9 +241,15 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     std::vector<int32_t> order((size_t)n_pairs);
     std::iota(order.begin(), order.end(), 0);
+    // (pairs with an empty side -- masked out by the caller, or really empty -- come last and are not launched at all: what the geometry
+    // is chosen by is the number of pairs that run, e.g. a rank's share of a level)
+    auto live = [&](int32_t x) { return h_len[2 * x] > 0 && h_len[2 * x + 1] > 0; };
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        if (live(x) != live(y)) return live(x);
         return (int64_t)h_len[2 * x] + h_len[2 * x + 1] > (int64_t)h_len[2 * y] + h_len[2 * y + 1];
     });
+    int32_t n_run = 0;
+    for (int32_t n = 0; n < n_pairs; ++n) n_run += live(n) ? 1 : 0;
     uint64_t nominal = 0;
     for (int32_t n = 0; n < n_pairs; ++n) nominal += (uint64_t)std::max(0, h_len[2 * n]) * (uint64_t)std::max(0, h_len[2 * n + 1]);
     HIP_TRY(hipMemcpyAsync(d->items.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -280,6 +286,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     { const int ms = p->P - 1; for (int l = 0; l < ms; ++l) for (int m = 0; m < ms; ++m) a.M[ms * l + m] = p->matrix[ms * l + m]; }
 
+    // the pairs that do not run: path length 0, errorType 0, no cells
+    HIP_TRY(hipMemsetAsync(d_alnlen, 0, (size_t)n_pairs * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(d_err, 0, (size_t)n_pairs * sizeof(int16_t), st));
+    HIP_TRY(hipMemsetAsync(d->cells.p, 0, (size_t)n_pairs * sizeof(unsigned long long), st));
+
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
@@ -291,7 +302,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         return prot ? launch_dp<22, 8, 9, false, false, false>(d, st, a, it, n_it, 1, g, w)
                     : launch_dp<6, 8, 9, false, false, true>(d, st, a, it, n_it, 1, g, w);
     };
-    if (force_wide) rc = launch_wide(items, n_pairs, &grid, &window);
+    if (n_run == 0) rc = TWL_OK;      // nothing to align in this call
+    else if (force_wide) rc = launch_wide(items, n_run, &grid, &window);
     else if (prot) {
         // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
         const char *pc = getenv("TWL_PROT_CFG");      // development knob
@@ -302,8 +314,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         for (int t = 0; t < 441; ++t) divOk = divOk && inRange(a.M[t]);
         divOk = divOk && inRange(p->gap_char);
         const bool lean = divOk && (pcs == "auto" || pcs == "lean_sparse" || pcs == "lean_presim");
-        if (pcs == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else if (pcs == "dense") rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+        if (pcs == "r1") rc = launch_dp<22, 8, 1, false, true, true>(d, st, a, items, n_run, 0, &grid, &window);
+        else if (pcs == "dense") rc = launch_dp<22, 8, 2, false, true, true>(d, st, a, items, n_run, 0, &grid, &window);
         else {
             // Few pairs (upper tree levels): the serial diagonal chain of each pair is what costs, and most of its instructions are the
             // column score.  Scores do not depend on the DP state, so the otherwise idle CUs compute them for the whole R x Q matrix
@@ -311,7 +323,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             size_t simFloats = 0;
             std::vector<long long> off((size_t)n_pairs, 0);
             std::vector<int32_t> blk((size_t)n_pairs + 1, 0);
-            for (int32_t t = 0; t < n_pairs; ++t) {
+            for (int32_t t = 0; t < n_run; ++t) {
                 const int32_t pr = order[t];
                 const long long R = std::max(0, h_len[2 * pr]), Q = std::max(0, h_len[2 * pr + 1]);
                 off[pr] = (long long)simFloats;
@@ -322,8 +334,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             }
             int32_t maxLenP = 0;
             for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLenP = std::max(maxLenP, h_len[t]);
-            const bool few = n_pairs <= std::max(1, d->num_cu / 2);      // measured break-even vs the sparse in-kernel path: ~150 pairs of 2 kaa
-            const bool fits = simFloats * sizeof(float) <= ((size_t)16 << 30) && blk[n_pairs] > 0;
+            const bool few = n_run <= std::max(1, d->num_cu / 2);      // measured break-even vs the sparse in-kernel path: ~150 pairs of 2 kaa
+            const bool fits = simFloats * sizeof(float) <= ((size_t)16 << 30) && blk[n_run] > 0;
             if ((rc = d->m24.ensure(21 * 24 * sizeof(float)))) return rc;
             std::vector<float> m24(21 * 24, 0.0f);
             for (int l = 0; l < 21; ++l) for (int m = 0; m < 21; ++m) m24[24 * l + m] = a.M[21 * l + m];
@@ -340,29 +352,29 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipStreamSynchronize(st));      // the host vectors above go out of scope
                 twl::ScoreArgs sa{};
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
-                sa.n_items = n_pairs; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p;
+                sa.n_items = n_run; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p;
                 sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
-                hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_pairs]), dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_run]), dim3(256), 0, st, sa);
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
-                statSpec = (lean && 2 * n_pairs <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) ? 1 : 0;
-                if (lean && 2 * n_pairs <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_pairs, &grid, &window);
-                else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_pairs, &grid, &window);
-                else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_pairs, 0, &grid, &window);
+                statSpec = (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) ? 1 : 0;
+                if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
+                else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_run, &grid, &window);
+                else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_run, 0, &grid, &window);
             } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
-                if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
-                rc = launch_lean<22, 16, 1, 3, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
-            } else if (lean && n_pairs > d->num_cu && !getenv("TWL_PROT_NO_SMALL")) {
+                if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
+                rc = launch_lean<22, 16, 1, 3, 1, false, true>(d, st, a, items, n_run, &grid, &window);
+            } else if (lean && n_run > d->num_cu && !getenv("TWL_PROT_NO_SMALL")) {
                 // more pairs than CUs: the 512-row window (8 waves, one block each; protein bands of 2 kaa pairs are ~270 rows wide, ~400
                 // at most) keeps the ring at 61 KB, so two workgroups share a CU like in the nucleotide throughput kernel; a pair
                 // whose band outgrows it goes to the 1024-row kernel below
-                rc = launch_lean<22, 8, 1, 3, 4>(d, st, a, items, n_pairs, &grid, &window);
+                rc = launch_lean<22, 8, 1, 3, 4>(d, st, a, items, n_run, &grid, &window);
                 protSmall = true;
             } else if (lean) {
-                rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, items, n_pairs, &grid, &window);
+                rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, items, n_run, &grid, &window);
             } else {
-                rc = launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, items, n_pairs, 0, &grid, &window);
+                rc = launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, items, n_run, 0, &grid, &window);
             }
         }
     }
@@ -383,47 +395,47 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         divOk = divOk && inRange(p->gap_char);
         const bool lean = (c != "w8r2") && divOk;
         // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
-        const bool few = (c == "nuc16") || (c == "nuc" && n_pairs <= d->num_cu && !getenv("TWL_NO_FEW"));
+        const bool few = (c == "nuc16") || (c == "nuc" && n_run <= d->num_cu && !getenv("TWL_NO_FEW"));
         // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
         int32_t maxLen = 0;
         for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLen = std::max(maxLen, h_len[t]);
         // (the mailbox words of the speculative start carry absolute positions in 16 bits each)
         // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
         const bool mm5 = lean && mm >= 1 && (qry_onehot || getenv("TWL_ASSUME_ONEHOT_QUERY") != nullptr) && !getenv("TWL_NO_ONEHOT");
-        const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_pairs <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
+        const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_run <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
         statMode = mm5 ? 5 : mm;
         statSpec = spec ? 1 : 0;
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
-            if (!lean || n_pairs != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
-            if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
-            else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_pairs, &grid, &window);
+            if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
+            if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_run, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_run, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_run, &grid, &window);
+            else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_run, &grid, &window);
         }
-        else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_pairs, &grid, &window);
-        else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_pairs, &grid, &window);
+        else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_run, &grid, &window);
+        else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_run, &grid, &window);
         else if (lean && few) {
-            if (mm5) rc = launch_lean<6, 16, 1, 5, 1>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_pairs, &grid, &window);
-            else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm5) rc = launch_lean<6, 16, 1, 5, 1>(d, st, a, items, n_run, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_run, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_run, &grid, &window);
+            else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_run, &grid, &window);
         } else if (lean) {
-            if (mm5) rc = launch_lean<6, 8, 2, 5, 4>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, n_pairs, &grid, &window);
-            else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, n_pairs, &grid, &window);
-            else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, n_pairs, &grid, &window);
+            if (mm5) rc = launch_lean<6, 8, 2, 5, 4>(d, st, a, items, n_run, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, n_run, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, n_run, &grid, &window);
+            else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, n_run, &grid, &window);
         }
-        else if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
-        else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_pairs, 0, &grid, &window);
+        else if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_run, 0, &grid, &window);
+        else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_run, 0, &grid, &window);
+        else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_run, 0, &grid, &window);
     }
-    else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w16m2") rc = launch_dp<6, 16, 1, false, true, true, 1, 2>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w16prem1") rc = launch_dp<6, 16, 1, true, true, true, 1, 1>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w8") rc = launch_dp<6, 8, 1, true, true>(d, st, a, items, n_pairs, 0, &grid, &window);
-    else if (c == "w4r4") rc = launch_dp<6, 4, 4, false, true>(d, st, a, items, n_pairs, 0, &grid, &window);
+    else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_run, 0, &grid, &window);
+    else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_run, 0, &grid, &window);
+    else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_run, 0, &grid, &window);
+    else if (c == "w16m2") rc = launch_dp<6, 16, 1, false, true, true, 1, 2>(d, st, a, items, n_run, 0, &grid, &window);
+    else if (c == "w16prem1") rc = launch_dp<6, 16, 1, true, true, true, 1, 1>(d, st, a, items, n_run, 0, &grid, &window);
+    else if (c == "w8") rc = launch_dp<6, 8, 1, true, true>(d, st, a, items, n_run, 0, &grid, &window);
+    else if (c == "w4r4") rc = launch_dp<6, 4, 4, false, true>(d, st, a, items, n_run, 0, &grid, &window);
     else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(d->ev[2], st));
