@@ -1,4 +1,9 @@
 // twilight_amd/csrc/host/capi.cpp -- C ABI of libtwl_host (include/twl_msa.h): the DEFAULT_ALN flow of driver.cpp in steps.
+#include <omp.h>
+#include <sched.h>
+#include <thread>
+#include <algorithm>
+#include <cstdlib>
 #include "../../../include/twl_msa.h"
 
 #include "twl_host.hpp"
@@ -53,6 +58,20 @@ int twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange,
 {
     if (!m || world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) { g_msaErr = "bad argument"; return -2; }
     if (m->aligned) { g_msaErr = "already aligned"; return -2; }
+    // Several ranks share the host: launchers export OMP_NUM_THREADS=1 for multi-process jobs (torch.distributed.run does), which would
+    // leave the host part of every level (gappy columns back, path blocks) on one core.  Each rank takes its share of the cores this
+    // process may run on instead; TWL_OMP_THREADS overrides.
+    if (world > 1) {
+        int threads = 0;
+        if (const char *v = getenv("TWL_OMP_THREADS")) threads = atoi(v);
+        if (threads <= 0) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            const int cores = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+            threads = std::max(1, cores / world);
+        }
+        omp_set_num_threads(threads);
+    }
     msa::progressive::gpu::Shard sh;
     sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user;
     msa::progressive::gpu::setShard(m->db, sh);
