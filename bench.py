@@ -208,11 +208,15 @@ def variant_of(pairs, num_cu, P, mode=-1, spec=-1):
     if P == 22:
         if pairs <= max(1, num_cu // 2):
             return "talco_lean_kernel<22, 16, 1, 4, 1, true, false> (precomputed column scores, speculative tile start)"
+        if spec == 2:
+            return "talco_lean_kernel<22, 8, 1, 4, 4, true, false> (precomputed column scores, speculative tile start, 512-row window, two workgroups per CU)"
         if pairs <= num_cu:
             return "talco_lean_kernel<22, 16, 1, 3, 1, false, false> (sparse column scores)"
         return "talco_lean_kernel<22, 8, 1, 3, 4, false, false> (sparse column scores, 512-row window, two workgroups per CU)"
     mm = mode if mode in (0, 1, 2, 5) else 2
     note = " (one-letter query rows)" if mm == 5 else ""
+    if spec == 2:
+        return "talco_lean_kernel<6, 8, 2, 2, 4, true, false> (speculative tile start, two workgroups per CU)"
     is_spec = (2 * pairs <= num_cu) if spec < 0 else bool(spec)
     if is_spec:
         return f"talco_lean_kernel<6, 16, 1, {mm}, 1, true, false> (speculative tile start)" + note

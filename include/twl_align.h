@@ -60,7 +60,7 @@ typedef struct twl_stats {
     int32_t  window;          /* rows of the fast-path window used */
     int32_t  grid;            /* persistent workgroups launched */
     int32_t  matrix_mode;     /* column-score mode of the first DP launch: nucleotide 0 / 1 / 2 / 5 (one-letter query rows), protein 3 / 4 */
-    int32_t  speculative;     /* 1: two workgroups per pair with speculative tile start */
+    int32_t  speculative;     /* two workgroups per pair with speculative tile start: 1 on a CU each (16 waves), 2 two to a CU (8 waves x 2 blocks); 0 none */
 } twl_stats;
 
 /* Select devices (HIP ordinals).  n_devices==0 or device_ids==NULL -> device 0 only.

@@ -32,7 +32,7 @@ typedef struct twl_msa_level {
     double   level_ms;      /* host wall time of the level-kernel call */
     double   exchange_ms;   /* of which: all-gather of the paths between processes */
     int32_t  matrix_mode;   /* column-score mode of the level's DP kernel (twl_stats.matrix_mode; -1 unknown) */
-    int32_t  speculative;   /* 1: the speculative two-workgroup kernel ran the level */
+    int32_t  speculative;   /* the speculative two-workgroup kernel ran the level: 1 a CU per workgroup, 2 two workgroups per CU (twl_stats.speculative) */
 } twl_msa_level;
 
 typedef struct twl_msa_totals {

@@ -341,7 +341,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             for (int l = 0; l < 21; ++l) for (int m = 0; m < 21; ++m) m24[24 * l + m] = a.M[21 * l + m];
             HIP_TRY(hipMemcpyAsync(d->m24.p, m24.data(), m24.size() * sizeof(float), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
-            const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few)) && fits && !d->dump_on;
+            // CUs/2 < pairs <= CUs: speculative teams of the 512-row geometry, two workgroups per CU, on precomputed scores (as the nucleotide
+            // path does with its throughput geometry)
+            const bool sharedSpec = lean && pcs == "auto" && !few && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on &&
+                                    !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED");
+            const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few) || sharedSpec) && fits && !d->dump_on;
             statMode = presim ? 4 : 3;
             if (presim) {
                 if ((rc = d->sim.ensure(simFloats * sizeof(float)))) return rc;
@@ -358,8 +362,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
-                statSpec = (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) ? 1 : 0;
-                if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
+                statSpec = sharedSpec ? 2 : ((lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) ? 1 : 0);
+                if (sharedSpec) { rc = launch_lean<22, 8, 1, 4, 4, true>(d, st, a, items, n_run, &grid, &window); protSmall = true; }
+                else if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_run, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_run, 0, &grid, &window);
             } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
@@ -411,6 +416,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_run, &grid, &window);
+        }
+        else if (lean && mm == 2 && n_run <= d->num_cu && 2 * n_run > d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED")) {
+            // CUs/2 < pairs <= CUs: still two workgroups per pair taking the tiles in turn, but of the throughput geometry, two to a CU
+            // (all 2n resident at once, as the teams wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one
+            // 16-wave workgroup per pair; below CUs/2 pairs the 16-wave teams on a CU each are a little faster (16.4 vs 16.9 ms)
+            rc = launch_lean<6, 8, 2, 2, 4, true>(d, st, a, items, n_run, &grid, &window);
+            statMode = 2; statSpec = 2;
         }
         else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_run, &grid, &window);
         else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_run, &grid, &window);
