@@ -162,10 +162,10 @@ def test_rows_grow_past_initial_capacity(gpu):
     rng = np.random.default_rng(5)
     N = 20
     seqs = [bytes(rng.choice(list(b"ACGT"), size=400).astype(np.uint8)) for _ in range(N)] + [b"ACGTAC"]
-    st = L.Store(seqs, "n")                      # initial pitch 16 x 400 + 256 = 6656 columns for 400-letter sequences
+    st = L.Store(seqs, "n")                      # initial pitch 8 x 400 + 256 = 3456 columns for 21 sequences of 400 letters
     p = twl.make_params(LC.matrix_of("n"))
     members, total = [0], 400
-    for nxt in range(1, N):                      # end-to-end concatenation: 800, 1200, ... 8000 columns (past the pitch from 6800 on)
+    for nxt in range(1, N):                      # end-to-end concatenation: 800, 1200, ... 8000 columns (past the pitch from 3600 on)
         k = len(members)
         st.prepare(p, [[L.Side(list(members), np.full(k, 1.0, dtype=F), total, k, float(k)), L.Side([nxt], np.asarray([1.0], dtype=F), 400, 1, 1.0)]],
                    gappy_threshold=1.0)

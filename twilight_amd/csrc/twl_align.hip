@@ -417,7 +417,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_run, &grid, &window);
         }
-        else if (lean && mm == 2 && n_run <= d->num_cu && 2 * n_run > d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED")) {
+        else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || getenv("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED")) {      // (TWL_SPEC_SHARED_ALL: development knob)
             // CUs/2 < pairs <= CUs: still two workgroups per pair taking the tiles in turn, but of the throughput geometry, two to a CU
             // (all 2n resident at once, as the teams wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one
             // 16-wave workgroup per pair; below CUs/2 pairs the 16-wave teams on a CU each are a little faster (16.4 vs 16.9 ms)

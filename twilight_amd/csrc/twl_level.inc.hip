@@ -68,7 +68,7 @@ void build_lut(char type, uint8_t *lut)
 // Room for the rows.  The final alignment is several times longer than the sequences (6.6x at 10 000 x 10 kbp, 22x on the synthetic
 // 100 000 x 1.6 kbp family), and re-pitching costs more than its copy: device memory the process has not touched before comes at tens of
 // ms per GB (tools/micro/alloc_cost.hip: a first 16 GB allocation 1.3 s, recycled ones < 1 ms), which a pass must not pay in its middle.
-// So the planes start at 16x the longest sequence and grow by half when they have to -- within a budget of a sixth of the device memory
+// So the planes start at 8x-48x the longest sequence (more for more sequences, see twl_store_create) and grow by half when they have to -- within a budget of a sixth of the device memory
 // for both planes (288 GB of HBM are there to be used), never below what is needed.
 int64_t rows_budget_cap(twl_store *s)
 {
@@ -137,7 +137,11 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
         maxLen = std::max<int64_t>(maxLen, lens[i]);
     }
     // room for the alignment to grow (see grow_rows); the sequences go up through a tight host image with its own pitch
-    if ((rc = grow_rows(s, maxLen + 1, 16 * maxLen + 256))) { twl_store_destroy(s); return rc; }
+    // (how much longer than its sequences an alignment gets grows with the number of sequences: 6.6x at 10 000, 22x at 100 000 on the
+    // synthetic families; 8 x log10(n) - 16, between 8x and 48x, within grow_rows' budget)
+    const double lg = std::log10((double)std::max<int32_t>(n_seqs, 10));
+    const int64_t factor = (int64_t)std::min(48.0, std::max(8.0, 8.0 * lg - 16.0));
+    if ((rc = grow_rows(s, maxLen + 1, factor * maxLen + 256))) { twl_store_destroy(s); return rc; }
     if (n_seqs > 0) {
         const size_t hp = (size_t)maxLen;
         std::unique_ptr<char[]> img(new char[(size_t)n_seqs * hp]);
