@@ -16,7 +16,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                        "-DTWL_KERNEL_STAMPS", "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
 api.LIB_PATH = so
 os.environ["TWL_DEBUG"] = "1"
-os.environ.setdefault("TWL_NO_SPEC", "1")
+if not os.environ.get("TWL_TIMELINE_SPEC"):      # TWL_TIMELINE_SPEC=1: the speculative kernel (tile 4 is one of workgroup 0's)
+    os.environ.setdefault("TWL_NO_SPEC", "1")
 b = synth.make_level_batch(1, length, members=((1, 8), (1, 8)), seed=5)
 api.init([0])
 api.align_batch(api.make_params(synth.nucleotide_matrix()), b)
