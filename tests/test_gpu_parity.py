@@ -401,3 +401,61 @@ def test_one_profile_entry_outside_the_fast_division_range(gpu, where):
     b2 = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=f, gap_open=batch.gap_open, gap_extend=batch.gap_extend, len=batch.len, num=batch.num)
     _compare(gpu, b2)
     assert gpu.get_stats(0).n_relaunched == len(pairs)
+
+
+def _replicated(batch, n):
+    idx = np.arange(n) % batch.n_pairs
+    return idx, synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq[idx], gap_open=batch.gap_open[idx], gap_extend=batch.gap_extend[idx],
+                                 len=batch.len[idx], num=batch.num[idx])
+
+
+@pytest.mark.parametrize("kind", ["nuc", "prot"])
+def test_mid_size_levels_take_speculative_teams_two_to_a_cu(gpu, kind):
+    """CUs/2 < pairs <= CUs: two workgroups per pair of the throughput geometry (nucleotide 8 waves x 2 blocks, protein 8 waves on the
+    512-row window with precomputed scores), all resident at once.  Several tiles per pair (marker 128); same paths, error codes and
+    band cells as the oracle."""
+    P = 22 if kind == "prot" else 6
+    mat = synth.protein_matrix() if kind == "prot" else M
+    base = synth.make_level_batch(24, 700 if kind == "nuc" else 420, P=P, members=((1, 5), (1, 5)), seed=71, length_jitter=0.2)
+    idx, big = _replicated(base, 170)
+    p = gpu.make_params(mat, marker=128)
+    aln, n, err = gpu.align_batch(p, big)
+    st = gpu.get_stats(0)
+    assert st.speculative == 2 and st.grid == 2 * 170, (st.speculative, st.grid)
+    oa, on, oerr, ost = O.align_batch(O.make_params(mat, marker=128), base, threads=8)
+    assert np.array_equal(n, on[idx]) and np.array_equal(err, oerr[idx])
+    for i in range(big.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}"
+    cells = gpu.get_pair_cells(big.n_pairs)
+    _, _, _, one = O.align_batch(O.make_params(mat, marker=128), synth.LevelBatch(P=base.P, seq_len=base.seq_len, freq=base.freq[:1], gap_open=base.gap_open[:1],
+                                                                                   gap_extend=base.gap_extend[:1], len=base.len[:1], num=base.num[:1]), threads=1)
+    assert int(cells[0]) == one.cells and int(cells[24]) == one.cells
+
+
+def test_protein_band_wider_than_the_512_row_window_moves_on(gpu):
+    """Protein levels with more pairs than CUs start on the 512-row window; with a large X-drop the band of 1.5 kaa pairs outgrows it and
+    those pairs must come back, bit-identical, from the 1024-row kernel."""
+    mat = synth.protein_matrix()
+    base = synth.make_level_batch(6, 1500, P=22, members=((1, 4), (1, 4)), seed=19, sub=0.3)
+    idx, big = _replicated(base, 300)
+    pk = dict(xdrop=30000)
+    p = gpu.make_params(mat, **pk)
+    aln, n, err = gpu.align_batch(p, big)
+    st = gpu.get_stats(0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(mat, **pk), base, threads=8)
+    assert ost.max_width > 520, ost.max_width
+    assert st.n_relaunched > 0
+    assert np.array_equal(n, on[idx]) and np.array_equal(err, oerr[idx])
+    for i in range(big.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}"
+
+
+def test_nothing_to_align(gpu):
+    """Every pair of the call masked out (empty sides): nothing is launched, every pair comes back with length 0 and errorType 0."""
+    b = synth.make_level_batch(5, 300, members=(1, 1), seed=3)
+    ln = b.len.copy()
+    ln[:, 1] = 0
+    b0 = synth.LevelBatch(P=b.P, seq_len=b.seq_len, freq=b.freq, gap_open=b.gap_open, gap_extend=b.gap_extend, len=ln, num=b.num)
+    aln, n, err = gpu.align_batch(gpu.make_params(M), b0)
+    assert np.all(n == 0) and np.all(err == 0)
+    assert gpu.get_stats(0).band_cells == 0
