@@ -343,7 +343,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
             // CUs/2 < pairs <= CUs: speculative teams of the 512-row geometry, two workgroups per CU, on precomputed scores (as the nucleotide
             // path does with its throughput geometry)
-            const bool sharedSpec = lean && pcs == "auto" && !few && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on &&
+            const bool sharedSpec = lean && pcs == "auto" && (!few || getenv("TWL_SPEC_SHARED_ALL")) && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on &&
                                     !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED");
             const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few) || sharedSpec) && fits && !d->dump_on;
             statMode = presim ? 4 : 3;
