@@ -414,6 +414,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
         finalLen[i] = (int32_t)full.size();
     }
+    const double tGappy = nowMs() - tFin;
     onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit_from_dp(g_stores[d], finalPaths, finalLen.data(), pathStride, inPlace ? fromDp.data() : nullptr); });
     for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
         if (finalLen[i] == 0) continue;
@@ -440,7 +441,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (option->printDetail)
         std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << g_totals.call_ms - before.call_ms
                   << " (kernel " << rec.kernel_ms << ", exchange " << rec.exchange_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
-                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << '\n';
+                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << "; gappy columns back " << tGappy << " ms\n";
 }
 
 }  // namespace gpu
