@@ -2,6 +2,7 @@
 // (/root/reference/src/alignment-helper.cpp, scoring-matrix.cpp, tree.cpp, progressive.cpp).  Prints "OK <name>" / "FAIL <name>".
 #include "../twilight_amd/csrc/host/twl_host.hpp"
 
+#include <random>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -136,6 +137,75 @@ int main(int argc, char **argv)
         int r = 0, q = 0;
         for (auto c : after) { r += (c != 1); q += (c != 2); }
         CHECK("add_gappy_columns_back_consumes_original_lengths", r == 6 && q == 5 && pathStr(after) == "10022012");
+    }
+    // ---- addGappyColumnsBack against the reference's one-step-at-a-time walk (alignment-helper.cpp:324-375) on random inputs ----
+    {
+        Params p(opt, 'n');
+        auto walk = [&](const alnPath &before, const std::pair<IntPairVec, IntPairVec> &g, const stringPair &org) {
+            alnPath after;
+            int rIdx = 0, qIdx = 0;
+            size_t gr = 0, gq = 0;
+            for (size_t a = 0; a < before.size() + 1; ++a) {
+                const bool gapR = gr < g.first.size() && rIdx == g.first[gr].first;
+                const bool gapQ = gq < g.second.size() && qIdx == g.second[gq].first;
+                if (gapR && gapQ) {
+                    alnPath sub;
+                    alignment_helper::pairwiseGlobal(org.first.substr(rIdx, g.first[gr].second), org.second.substr(qIdx, g.second[gq].second), sub, p);
+                    after.insert(after.end(), sub.begin(), sub.end());
+                    rIdx += g.first[gr].second; qIdx += g.second[gq].second; ++gr; ++gq;
+                } else {
+                    if (gapR) { after.insert(after.end(), g.first[gr].second, 2); rIdx += g.first[gr].second; ++gr; }
+                    if (gapQ) { after.insert(after.end(), g.second[gq].second, 1); qIdx += g.second[gq].second; ++gq; }
+                }
+                if (a < before.size()) { after.push_back(before[a]); if (before[a] != 1) ++rIdx; if (before[a] != 2) ++qIdx; }
+            }
+            return after;
+        };
+        std::mt19937 rng(12345);
+        bool ok = true;
+        int bothEvents = 0;
+        for (int t = 0; t < 400 && ok; ++t) {
+            // a reduced path, then random runs of removed columns placed into the original coordinates of either side
+            const int len = (t < 20) ? (int)(rng() % 6) : (int)(rng() % 300);
+            alnPath before(len);
+            for (auto &c : before) c = (int8_t)(rng() % 8 < 6 ? 0 : (rng() % 2 ? 1 : 2));
+            int nr = 0, nq = 0;
+            for (auto c : before) { nr += (c != 1); nq += (c != 2); }
+            auto runs = [&](int compactLen, bool sameAs, const IntPairVec *other, const std::vector<int> *otherCompact) {
+                IntPairVec out; std::vector<int> compact;
+                int inserted = 0;
+                for (int c = 0; c <= compactLen; ++c) {
+                    const bool force = sameAs && other && !otherCompact->empty() && rng() % 3 == 0;      // (both-sides events are made below, by position)
+                    (void)force;
+                    if (rng() % 9 == 0) { const int l = 1 + (int)(rng() % 5); out.push_back({c + inserted, l}); compact.push_back(c); inserted += l; }
+                }
+                return std::make_pair(out, compact);
+            };
+            auto R = runs(nr, false, nullptr, nullptr);
+            auto Q = runs(nq, false, nullptr, nullptr);
+            std::pair<IntPairVec, IntPairVec> g{R.first, Q.first};
+            int totR = nr, totQ = nq;
+            for (auto &x : g.first) totR += x.second;
+            for (auto &x : g.second) totQ += x.second;
+            stringPair org{std::string(totR + 8, 'A'), std::string(totQ + 8, 'A')};
+            static const char L[] = "ACGT";
+            for (auto &c : org.first) c = L[rng() % 4];
+            for (auto &c : org.second) c = L[rng() % 4];
+            const alnPath want = walk(before, g, org);
+            alnPath got;
+            alnPath b2 = before;
+            alignment_helper::addGappyColumnsBack(b2, got, g, p, {nr, nq}, org);
+            ok = ok && got == want;
+            // count the steps at which both sides had a run (the pairwiseGlobal branch)
+            { int rIdx = 0, qIdx = 0; size_t gr = 0, gq = 0;
+              for (size_t a = 0; a < before.size() + 1; ++a) {
+                  const bool gapR = gr < g.first.size() && rIdx == g.first[gr].first, gapQ = gq < g.second.size() && qIdx == g.second[gq].first;
+                  if (gapR && gapQ) ++bothEvents;
+                  if (gapR) { rIdx += g.first[gr].second; ++gr; }
+                  if (gapQ) { qIdx += g.second[gq].second; ++gq; }
+                  if (a < before.size()) { if (before[a] != 1) ++rIdx; if (before[a] != 2) ++qIdx; } } }
+        }
+        CHECK("add_gappy_columns_back_equals_the_walk_on_random_inputs", ok && bothEvents > 50);
     }
     // ---- pairwiseGlobal tie-breaks (alignment-helper.cpp:243-322) ----
     {
