@@ -184,11 +184,13 @@ void pairwiseGlobal(const std::string &seq1, const std::string &seq2, alnPath &p
     std::vector<int8_t> tb((m + 1) * W, 0);
     for (int i = 1; i <= m; ++i) { M[i * W] = 0; X[i * W] = M[i * W]; Y[i * W] = -1e9; tb[i * W] = 2; }
     for (int j = 1; j <= n; ++j) { M[j] = 0; Y[j] = M[j]; X[j] = -1e9; tb[j] = 1; }
+    std::vector<int> idx2(n);      // (letter indices once per letter, not once per cell)
+    for (int j = 0; j < n; ++j) idx2[j] = letterIdx(type, (char)toupper((unsigned char)seq2[j]));
     for (int i = 1; i <= m; ++i) {
         const int a = letterIdx(type, (char)toupper((unsigned char)seq1[i - 1]));
+        const float *row = param.scoringMatrix[a];
         for (int j = 1; j <= n; ++j) {
-            const int b = letterIdx(type, (char)toupper((unsigned char)seq2[j - 1]));
-            const float base = param.scoringMatrix[a][b];
+            const float base = row[idx2[j - 1]];
             const size_t c = i * W + j, up = (i - 1) * W + j, left = i * W + j - 1, diag = (i - 1) * W + j - 1;
             M[c] = base + std::max({M[diag], X[diag], Y[diag]});
             X[c] = std::max(M[up] + gap_open, X[up] + gap_extend);
