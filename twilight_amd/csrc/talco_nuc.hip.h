@@ -461,7 +461,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             (void)PARX;
             // Single-lane LDS side effects without touching EXEC: every lane issues the instruction, the lanes that have nothing
             // to say aim at their trash slot of the same struct.
-            const unsigned relTrashRed = O_TRASH + (unsigned)lane * 16u - O_RED;     // + O_RED (immediate) = this lane's trash slot
+            // (+ O_RED, the immediate of the reduction atomics, = a trash word of this lane; consecutive words: 64 lanes over 32 banks,
+            // where the 16-byte slots of the mailbox stores made every atomic an 8-way bank conflict)
+            const unsigned relTrashRed = O_TRASH + (unsigned)lane * 4u - O_RED;
             unsigned mbRel[RPL], exRel[RPL];
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
