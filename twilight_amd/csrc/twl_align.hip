@@ -519,6 +519,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 
 }  // namespace
 
+static void twl_level_pool_release(Device *d);      // twl_level.inc.hip: the level buffers the device lent to its stores
+
 extern "C" {
 
 const char *twl_last_error(void) { return g_err.c_str(); }
@@ -566,6 +568,7 @@ void twl_shutdown(void)
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
+        twl_level_pool_release(d);
         for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();

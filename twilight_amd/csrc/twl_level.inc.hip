@@ -16,6 +16,51 @@ struct CacheEntry {
 
 }  // namespace
 
+// The device buffers of one prepared level (raw and packed columns are GBs at the leaf level).  They belong to the DEVICE, not to the
+// store: a store takes a set at twl_level_prepare and gives it back at twl_level_commit, so the runs of a process that align one after
+// the other work in the same, already mapped memory (device memory a process has not touched before costs tens of ms per GB:
+// tools/micro/alloc_cost.hip), and a run holds only its rows while it waits.  Stores that are between prepare and commit at the same
+// time (device replicas of a test) get a set each.
+struct LevelBufs {
+    Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
+    Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew;
+    bool busy = false;
+    void release_all()
+    {
+        for (Buf *b : {&d_sides, &d_mseq, &d_mw, &d_mplane, &d_tab, &d_raw, &d_colinfo, &d_cols, &d_len, &d_lenmask, &d_num, &d_aln, &d_alnlen, &d_err,
+                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew})
+            b->release();
+    }
+};
+
+namespace {
+std::vector<LevelBufs *> &level_pool(Device *d)
+{
+    static std::mutex mu;
+    static std::unordered_map<Device *, std::vector<LevelBufs *>> pools;
+    std::lock_guard<std::mutex> lk(mu);
+    return pools[d];
+}
+// (callers hold d->mu)
+LevelBufs *acquire_level(Device *d)
+{
+    auto &pool = level_pool(d);
+    for (LevelBufs *b : pool) if (!b->busy) { b->busy = true; return b; }
+    auto *b = new LevelBufs();
+    b->busy = true;
+    pool.push_back(b);
+    return b;
+}
+void release_level(LevelBufs *&lv) { if (lv) { lv->busy = false; lv = nullptr; } }
+}  // namespace
+
+static void twl_level_pool_release(Device *d)
+{
+    auto &pool = level_pool(d);
+    for (LevelBufs *b : pool) { b->release_all(); delete b; }
+    pool.clear();
+}
+
 struct twl_store {
     Device *d = nullptr;
     int P = 6;
@@ -33,8 +78,8 @@ struct twl_store {
     std::vector<twl_side> sides;
     std::vector<int32_t> members;
     std::vector<int32_t> h_len, h_num;
-    Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
-    Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew, d_gather, d_off, d_plane, d_rowlen;
+    LevelBufs *lv = nullptr;     // the level's device buffers, held from prepare to commit (from the device's pool, see LevelBufs)
+    Buf d_gather, d_off, d_plane, d_rowlen;
     double prepare_ms = 0, commit_ms = 0;
 };
 
@@ -161,9 +206,8 @@ void twl_store_destroy(twl_store *s)
     if (!s) return;
     (void)hipSetDevice(s->d->id);
     for (auto &kv : s->cache) { kv.second->buf.release(); delete kv.second; }
-    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_sides, &s->d_mseq, &s->d_mw, &s->d_mplane, &s->d_tab, &s->d_raw, &s->d_colinfo, &s->d_cols,
-                   &s->d_len, &s->d_lenmask, &s->d_num, &s->d_aln, &s->d_alnlen, &s->d_err, &s->d_paths, &s->d_pathlen, &s->d_chunk, &s->d_work,
-                   &s->d_merge, &s->d_mergew, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
+    release_level(s->lv);
+    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
         b->release();
     delete s;
 }
@@ -256,6 +300,7 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     HIP_TRY(hipSetDevice(d->id));
     hipStream_t st = d->stream;
     const size_t ns = (size_t)n_pairs * 2, P = (size_t)s->P, sl = (size_t)seq_len;
+    if (!s->lv) s->lv = acquire_level(d);      // held until the commit (or the store's end)
 
     s->sides.assign(sides, sides + ns);
     size_t nm = 0;
@@ -304,30 +349,30 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     for (size_t i = 0; i < ns; ++i) s->h_num[i] = sides[i].num;
 
     HIP_TRY(hipEventRecord(d->ev[0], st));
-    if ((rc = upload(s->d_sides, dsides, st))) return rc;
-    if ((rc = upload(s->d_mseq, s->members, st))) return rc;
-    { std::vector<float> w(member_weight, member_weight + nm); if ((rc = upload(s->d_mw, w, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
-    if ((rc = upload(s->d_mplane, mplane, st))) return rc;
-    if ((rc = upload(s->d_tab, tab, st))) return rc;
-    if ((rc = upload(s->d_num, s->h_num, st))) return rc;
-    if ((rc = s->d_raw.ensure(ns * sl * P * sizeof(float)))) return rc;
-    if ((rc = s->d_colinfo.ensure(ns * sl))) return rc;
-    if ((rc = s->d_cols.ensure(ns * sl * (P + 2) * sizeof(float)))) return rc;
-    if ((rc = s->d_len.ensure(ns * sizeof(int32_t)))) return rc;
+    if ((rc = upload(s->lv->d_sides, dsides, st))) return rc;
+    if ((rc = upload(s->lv->d_mseq, s->members, st))) return rc;
+    { std::vector<float> w(member_weight, member_weight + nm); if ((rc = upload(s->lv->d_mw, w, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    if ((rc = upload(s->lv->d_mplane, mplane, st))) return rc;
+    if ((rc = upload(s->lv->d_tab, tab, st))) return rc;
+    if ((rc = upload(s->lv->d_num, s->h_num, st))) return rc;
+    if ((rc = s->lv->d_raw.ensure(ns * sl * P * sizeof(float)))) return rc;
+    if ((rc = s->lv->d_colinfo.ensure(ns * sl))) return rc;
+    if ((rc = s->lv->d_cols.ensure(ns * sl * (P + 2) * sizeof(float)))) return rc;
+    if ((rc = s->lv->d_len.ensure(ns * sizeof(int32_t)))) return rc;
 
     twl::LevelArgs a{};
-    a.sides = (const twl::SideDesc *)s->d_sides.p;
-    a.member_seq = (const int32_t *)s->d_mseq.p;
-    a.member_w = (const float *)s->d_mw.p;
-    a.member_plane = (const uint8_t *)s->d_mplane.p;
+    a.sides = (const twl::SideDesc *)s->lv->d_sides.p;
+    a.member_seq = (const int32_t *)s->lv->d_mseq.p;
+    a.member_w = (const float *)s->lv->d_mw.p;
+    a.member_plane = (const uint8_t *)s->lv->d_mplane.p;
     a.rows0 = (const char *)s->rows[0].p; a.rows1 = (const char *)s->rows[1].p;
     a.cap = s->cap;
-    a.cache = (float *const *)s->d_tab.p;
+    a.cache = (float *const *)s->lv->d_tab.p;
     a.lut = (const uint8_t *)s->lut.p;
-    a.raw = (float *)s->d_raw.p;
-    a.colinfo = (uint8_t *)s->d_colinfo.p;
-    a.cols = (float *)s->d_cols.p;
-    a.len_out = (int32_t *)s->d_len.p;
+    a.raw = (float *)s->lv->d_raw.p;
+    a.colinfo = (uint8_t *)s->lv->d_colinfo.p;
+    a.cols = (float *)s->lv->d_cols.p;
+    a.len_out = (int32_t *)s->lv->d_len.p;
     a.stride = seq_len;
     a.gappy_thr = gappy_threshold;
     a.remove = (gappy_threshold == 1.0) ? 0 : 1;                         // alignment-helper.cpp:77
@@ -348,8 +393,8 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(d->ev[1], st));
     s->h_len.resize(ns);
-    HIP_TRY(hipMemcpyAsync(s->h_len.data(), s->d_len.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (colinfo_out) HIP_TRY(hipMemcpyAsync(colinfo_out, s->d_colinfo.p, ns * sl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s->h_len.data(), s->lv->d_len.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (colinfo_out) HIP_TRY(hipMemcpyAsync(colinfo_out, s->lv->d_colinfo.p, ns * sl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
@@ -366,12 +411,12 @@ int twl_level_read_colinfo(twl_store *s, int32_t pair, int32_t side, uint8_t *ou
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
     if (pair < 0) {      // the whole level: [n_pairs][2][seq_len]
-        HIP_TRY(hipMemcpy(out, s->d_colinfo.p, (size_t)s->n_pairs * 2 * (size_t)s->seq_len, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, s->lv->d_colinfo.p, (size_t)s->n_pairs * 2 * (size_t)s->seq_len, hipMemcpyDeviceToHost));
         return TWL_OK;
     }
     const size_t idx = (size_t)pair * 2 + (size_t)side;
     const size_t len = (size_t)std::max(0, s->sides[idx].len);
-    if (len) HIP_TRY(hipMemcpy(out, (const uint8_t *)s->d_colinfo.p + idx * (size_t)s->seq_len, len, hipMemcpyDeviceToHost));
+    if (len) HIP_TRY(hipMemcpy(out, (const uint8_t *)s->lv->d_colinfo.p + idx * (size_t)s->seq_len, len, hipMemcpyDeviceToHost));
     return TWL_OK;
 }
 
@@ -392,30 +437,30 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     std::vector<int32_t> lm(s->h_len);
     if (run_mask)
         for (int32_t i = 0; i < n; ++i) if (!run_mask[i]) lm[2 * i] = lm[2 * i + 1] = 0;
-    if ((rc = upload(s->d_lenmask, lm, st))) return rc;
-    if ((rc = s->d_aln.ensure((size_t)n * 2 * sl))) return rc;
-    if ((rc = s->d_alnlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
-    if ((rc = s->d_err.ensure((size_t)n * sizeof(int16_t)))) return rc;
+    if ((rc = upload(s->lv->d_lenmask, lm, st))) return rc;
+    if ((rc = s->lv->d_aln.ensure((size_t)n * 2 * sl))) return rc;
+    if ((rc = s->lv->d_alnlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = s->lv->d_err.ensure((size_t)n * sizeof(int16_t)))) return rc;
     HIP_TRY(hipEventRecord(d->ev[5], st));
     // every selected query side a single, uncached sequence: its profile rows hold one letter each (profile_kernel built them)
     bool qryOneHot = true;
     for (int32_t i = 0; i < n && qryOneHot; ++i)
         if (lm[2 * i] > 0 && lm[2 * i + 1] > 0) qryOneHot = s->sides[2 * (size_t)i + 1].n_members == 1 && s->sides[2 * (size_t)i + 1].cache_id < 0;
-    rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->d_lenmask.p, (const int32_t *)s->d_num.p, (int8_t *)s->d_aln.p,
-                    (int32_t *)s->d_alnlen.p, (int16_t *)s->d_err.p, lm.data(), (const float *)s->d_cols.p, qryOneHot);
+    rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->lv->d_lenmask.p, (const int32_t *)s->lv->d_num.p, (int8_t *)s->lv->d_aln.p,
+                    (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(aln_len_out, s->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(err_out, s->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(aln_len_out, s->lv->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(err_out, s->lv->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     // paths: bulk when most pairs ran, else one copy per pair that has a path
     int32_t ran = 0;
     for (int32_t i = 0; i < n; ++i) ran += aln_len_out[i] > 0;
     if (!aln_out) {}                            // the paths stay in HBM (twl_level_read_path / twl_level_commit_from_dp)
-    else if (ran * 2 >= n) HIP_TRY(hipMemcpyAsync(aln_out, s->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
+    else if (ran * 2 >= n) HIP_TRY(hipMemcpyAsync(aln_out, s->lv->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
     else
         for (int32_t i = 0; i < n; ++i)
             if (aln_len_out[i] > 0)
-                HIP_TRY(hipMemcpyAsync(aln_out + (size_t)i * 2 * sl, (int8_t *)s->d_aln.p + (size_t)i * 2 * sl, (size_t)aln_len_out[i], hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(aln_out + (size_t)i * 2 * sl, (int8_t *)s->lv->d_aln.p + (size_t)i * 2 * sl, (size_t)aln_len_out[i], hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(d->ev[3], st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
@@ -426,24 +471,24 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
 
 int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len)
 {
-    if (!s || !s->prepared || !out || pair < 0 || pair >= s->n_pairs || len < 0 || len > 2 * s->seq_len || !s->d_aln.p) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (!s || !s->prepared || !out || pair < 0 || pair >= s->n_pairs || len < 0 || len > 2 * s->seq_len || !s->lv || !s->lv->d_aln.p) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     Device *d = s->d;
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
-    if (len) HIP_TRY(hipMemcpy(out, (const int8_t *)s->d_aln.p + (size_t)pair * 2 * (size_t)s->seq_len, (size_t)len, hipMemcpyDeviceToHost));
+    if (len) HIP_TRY(hipMemcpy(out, (const int8_t *)s->lv->d_aln.p + (size_t)pair * 2 * (size_t)s->seq_len, (size_t)len, hipMemcpyDeviceToHost));
     return TWL_OK;
 }
 
 int twl_level_read_colinfo_many(twl_store *s, int32_t n_sel, const int32_t *pairs, uint8_t *out)
 {
-    if (!s || !s->prepared || n_sel < 0 || (n_sel > 0 && (!pairs || !out))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (!s || !s->prepared || n_sel < 0 || (n_sel > 0 && (!pairs || !out || !s->lv))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     Device *d = s->d;
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
     const size_t sl = (size_t)s->seq_len;
     for (int32_t t = 0; t < n_sel; ++t) {
         if (pairs[t] < 0 || pairs[t] >= s->n_pairs) { g_err = "pair index out of range"; return TWL_ERR_BAD_ARGUMENT; }
-        HIP_TRY(hipMemcpyAsync(out + (size_t)t * 2 * sl, (const uint8_t *)s->d_colinfo.p + (size_t)pairs[t] * 2 * sl, 2 * sl, hipMemcpyDeviceToHost, d->stream));
+        HIP_TRY(hipMemcpyAsync(out + (size_t)t * 2 * sl, (const uint8_t *)s->lv->d_colinfo.p + (size_t)pairs[t] * 2 * sl, 2 * sl, hipMemcpyDeviceToHost, d->stream));
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return TWL_OK;
@@ -451,14 +496,14 @@ int twl_level_read_colinfo_many(twl_store *s, int32_t n_sel, const int32_t *pair
 
 int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, int8_t *out, int32_t out_stride)
 {
-    if (!s || !s->prepared || n_sel < 0 || (n_sel > 0 && (!pairs || !lens || !out || !s->d_aln.p)) || out_stride < 0) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (!s || !s->prepared || n_sel < 0 || (n_sel > 0 && (!pairs || !lens || !out || !s->lv || !s->lv->d_aln.p)) || out_stride < 0) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     Device *d = s->d;
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
     const size_t sl = (size_t)s->seq_len;
     for (int32_t t = 0; t < n_sel; ++t) {
         if (pairs[t] < 0 || pairs[t] >= s->n_pairs || lens[t] < 0 || lens[t] > out_stride || (size_t)lens[t] > 2 * sl) { g_err = "bad selection"; return TWL_ERR_BAD_ARGUMENT; }
-        if (lens[t]) HIP_TRY(hipMemcpyAsync(out + (size_t)t * (size_t)out_stride, (const int8_t *)s->d_aln.p + (size_t)pairs[t] * 2 * sl, (size_t)lens[t], hipMemcpyDeviceToHost, d->stream));
+        if (lens[t]) HIP_TRY(hipMemcpyAsync(out + (size_t)t * (size_t)out_stride, (const int8_t *)s->lv->d_aln.p + (size_t)pairs[t] * 2 * sl, (size_t)lens[t], hipMemcpyDeviceToHost, d->stream));
     }
     HIP_TRY(hipStreamSynchronize(d->stream));
     return TWL_OK;
@@ -478,12 +523,13 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if ((!paths && !from_dp) || !path_len || path_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     if (from_dp) {
         for (int32_t i = 0; i < n; ++i) {
-            if (from_dp[i] && (!s->d_aln.p || path_len[i] > 2 * s->seq_len)) { g_err = "from_dp without a DP output of this level"; return TWL_ERR_BAD_ARGUMENT; }
+            if (from_dp[i] && (!s->lv || !s->lv->d_aln.p || path_len[i] > 2 * s->seq_len)) { g_err = "from_dp without a DP output of this level"; return TWL_ERR_BAD_ARGUMENT; }
             if (!from_dp[i] && path_len[i] > 0 && !paths) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
         }
     }
     Device *d = s->d;
     std::lock_guard<std::mutex> lk(d->mu);
+    struct GiveBack { twl_store *s; ~GiveBack() { release_level(s->lv); } } giveBack{s};      // the level's buffers return to the device's pool
     HIP_TRY(hipSetDevice(d->id));
     hipStream_t st = d->stream;
     const size_t P = (size_t)s->P;
@@ -529,39 +575,39 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     for (size_t k = 0; k < s->members.size(); ++k) mplane[k] = s->plane[s->members[k]];
 
     HIP_TRY(hipEventRecord(d->ev[0], st));
-    if ((rc = s->d_paths.ensure((size_t)n * (size_t)path_stride))) return rc;
-    if (!from_dp) HIP_TRY(hipMemcpyAsync(s->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
+    if ((rc = s->lv->d_paths.ensure((size_t)n * (size_t)path_stride))) return rc;
+    if (!from_dp) HIP_TRY(hipMemcpyAsync(s->lv->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
     else {
         // the DP output of this level, row by row, inside HBM; then the (few) rows the caller brought
         const size_t width = std::min((size_t)path_stride, 2 * (size_t)s->seq_len);
-        HIP_TRY(hipMemcpy2DAsync(s->d_paths.p, (size_t)path_stride, s->d_aln.p, 2 * (size_t)s->seq_len, width, (size_t)n, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(s->lv->d_paths.p, (size_t)path_stride, s->lv->d_aln.p, 2 * (size_t)s->seq_len, width, (size_t)n, hipMemcpyDeviceToDevice, st));
         for (int32_t i = 0; i < n; ++i)
             if (!from_dp[i] && path_len[i] > 0)
-                HIP_TRY(hipMemcpyAsync((int8_t *)s->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
     }
-    { std::vector<int32_t> pl(path_len, path_len + n); if ((rc = upload(s->d_pathlen, pl, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
-    if ((rc = s->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
-    if ((rc = upload(s->d_work, work, st))) return rc;
-    if ((rc = upload(s->d_merge, merge, st))) return rc;
-    if ((rc = upload(s->d_mergew, mergew, st))) return rc;
-    if ((rc = upload(s->d_tab, tab, st))) return rc;
-    if ((rc = upload(s->d_mplane, mplane, st))) return rc;
+    { std::vector<int32_t> pl(path_len, path_len + n); if ((rc = upload(s->lv->d_pathlen, pl, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    if ((rc = s->lv->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = upload(s->lv->d_work, work, st))) return rc;
+    if ((rc = upload(s->lv->d_merge, merge, st))) return rc;
+    if ((rc = upload(s->lv->d_mergew, mergew, st))) return rc;
+    if ((rc = upload(s->lv->d_tab, tab, st))) return rc;
+    if ((rc = upload(s->lv->d_mplane, mplane, st))) return rc;
 
     twl::CommitArgs a{};
-    a.paths = (const int8_t *)s->d_paths.p;
-    a.path_len = (const int32_t *)s->d_pathlen.p;
+    a.paths = (const int8_t *)s->lv->d_paths.p;
+    a.path_len = (const int32_t *)s->lv->d_pathlen.p;
     a.path_stride = path_stride;
-    a.chunk_base = (int32_t *)s->d_chunk.p;
+    a.chunk_base = (int32_t *)s->lv->d_chunk.p;
     a.n_chunks = nChunks;
-    a.sides = (const twl::SideDesc *)s->d_sides.p;
-    a.member_seq = (const int32_t *)s->d_mseq.p;
-    a.member_plane = (const uint8_t *)s->d_mplane.p;
+    a.sides = (const twl::SideDesc *)s->lv->d_sides.p;
+    a.member_seq = (const int32_t *)s->lv->d_mseq.p;
+    a.member_plane = (const uint8_t *)s->lv->d_mplane.p;
     a.rows0 = (char *)s->rows[0].p; a.rows1 = (char *)s->rows[1].p;
     a.cap = s->cap;
-    a.work = (const int32_t *)s->d_work.p;
-    a.cache = (float *const *)s->d_tab.p;
-    a.merge = (const int32_t *)s->d_merge.p;
-    a.merge_w = (const float *)s->d_mergew.p;
+    a.work = (const int32_t *)s->lv->d_work.p;
+    a.cache = (float *const *)s->lv->d_tab.p;
+    a.merge = (const int32_t *)s->lv->d_merge.p;
+    a.merge_w = (const float *)s->lv->d_mergew.p;
     hipLaunchKernelGGL(twl::path_scan_kernel, dim3((unsigned)n), dim3(256), 0, st, a);
     const unsigned nWork = (unsigned)(work.size() / 3), nMerge = (unsigned)(merge.size() / 4);
     if (nWork) hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)nChunks), dim3(256), 0, st, a);
@@ -606,7 +652,7 @@ int twl_level_read_columns(twl_store *s, int32_t pair, int32_t side, float *out,
     std::lock_guard<std::mutex> lk(s->d->mu);
     HIP_TRY(hipSetDevice(s->d->id));
     if (n > 0)
-        HIP_TRY(hipMemcpy(out, (const float *)s->d_cols.p + ((size_t)pair * 2 + side) * (size_t)s->seq_len * CW, (size_t)n * CW * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, (const float *)s->lv->d_cols.p + ((size_t)pair * 2 + side) * (size_t)s->seq_len * CW, (size_t)n * CW * sizeof(float), hipMemcpyDeviceToHost));
     return TWL_OK;
 }
 
