@@ -78,7 +78,8 @@ def test_sharded_run_of_world_size_one_uses_the_rccl_all_gather(built, tmp_path)
         m.upload().align().write()
         tot, levels = m.report()
         m.close()
-        assert len(calls) == tot.n_levels and all(c > 32 for c in calls)      # one all-gather per level, header + path rows
+        # two all-gathers per level: the 8-byte block sizes, then the blocks (header + path rows)
+        assert len(calls) == 2 * tot.n_levels and all(c == 8 for c in calls[0::2]) and all(c > 32 for c in calls[1::2])
     finally:
         dist.destroy_process_group()
     ref = os.path.join(tmp, "ref.aln")

@@ -74,8 +74,10 @@ std::vector<int> dealPairs(const std::vector<long long> &cost, const std::vector
 }
 
 // Block layout per rank: header {band cells u64, relaunched u64, kernel ms f64, reserved} then, for the rank's pairs in ascending
-// order, {path length i32, errorType i32, path bytes padded to pathCap}.  Every rank knows every rank's pair list (the deal is
-// deterministic), so only the blocks travel.
+// order, {path length i32, errorType i32, path bytes padded to 8}: rows as long as their paths.  Every rank knows every rank's pair
+// list (the deal is deterministic), so only the blocks travel -- after an 8-byte all-gather of the block sizes, because the
+// collective wants equal blocks and the paths are about half as long as the bound 2 * seq_len the rows used to be padded to.
+// The blocks live in grow-only staging that is never zero-filled (page-locked when the library can give it).
 void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector<char> &takesPart, int pathCap, std::vector<alnPath> &paths,
                    std::vector<int16_t> &errs, LevelRecord &rec)
 {
@@ -84,29 +86,40 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
         if (sh.world > 1) { std::cerr << "ERROR: sharded run without an exchange function.\n"; exit(1); }
         return;
     }
+    static RunCtx::Raw sendStage, recvStage;      // (one run aligns at a time per process)
     const double t0 = nowMs();
     const int n = (int)owner.size();
     std::vector<std::vector<int>> mine(sh.world);
     for (int i = 0; i < n; ++i) if (takesPart[i]) mine[owner[i]].push_back(i);
-    size_t maxOwn = 0;
-    for (auto &v : mine) maxOwn = std::max(maxOwn, v.size());
-    const size_t rowBytes = 8 + (size_t)((pathCap + 7) & ~7), head = 32;
-    const size_t blockBytes = head + maxOwn * rowBytes;
-    std::vector<char> send(blockBytes, 0), recv(blockBytes * (size_t)sh.world, 0);
+    const size_t head = 32;
+    auto rowBytes = [](size_t len) { return 8 + ((len + 7) & ~(size_t)7); };
+    size_t myBytes = head;
+    for (int i : mine[sh.rank]) {
+        if ((int)paths[i].size() > pathCap) { std::cerr << "ERROR: path longer than the exchange row.\n"; exit(1); }
+        myBytes += rowBytes(paths[i].size());
+    }
+    // block sizes first (8 bytes per rank)
+    std::vector<int64_t> sizes((size_t)sh.world, 0);
+    {
+        const int64_t mineSz = (int64_t)myBytes;
+        const int rc0 = sh.exchange(sh.user, &mineSz, (int64_t)sizeof(int64_t), sizes.data());
+        if (rc0 != 0) { std::cerr << "ERROR: exchange of the block sizes failed (" << rc0 << ").\n"; exit(1); }
+    }
+    const size_t blockBytes = (size_t)*std::max_element(sizes.begin(), sizes.end());
+    char *send = sendStage.get(blockBytes), *recv = recvStage.get(blockBytes * (size_t)sh.world);
     {
         uint64_t h[4] = {rec.band_cells, rec.relaunched, 0, 0};
         memcpy(&h[2], &rec.kernel_ms, sizeof(double));
-        memcpy(send.data(), h, sizeof h);
+        memcpy(send, h, sizeof h);
         size_t at = head;
         for (int i : mine[sh.rank]) {
             const int32_t len = (int32_t)paths[i].size(), e = errs[i];
-            if (len > pathCap) { std::cerr << "ERROR: path longer than the exchange row.\n"; exit(1); }
             memcpy(&send[at], &len, 4); memcpy(&send[at + 4], &e, 4);
             if (len) memcpy(&send[at + 8], paths[i].data(), (size_t)len);
-            at += rowBytes;
+            at += rowBytes((size_t)len);
         }
     }
-    const int rc = sh.exchange(sh.user, send.data(), (int64_t)blockBytes, recv.data());
+    const int rc = sh.exchange(sh.user, send, (int64_t)blockBytes, recv);
     if (rc != 0) { std::cerr << "ERROR: exchange of the level's paths failed (" << rc << ").\n"; exit(1); }
     rec.band_cells = 0; rec.relaunched = 0;
     double kmax = 0;
@@ -118,8 +131,9 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
         size_t at = head;
         for (int i : mine[r]) {
             int32_t len, e; memcpy(&len, blk + at, 4); memcpy(&e, blk + at + 4, 4);
+            if (len < 0 || at + rowBytes((size_t)len) > (size_t)sizes[r]) { std::cerr << "ERROR: malformed path block from rank " << r << ".\n"; exit(1); }
             if (r != sh.rank) { errs[i] = (int16_t)e; paths[i].assign(blk + at + 8, blk + at + 8 + len); }
-            at += rowBytes;
+            at += rowBytes((size_t)len);
         }
     }
     rec.kernel_ms = kmax;
