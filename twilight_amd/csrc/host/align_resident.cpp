@@ -175,6 +175,14 @@ void uploadSequences(SequenceDB *database, Option *option)
     ensureInit(option);
     const double t0 = nowMs();
     createStore(ctx, database, option);
+    // the rows live in HBM from here on; the host copies (two buffers per sequence) come back as one arena when something on the host
+    // needs them (materialise): a resident run that waits for its turn holds names and lengths only
+    for (auto *s : database->sequences) {
+        if (!s->borrowed) { free(s->alnStorage[0]); free(s->alnStorage[1]); }
+        s->alnStorage[0] = s->alnStorage[1] = nullptr;
+        s->borrowed = true;
+        s->memLen = 0;
+    }
     if (option->printDetail) std::cerr << "Sequences resident on " << g_stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
     database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
 }
