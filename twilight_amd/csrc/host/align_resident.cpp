@@ -410,6 +410,12 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         if (deferred[i]) { paths[i].clear(); fromDp[i] = 0; }
         if (fromDp[i]) { finalLen[i] = dpLen[i]; continue; }      // no column was removed: the DP path is the final path, and it is in HBM
         if (paths[i].empty()) continue;
+        if (s.gappy.first.empty() && s.gappy.second.empty()) {      // nothing was removed: the DP path is the final path (addGappyColumnsBack would copy it)
+            if ((int)paths[i].size() > pathStride) { std::cerr << "ERROR: path longer than both profiles together.\n"; exit(1); }
+            std::copy(paths[i].begin(), paths[i].end(), &finalPaths[(size_t)i * pathStride]);
+            finalLen[i] = (int32_t)paths[i].size();
+            continue;
+        }
         alnPath full;
         int alnRef = 0, alnQry = 0;
         for (auto a : paths[i]) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
