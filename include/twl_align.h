@@ -60,7 +60,12 @@ typedef struct twl_stats {
     int32_t  window;          /* rows of the fast-path window used */
     int32_t  grid;            /* persistent workgroups launched */
     int32_t  matrix_mode;     /* column-score mode of the first DP launch: nucleotide 0 / 1 / 2 / 5 (one-letter query rows), protein 3 / 4 */
-    int32_t  speculative;     /* two workgroups per pair with speculative tile start: 1 on a CU each (16 waves), 2 two to a CU (8 waves x 2 blocks); 0 none */
+    int32_t  speculative;     /* two workgroups per pair with speculative tile start: 1 on a CU each (16 waves), 2 two to a CU (8 waves x 2 blocks);
+                                 3 tile-parallel (all tiles of all pairs side by side from predicted starts); 0 none */
+    int32_t  mt_tiles_predicted;   /* tile-parallel launches: tiles whose predicted start was the true one (taken from the parallel launch) */
+    int32_t  mt_tiles_inline;      /* ... tiles computed in line by the stitch launch (prediction missing or wrong) */
+    int32_t  mt_scouts_failed;     /* ... scouts that produced no path sample */
+    int32_t  reserved;
 } twl_stats;
 
 /* Select devices (HIP ordinals).  n_devices==0 or device_ids==NULL -> device 0 only.
@@ -124,6 +129,16 @@ int twl_column_scores(const twl_params *p, int32_t seq_len, const float *freq, c
    the band never visited hold NaN.  Arrays as one pair of twl_align_batch. */
 int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const float *gap_open, const float *gap_extend,
                          const int32_t *len, const int32_t *num, float *out);
+
+/* Development / test knobs of the launch policy (process-wide; not needed in production).  Returns TWL_ERR_BAD_ARGUMENT for an unknown key.
+     TWL_KNOB_MT_PERTURB     n > 0: spoil every n-th predicted tile start of the tile-parallel path, so that its stitch launch has tiles to
+                             compute in line (tests of that path); 0 = off (default)
+     TWL_KNOB_MT_MAX_PAIRS   levels with at most this many pairs take the tile-parallel path (default 128; 0 = never)
+     TWL_KNOB_MT_MIN_MARKER  ... and only with marker >= this (default 512)
+     TWL_KNOB_MT_LEAD        anti-diagonals a scout starts ahead of its tile boundary (default 384)
+     TWL_KNOB_MT_MARGIN      anti-diagonals a scout runs past its tile boundary (default 48) */
+enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5 };
+int twl_set_knob(int key, int value);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <mutex>
@@ -50,6 +52,24 @@ void alignmentKernel_CPU(msa::Tree *, msa::NodePairVec &nodes, msa::SequenceDB *
         tp.flen = 1 << 12;
         tp.marker = 1 << 10;
         if (database->currentTask == 1 || database->currentTask == 2 || in.refNum > 10000 || in.qryNum > 10000) tp.gap_char = 0;   // :88
+        if (const char *dumpDir = getenv("TWLO_DUMP_PAIRS")) {      // study aid: the DP inputs of the pairs of small levels, one file per pair
+            const char *mx = getenv("TWLO_DUMP_MAX_PAIRS");
+            if (n <= (mx ? atoi(mx) : 64) && in.lens.first > 0 && in.lens.second > 0 && !in.lowQ_r && !in.lowQ_q) {
+                char path[512];
+                snprintf(path, sizeof path, "%s/L%03zu_p%04d.bin", dumpDir, g_pairsPerLevel.size() + 1, i);
+                if (FILE *f = fopen(path, "wb")) {
+                    const int32_t hdr[6] = {P, in.lens.first, in.lens.second, in.refNum, in.qryNum, in.memLen};
+                    fwrite(hdr, sizeof hdr, 1, f);
+                    fwrite(in.freq.data(), sizeof(float), (size_t)P * in.lens.first, f);
+                    fwrite(in.freq.data() + (size_t)P * in.memLen, sizeof(float), (size_t)P * in.lens.second, f);
+                    fwrite(in.gapOp.data(), sizeof(float), in.lens.first, f);
+                    fwrite(in.gapEx.data(), sizeof(float), in.lens.first, f);
+                    fwrite(in.gapOp.data() + in.memLen, sizeof(float), in.lens.second, f);
+                    fwrite(in.gapEx.data() + in.memLen, sizeof(float), in.lens.second, f);
+                    fclose(f);
+                }
+            }
+        }
         alnPath aln_wo_gc;
         if (in.refLen == 0) aln_wo_gc.assign(in.qryLen, 1);
         if (in.qryLen == 0) aln_wo_gc.insert(aln_wo_gc.end(), in.refLen, 2);

@@ -323,6 +323,9 @@ static void tile_run(const ctx_t *c, int32_t *reference_idx, int32_t *query_idx,
         }
         max_score = (max_score_prime < 0) ? 0 : max_score_prime;   /* :607 */
         last_k = k;
+#ifdef TWLO_TILE_HOOK      /* study builds only (tests/study/): never defined for the checker library */
+        TWLO_TILE_HOOK
+#endif
         if (converged && max_score > conv_score) { conv_logic = 1; break; }   /* :609-612 */
     }
 

@@ -1,0 +1,107 @@
+/* tests/study/tile_predict_study.c -- STUDY AID (test infrastructure, uses the oracle): how well can the start cells of
+ * all tiles of a pair be predicted without running the tiles one after the other?
+ *
+ * For one dumped pair (oracle/e2e_oracle with TWLO_DUMP_PAIRS) it runs the true tile chain (Align_freq, TALCO-XDrop.cpp:62-108),
+ * then for every tile boundary starts a "scout" tile LEAD diagonals earlier from a cell DELTA rows off the true path and asks
+ * whether the scout's traceback path runs through the true start cell of the next tile.
+ *   cc -O2 -ffp-contract=off -fopenmp -o /tmp/tps tests/study/tile_predict_study.c -lm
+ *   /tmp/tps pair.bin [lead] [tailmarg]
+ */
+/* scouts that do not wait for convergence: after the marker diagonal take the better of the best cells of diagonals marker-1 / marker
+ * (the rule of the speculative tile start, talco_nuc.hip.h) and trace back from there */
+static int g_stop_at_marker = 0;
+#define TWLO_TILE_HOOK                                                                                              \
+    if (g_stop_at_marker && tile == 7777 && k == marker) {                                                          \
+        float b0 = -inf, b1 = -inf; int i0 = -1, i1 = -1;                                                           \
+        for (int32_t i = L[c1]; i <= U[c1]; ++i) if (S[c1][i - L[c1]] > b0) { b0 = S[c1][i - L[c1]]; i0 = i; }     \
+        for (int32_t i = Lk; i <= Uk; ++i) if (S[c0][i - Lk] > b1) { b1 = S[c0][i - Lk]; i1 = i; }                 \
+        if (i0 >= 0 || i1 >= 0) { conv_value = (b1 >= b0) ? (i1 & 0xFFFF) : ((3 << 16) | (i0 & 0xFFFF)); conv_logic = 1; break; } \
+    }
+#include "../../oracle/talco_oracle.c"
+#include <stdio.h>
+
+static float M5[25];
+
+typedef struct { int32_t r, q; } cell_t;
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 1;
+    const int lead = argc > 2 ? atoi(argv[2]) : 512;
+    const int marg = argc > 3 ? atoi(argv[3]) : 64;
+    const int sxdrop = argc > 4 ? atoi(argv[4]) : 5000;
+    g_stop_at_marker = argc > 5 ? atoi(argv[5]) : 0;
+    FILE *f = fopen(argv[1], "rb");
+    int32_t h[6];
+    if (!f || fread(h, sizeof h, 1, f) != 1) return 2;
+    const int P = h[0], R = h[1], Q = h[2];
+    float *ref = malloc(sizeof(float) * P * R), *qry = malloc(sizeof(float) * P * Q);
+    float *gor = malloc(4 * R), *ger = malloc(4 * R), *goq = malloc(4 * Q), *geq = malloc(4 * Q);
+    if (fread(ref, 4, (size_t)P * R, f) != (size_t)P * R || fread(qry, 4, (size_t)P * Q, f) != (size_t)P * Q || fread(gor, 4, R, f) != (size_t)R ||
+        fread(ger, 4, R, f) != (size_t)R || fread(goq, 4, Q, f) != (size_t)Q || fread(geq, 4, Q, f) != (size_t)Q) return 3;
+    fclose(f);
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) M5[5 * i + j] = (i == 4 || j == 4) ? 0.f : (i == j ? 18.f : ((i ^ j) == 2 ? -4.f : -8.f));
+    twlo_params p = {P, M5, -50.f, -5.f, -5.f, 5000, 4096, 1024};
+    ctx_t c = {&p, ref, qry, R, Q, gor, ger, goq, geq, (float)h[3], (float)h[4], NULL, NULL, NULL};
+
+    /* true chain */
+    cell_t starts[256]; int nt = 0;
+    int32_t ri = 0, qi = 0; int last = 0, tile = 0; int16_t err = 0;
+    bytes_t seg = {0, 0, 0};
+    int8_t *full = malloc(R + Q + 8); int n = 0;
+    while (!last) {
+        starts[nt].r = ri; starts[nt].q = qi; nt++;
+        seg.n = 0;
+        tile_run(&c, &ri, &qi, &seg, &last, tile, &err);
+        if (seg.n == 0) { printf("pair failed err %d\n", err); return 0; }
+        for (long i = (long)seg.n - 1; i >= 0; --i) { if (i == (long)seg.n - 1 && tile > 0) continue; full[n++] = seg.d[i]; }
+        tile++;
+    }
+    /* true path cells: cell index after each column; pathq[d] = q of the path cell on diagonal d (r+q), -1 if skipped */
+    int32_t *pathq = malloc(4 * (R + Q + 2));
+    for (int d = 0; d < R + Q + 2; ++d) pathq[d] = -1;
+    { int r = -1, q = -1; for (int t = 0; t < n; ++t) { if (full[t] == 0) { r++; q++; } else if (full[t] == 1) q++; else r++; if (r >= 0 && q >= 0) pathq[r + q] = q; } }
+    /* drift of the true path from the proportional diagonal */
+    int maxdev = 0;
+    for (int t = 1; t < nt; ++t) { int d = starts[t].r + starts[t].q; int pq = (int)((double)d * Q / (R + Q)); int dev = abs(pq - starts[t].q); if (dev > maxdev) maxdev = dev; }
+    printf("pair R %d Q %d num %d %d tiles %d maxdev_from_proportional %d\n", R, Q, h[3], h[4], nt, maxdev);
+
+    const int deltas[] = {0, 8, -8, 40, -40, 120, -120, 250, -250};
+    int hits[9] = {0}, tot[9] = {0}, fail[9] = {0};
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 1; t < nt; ++t) {
+        const int dT = starts[t].r + starts[t].q;
+        int d0 = dT - lead; if (d0 < 2) d0 = 2;
+        /* true path cell on d0 (or d0 - 1) */
+        int qq = pathq[d0]; if (qq < 0) { d0--; qq = pathq[d0]; }
+        if (qq < 0) continue;
+        for (int di = 0; di < 9; ++di) {
+            int gq = qq + deltas[di], gr = d0 - gq;
+            if (gq < 0 || gr < 0 || gq >= Q || gr >= R) continue;
+            twlo_params sp = p; sp.marker = dT - d0 + marg; sp.xdrop = sxdrop;
+            ctx_t sc = c; sc.p = &sp;
+            int32_t sr = gr, sq = gq; int sl = 0; int16_t se = 0; bytes_t sg = {0, 0, 0};
+            tile_run(&sc, &sr, &sq, &sg, &sl, g_stop_at_marker ? 7777 : 1, &se);
+#pragma omp atomic
+            tot[di]++;
+            if (sg.n == 0) {
+#pragma omp atomic
+                fail[di]++;
+                free(sg.d); continue; }
+            /* forward walk: seg reversed; its last element is the start cell's own column */
+            int r = gr, q = gq, hit = 0;
+            for (long i = (long)sg.n - 2; i >= 0; --i) {
+                if (sg.d[i] == 0) { r++; q++; } else if (sg.d[i] == 1) q++; else r++;
+                if (r == starts[t].r && q == starts[t].q) { hit = 1; break; }
+                if (r + q > dT) break;
+            }
+            if (hit) {
+#pragma omp atomic
+                hits[di]++;
+            }
+            free(sg.d);
+        }
+    }
+    for (int di = 0; di < 9; ++di) printf("  delta %5d: %d / %d hit (%d scout failures)\n", deltas[di], hits[di], tot[di], fail[di]);
+    return 0;
+}

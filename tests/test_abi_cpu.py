@@ -52,9 +52,9 @@ def test_host_library_header_symbols_are_exported(built):
 def test_struct_layouts_match_header(built):
     import twilight_amd as twl
 
-    # twl_params: int32 + 441 floats + 4 floats + 3 int32; twl_stats: 2 u64 + 3 double + 4 int32
+    # twl_params: int32 + 441 floats + 4 floats + 3 int32; twl_stats: 2 u64 + 3 double + 10 int32
     assert C.sizeof(twl.TwlParams) == 4 + 441 * 4 + 4 * 4 + 3 * 4
-    assert C.sizeof(twl.TwlStats) == 2 * 8 + 3 * 8 + 6 * 4
+    assert C.sizeof(twl.TwlStats) == 2 * 8 + 3 * 8 + 10 * 4
 
 
 def test_calls_fail_loudly_without_init_or_gpu(built):

@@ -1,0 +1,117 @@
+"""Tile-parallel alignment (talco_nuc.hip.h, MT kernels: scouts -> chain -> tiles -> stitch) vs the oracle, through the C ABI (-m gpu).
+
+Levels with few pairs of many tiles each run all tiles of all pairs side by side from PREDICTED start cells; the stitch launch keeps a
+tile only when its true start equals the predicted one and computes it in line otherwise, so paths, error codes and band cells must be
+those of the plain tile loop (Align_freq, /root/reference/src/TALCO-XDrop.cpp:62-108) whatever the predictions were."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from twilight_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+M = synth.nucleotide_matrix()
+
+
+@pytest.fixture()
+def knobs(gpu):
+    yield gpu
+    gpu.set_knob(api.KNOB_MT_PERTURB, 0)
+    gpu.set_knob(api.KNOB_MT_MAX_PAIRS, 128)
+    gpu.set_knob(api.KNOB_MT_MIN_MARKER, 512)
+    gpu.set_knob(api.KNOB_MT_LEAD, 384)
+    gpu.set_knob(api.KNOB_MT_MARGIN, 48)
+
+
+def _compare(twl, batch, **pk):
+    p = twl.make_params(M, **pk)
+    aln, n, err = twl.align_batch(p, batch)
+    st = twl.get_stats(0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), batch, threads=8)
+    assert np.array_equal(err, oerr), f"errorType differs: gpu {err.tolist()} oracle {oerr.tolist()}"
+    assert np.array_equal(n, on), f"path length differs: gpu {n.tolist()} oracle {on.tolist()}"
+    for i in range(batch.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[i, : on[i]]), f"pair {i}: path differs"
+    if np.all(oerr == 0):
+        assert st.band_cells == ost.cells, f"band cells gpu {st.band_cells} oracle {ost.cells}"
+    return st, ost
+
+
+def test_tile_parallel_default_params(knobs):
+    """6 pairs x ~6000 columns, marker 1024: ~12 tiles per pair, all predicted."""
+    batch = synth.make_level_batch(6, 6000, members=((1, 8), (1, 8)), seed=31)
+    st, ost = _compare(knobs, batch)
+    assert st.speculative == 3
+    assert st.mt_tiles_predicted + st.mt_tiles_inline == ost.tiles
+    assert st.mt_tiles_predicted >= 0.8 * ost.tiles, (st.mt_tiles_predicted, st.mt_tiles_inline, st.mt_scouts_failed)
+
+
+@pytest.mark.parametrize("perturb", [1, 2, 3])
+def test_wrong_predictions_are_computed_in_line(knobs, perturb):
+    """Every n-th predicted start is moved by one cell: those tiles must come from the stitch launch itself, results unchanged."""
+    knobs.set_knob(api.KNOB_MT_PERTURB, perturb)
+    batch = synth.make_level_batch(5, 5000, members=((1, 6), (1, 6)), seed=32 + perturb)
+    st, ost = _compare(knobs, batch)
+    assert st.speculative == 3
+    assert st.mt_tiles_inline >= (ost.tiles - batch.n_pairs) // (perturb + 1), (st.mt_tiles_predicted, st.mt_tiles_inline)
+
+
+@pytest.mark.parametrize("marker", [128, 250, 600])
+def test_small_markers(knobs, marker):
+    knobs.set_knob(api.KNOB_MT_MIN_MARKER, 64)
+    batch = synth.make_level_batch(4, 2500, members=((1, 5), (1, 5)), seed=40 + marker)
+    st, ost = _compare(knobs, batch, marker=marker)
+    assert st.speculative == 3
+    assert st.mt_tiles_predicted + st.mt_tiles_inline == ost.tiles
+
+
+def test_short_lead_and_margin(knobs):
+    """Scouts that start too late to find the path: predictions fail, the stitch launch does the work; results unchanged."""
+    knobs.set_knob(api.KNOB_MT_LEAD, 16)
+    knobs.set_knob(api.KNOB_MT_MARGIN, 2)
+    batch = synth.make_level_batch(4, 5000, members=((2, 6), (2, 6)), seed=44, indel=0.02)
+    st, ost = _compare(knobs, batch)
+    assert st.speculative == 3
+
+
+def test_error_types_through_the_tile_parallel_path(knobs):
+    """errorType 2 (band wider than fLen) and 1 (X-drop emptied the band) must surface exactly as from the plain loop."""
+    batch = synth.make_level_batch(5, 4000, members=(1, 1), seed=9)
+    st, ost = _compare(knobs, batch, flen=128)
+    assert st.speculative == 3
+    b2 = synth.make_level_batch(4, 4000, members=(1, 1), seed=21, sub=0.75, indel=0.05)
+    _compare(knobs, b2, xdrop=40)
+
+
+def test_unequal_lengths_and_trailing_runs(knobs):
+    """One side much shorter than the other: the straight-line start cells are far from the path, tiles end with trailing runs."""
+    batch = synth.make_level_batch(4, 5000, members=((1, 4), (1, 4)), seed=51)
+    ln = batch.len.copy()
+    ln[0, 0] = 3000
+    ln[1, 1] = 2500
+    ln[2, 0] = 1100
+    b = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=batch.freq, gap_open=batch.gap_open, gap_extend=batch.gap_extend, len=ln, num=batch.num)
+    _compare(knobs, b)
+
+
+def test_many_pairs_more_jobs_than_compute_units(knobs):
+    """100 pairs x 4000 columns: ~800 tile jobs on 256 compute units (several rounds per launch)."""
+    base = synth.make_level_batch(10, 4000, members=((1, 6), (1, 6)), seed=61)
+    idx = np.arange(100) % 10
+    big = synth.LevelBatch(P=base.P, seq_len=base.seq_len, freq=base.freq[idx], gap_open=base.gap_open[idx], gap_extend=base.gap_extend[idx], len=base.len[idx], num=base.num[idx])
+    p = knobs.make_params(M)
+    aln, n, err = knobs.align_batch(p, big)
+    st = knobs.get_stats(0)
+    assert st.speculative == 3
+    oa, on, oerr, ost = O.align_batch(O.make_params(M), base, threads=8)
+    assert np.array_equal(n, on[idx]) and np.array_equal(err, oerr[idx])
+    for i in range(big.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}"
+    assert st.band_cells == 10 * ost.cells
+
+
+def test_long_pair_100k(knobs):
+    batch = synth.make_level_batch(2, 100000, members=((1, 3), (1, 3)), seed=77, sub=0.03, indel=0.002)
+    st, ost = _compare(knobs, batch)
+    assert st.speculative == 3 and st.mt_tiles_predicted > 150

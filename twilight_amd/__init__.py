@@ -20,7 +20,9 @@ from .api import (  # noqa: F401
     init,
     load_library,
     make_params,
+    set_knob,
     shutdown,
 )
+from . import api as knobs  # noqa: F401  (KNOB_* constants)
 
 __version__ = "0.1.0"

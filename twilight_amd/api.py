@@ -27,11 +27,12 @@ class TwlParams(C.Structure):
 class TwlStats(C.Structure):
     _fields_ = [("band_cells", C.c_uint64), ("nominal_cells", C.c_uint64), ("kernel_ms", C.c_double),
                 ("pack_ms", C.c_double), ("total_ms", C.c_double), ("n_launches", C.c_int32),
-                ("n_relaunched", C.c_int32), ("window", C.c_int32), ("grid", C.c_int32), ("matrix_mode", C.c_int32), ("speculative", C.c_int32)]
+                ("n_relaunched", C.c_int32), ("window", C.c_int32), ("grid", C.c_int32), ("matrix_mode", C.c_int32), ("speculative", C.c_int32),
+                ("mt_tiles_predicted", C.c_int32), ("mt_tiles_inline", C.c_int32), ("mt_scouts_failed", C.c_int32), ("reserved", C.c_int32)]
 
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
-            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_dp_column_scores", "twl_host_alloc", "twl_host_free"]
+            "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_dp_column_scores", "twl_host_alloc", "twl_host_free", "twl_set_knob"]
 
 
 def exported_symbols():
@@ -61,6 +62,7 @@ def load_library():
         lib.twl_column_scores.restype = C.c_int
         lib.twl_dp_column_scores.restype = C.c_int
         lib.twl_shutdown.restype = None
+        lib.twl_set_knob.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -133,6 +135,14 @@ def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex
     _check(lib.twl_align_batch_device(C.c_int(device), vp(stream or 0), C.byref(params), C.c_int32(n_pairs), C.c_int32(seq_len),
                                       vp(d_freq), vp(d_gop), vp(d_gex), vp(d_len), vp(d_num), vp(d_aln), vp(d_aln_len),
                                       vp(d_err)))
+
+
+KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN = 1, 2, 3, 4, 5
+
+
+def set_knob(key: int, value: int):
+    """twl_set_knob: development / test knobs of the launch policy (include/twl_align.h)."""
+    _check(load_library().twl_set_knob(C.c_int(key), C.c_int(value)))
 
 
 def get_stats(device=0) -> TwlStats:

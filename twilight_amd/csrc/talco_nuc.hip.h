@@ -54,6 +54,14 @@ struct NArgs {
     const long long *sim_off;
     unsigned long long *team; // speculative tile start (SPEC kernels): [n_items][16] mailbox words, zeroed by the host
     float *simdump;           // DUMP kernels (diagnostics, one pair): [Q][R] column scores as the DP evaluated them
+    // tile-parallel alignment (MT kernels, see below)
+    const int32_t *mt_jobs;   // [n_items][2] {pair, slot} (MT 1, 2; `items` is unused there)
+    int32_t *mt_chain;        // [pair][mt_slots][2] predicted start {ref_idx, qry_idx} of tile `slot`; ref_idx < 0: unknown
+    int32_t *mt_rec;          // [pair][mt_slots][kMtRec] result of the tile that was run from the predicted start
+    int8_t *mt_seg;           // [pair][mt_slots][mt_segcap] its path segment, forward order
+    int32_t *mt_spath;        // [pair][mt_sp_pitch] scouts: query row of the path cell on anti-diagonal d; -1 = the path skips d; < -1 = unknown
+    unsigned long long *mt_stat;   // [4] {tiles taken from the records, tiles run in line, scouts that failed, -}
+    int32_t mt_slots, mt_segcap, mt_sp_pitch, mt_lead, mt_marg;
 };
 
 typedef float nuc_f4 __attribute__((ext_vector_type(4)));
@@ -158,6 +166,53 @@ __device__ __forceinline__ unsigned score_key(float f)
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// ---- tile-parallel alignment (MT != 0) ----
+// A tile is a pure function of its start cell (TALCO-XDrop.cpp:77-93: Tile() reads reference_idx / query_idx and `tile == 0`, nothing else
+// of the previous tile), and every tile after the first advances ref_idx + qry_idx by marker or marker - 1 (:616-619).  So if the start
+// cells of all tiles of a pair were known, the tiles could run side by side on as many compute units.  They can be PREDICTED: a DP that
+// starts a few hundred anti-diagonals before a tile boundary, from a cell merely NEAR the optimal path, runs into that path (the band
+// opens by a row per diagonal, the X-drop keeps everything within `xdrop` of the best cell) and from there on its traceback path IS the
+// optimal path.  Four launches per level:
+//   MT 2  scouts   one workgroup per (pair, tile boundary t): a short tile from the cell of anti-diagonal (marker-1)*t - 1 - lead that lies on
+//                  the straight line between the corners, stopped right after its own marker (placed mt_marg diagonals behind the boundary
+//                  range), traced back from the better of the best cells of its two marker diagonals; writes where its path crosses the
+//                  anti-diagonals [(marker-1)*t - 1, marker*t + 1] into mt_spath
+//   (mt_chain_kernel: walks mt_spath from (0, 0): start of tile t = the path cell on diagonal s + marker, or on s + marker - 1 when the
+//                  path steps over that diagonal -- the reference's state 3, :520-524)
+//   MT 1  tiles    one workgroup per (pair, tile): the tile from the predicted start, result + path segment into mt_rec / mt_seg
+//   MT 3  stitch   one workgroup per pair runs the ordinary tile loop; a tile whose TRUE start equals the start a record was computed
+//                  from takes the record (same function, same argument), any other tile is computed in line as always.
+// Results are those of the plain loop by construction; predictions only decide how much of it is already done.
+constexpr int kMtRec = 12;     // {1 = valid, start ref, start qry, next ref, next qry, last_tile, segment bytes, tail dir, tail len, band cells, -, -}
+
+// start cells of all tiles of a pair from the scouts' path samples (one thread per pair)
+__global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_t *len, const int32_t *items, int n_items, int32_t *chain, int slots,
+                                int marker, int perturb)
+{
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= n_items) return;
+    const int pair = items[it];
+    const int R = len[2 * pair], Q = len[2 * pair + 1];
+    const int32_t *sp = spath + (size_t)pair * (size_t)sp_pitch;
+    int32_t *ch = chain + (size_t)pair * (size_t)slots * 2;
+    ch[0] = 0; ch[1] = 0;
+    int s = 0, t = 1;
+    for (; t < slots; ++t) {
+        const int d = s + marker;
+        if (d > R + Q - 2) break;
+        int q = sp[d];
+        if (q >= 0) s = d;
+        else if (q == -1 && d - 1 > s && sp[d - 1] >= 0) { q = sp[d - 1]; s = d - 1; }
+        else break;
+        int r = s - q;
+        // development / test aid: spoil every perturb-th prediction, so that the stitch kernel has tiles to compute in line
+        if (perturb > 0 && (t % perturb) == 0) { if (q > 0 && r + 1 < R) { q -= 1; r += 1; } else if (r > 0 && q + 1 < Q) { q += 1; r -= 1; } }
+        if (r < 0 || r >= R || q >= Q) break;
+        ch[2 * t] = r; ch[2 * t + 1] = q;
+    }
+    for (; t < slots; ++t) { ch[2 * t] = -1; ch[2 * t + 1] = -1; }
+}
+
 template <int W, int RPL>
 struct NCfg {
     static constexpr int NV = W * RPL;          // 64-row blocks resident at once
@@ -171,10 +226,12 @@ struct NCfg {
 // talco_kernel): nucleotide 0 general 5x5, 1 zero N row/column (4x4 core), 2 mode 1 with the match / transition / transversion
 // structure (three products per row letter), 5 modes 1 / 2 for query rows with one non-zero letter (single sequences); protein 3 loop over the non-zero letters of the reference column, 4 scores
 // precomputed by score_matrix_kernel for the whole R x Q matrix (launches with few pairs: the other CUs are idle anyway).
-template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false, int MT = 0>
 __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 {
     static_assert((P == 6 && ((MM >= 0 && MM <= 2) || MM == 5)) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
+    static_assert(MT == 0 || (!SPEC && !DUMP), "the tile-parallel kernels are plain ones");
+    constexpr bool GUESS = SPEC || MT == 2;      // the best cells of the two marker diagonals are collected
     using C = NCfg<W, RPL>;
     constexpr int NV = C::NV, WINDOW = C::WINDOW, NB = C::NB, CAP = C::CAP;
     // first products q[m]*M[l][m] kept per row as PAIRS over two matrix rows, {l = 2h, l = 2h+1}, so that the second product and the
@@ -208,7 +265,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *tb = a.tb + (size_t)blockIdx.x * (size_t)a.tb_words;
-    const int marker = a.marker;
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
     const float gc = a.gap_char;
@@ -229,8 +285,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             item = __builtin_amdgcn_readfirstlane(s_misc[0]);
         }
         if (item >= a.n_items) break;
-        const int pair = __builtin_amdgcn_readfirstlane(a.items[item]);
+        const int pair = __builtin_amdgcn_readfirstlane((MT == 1 || MT == 2) ? a.mt_jobs[2 * item] : a.items[item]);
+        const int slot = (MT == 1 || MT == 2) ? __builtin_amdgcn_readfirstlane(a.mt_jobs[2 * item + 1]) : 0;
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
+        // MT 2 (scout of tile boundary `slot`): the anti-diagonals it reports and its own marker behind them
+        const int spLo = (a.marker - 1) * slot - 1, spHi = a.marker * slot + 1;
+        const int scoutD0 = max(spLo - a.mt_lead, 0);
+        const int marker = (MT == 2) ? min(spHi + a.mt_marg - scoutD0, kMaxMarker) : a.marker;
         const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
         const bool denomOne = (denom == 1.0f);
         const float rden = refined_rcp(denom);
@@ -238,12 +299,33 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * (P + 2));
         const float *simP = PRESIM ? a.sim + a.sim_off[pair] : nullptr;
         const int simPitch = (Q + 63) & ~63;
-        int8_t *out = a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
 
         // NOTE on control flow (as in talco_kernel): no `continue`, and every single-lane block is followed by a workgroup
         // barrier before a loop back-edge.
         int ref_idx = 0, qry_idx = 0, tile = 0, pos = 0, err = 0;
         bool last_tile = (R <= 0 || Q <= 0);
+        if constexpr (MT == 1) {          // one tile, from its predicted start (tile 0: from the corner)
+            if (slot > 0) {
+                ref_idx = __builtin_amdgcn_readfirstlane(a.mt_chain[((size_t)pair * a.mt_slots + slot) * 2]);
+                qry_idx = __builtin_amdgcn_readfirstlane(a.mt_chain[((size_t)pair * a.mt_slots + slot) * 2 + 1]);
+                tile = 1;
+                if (ref_idx < 0) last_tile = true;      // no prediction for this tile
+            }
+        }
+        if constexpr (MT == 2) {          // the cell of diagonal scoutD0 on the straight line between the corners
+            tile = 1;
+            if (spLo > R + Q - 2 || R < 2 || Q < 2) last_tile = true;
+            else {
+                qry_idx = (int)(((long long)scoutD0 * Q) / (R + Q));
+                qry_idx = min(qry_idx, Q - 1);
+                ref_idx = scoutD0 - qry_idx;
+                if (ref_idx > R - 1) { ref_idx = R - 1; qry_idx = scoutD0 - ref_idx; }
+                if (qry_idx > Q - 1 || ref_idx < 0) last_tile = true;
+            }
+        }
+        const int jobRef = ref_idx, jobQry = qry_idx;
+        int mtHits = 0, mtInline = 0;
+        int8_t *out = (MT == 1) ? a.mt_seg + ((size_t)pair * a.mt_slots + slot) * (size_t)a.mt_segcap : a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
         unsigned long long cells = 0;
         long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
         // The row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits -- TILE-local values, so sequences of any length pass
@@ -301,7 +383,32 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 redo = false;
                 if (teamExit) { last_tile = true; }
             }
-            if (!(SPEC && teamExit)) {
+            bool memoHit = false;
+            if constexpr (MT == 3) {      // the tile that starts here may have been computed already (MT 1 launch): same start, same tile
+                if (tile < a.mt_slots) {
+                    const int32_t *rc = a.mt_rec + ((size_t)pair * a.mt_slots + tile) * kMtRec;
+                    const int rcValid = __builtin_amdgcn_readfirstlane(rc[0]), rcRef = __builtin_amdgcn_readfirstlane(rc[1]), rcQry = __builtin_amdgcn_readfirstlane(rc[2]);
+                    memoHit = (rcValid == 1 && rcRef == ref_idx && rcQry == qry_idx);
+                    if (memoHit) {
+                        const int cnt = __builtin_amdgcn_readfirstlane(rc[6]), tailDir = __builtin_amdgcn_readfirstlane(rc[7]), tailLen = __builtin_amdgcn_readfirstlane(rc[8]);
+                        if (pos + cnt + tailLen > 2 * a.seq_len) err = 3;
+                        else {
+                            const int8_t *sg = a.mt_seg + ((size_t)pair * a.mt_slots + tile) * (size_t)a.mt_segcap;
+                            for (int t = threadIdx.x; t < cnt; t += C::THREADS) out[pos + t] = sg[t];
+                            for (int t = threadIdx.x; t < tailLen; t += C::THREADS) out[pos + cnt + t] = (int8_t)tailDir;
+                            pos += cnt + tailLen;
+                            ref_idx = __builtin_amdgcn_readfirstlane(rc[3]); qry_idx = __builtin_amdgcn_readfirstlane(rc[4]);
+                            last_tile = __builtin_amdgcn_readfirstlane(rc[5]) != 0;
+                            cells += (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rc[9]);
+                            mtHits += 1;
+                            tile += 1;
+                        }
+                    }
+                }
+                if (!memoHit) mtInline += 1;
+            }
+            if constexpr (MT == 3) { if (err != 0) break; }
+            if (!(SPEC && teamExit) && !memoHit) {
             const int refLen = R - ref_idx, qLen = Q - qry_idx;
             const int fLen = min(a.flen, min(refLen, qLen));                          // :258
             // one unsigned compare per step covers "band empty", "wider than fLen" and (conservatively) "outgrew the window"
@@ -658,7 +765,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             if (PH == 2 || k == marker) { if (inband) lds_st<int>(vcur + 4u * (unsigned)(i - vL) + O_CD, CDn); }
                         }
                         S1[r] = Sv; I1[r] = Iv; D1[r] = Dv;
-                        if constexpr (SPEC && PH == 1) {      // the guess for the next tile's start: best cell of diagonal marker-1 / marker
+                        if constexpr (GUESS && PH == 1) {      // the guess for the next tile's start: best cell of diagonal marker-1 / marker
                             if (inband && Sv > -inf) {
                                 const unsigned long long key = ((unsigned long long)score_key(Sv) << 32) | (unsigned)i;
                                 asm volatile("ds_max_u64 %0, %1" ::"v"(lds_off(&s_team[(k == marker) ? 3 : 2])), "v"(key) : "memory");
@@ -878,6 +985,16 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         }
                     }
                 }
+                if constexpr (MT == 2) {       // a scout ends here: its path is traced back from the better of the best cells of its two marker diagonals
+                    if (go && k == marker + 1 && k < kEnd) {
+                        const unsigned long long b0 = s_team[2], b1 = s_team[3];
+                        const unsigned k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)), k1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(b1 >> 32));
+                        const int i0 = __builtin_amdgcn_readfirstlane((int)(b0 & 0xFFFFFFFFu)), i1 = __builtin_amdgcn_readfirstlane((int)(b1 & 0xFFFFFFFFu));
+                        if ((k0 | k1) != 0u) { conv_value = (k1 >= k0) ? (i1 & 0xFFFF) : ((3 << 16) | (i0 & 0xFFFF)); conv_logic = true; }
+                        else tile_err = 1;
+                        go = false;
+                    }
+                }
                 const int kCap = min(kEnd, 65534);      // k + 1 must fit the 16-bit tag
                 while (go && k < kCap) step(T2{});
                 if (go && k < kEnd) { tile_err = kErrOverflow; go = false; }      // (never seen: tiles converge within ~1.5 markers)
@@ -1029,6 +1146,29 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 n = __builtin_amdgcn_readfirstlane(n);
                 const int skip = (tile > 0) ? 1 : 0;                          // :98-102
                 const int cnt = n - skip;
+                if constexpr (MT == 1) {          // the segment and the record of this tile (read by the stitch launch)
+                    if (cnt <= a.mt_segcap) {
+                        for (int t = lane; t < cnt; t += 64) out[t] = s_rev[n - 1 - skip - t];
+                        if (lane == 0) {
+                            int32_t *rc = a.mt_rec + ((size_t)pair * a.mt_slots + slot) * kMtRec;
+                            rc[1] = jobRef; rc[2] = jobQry; rc[3] = ref_idx; rc[4] = qry_idx; rc[5] = last_tile ? 1 : 0; rc[6] = cnt;
+                            rc[7] = tailDir; rc[8] = tailLen; rc[9] = (int32_t)tile_cells; rc[0] = 1;
+                        }
+                    }
+                } else if constexpr (MT == 2) {   // where the scout's path crosses the anti-diagonals of its tile boundary
+                    if (lane == 0) {
+                        int32_t *sp = a.mt_spath + (size_t)pair * (size_t)a.mt_sp_pitch;
+                        const int dMax = min(spHi, R + Q - 2);
+                        for (int d = spLo; d <= dMax; ++d) sp[d] = -1;
+                        int r = jobRef, q = jobQry;
+                        for (int t = n - 2; t >= 0; --t) {      // (s_rev[n - 1] is the column of the start cell itself)
+                            const int dir = s_rev[t];
+                            r += (dir != 1) ? 1 : 0; q += (dir != 2) ? 1 : 0;
+                            const int d = r + q;
+                            if (d >= spLo && d <= dMax) sp[d] = q;
+                        }
+                    }
+                } else
                 if (pos + cnt + tailLen > 2 * a.seq_len) { err = 3; }
                 else {
                     for (int t = lane; t < cnt; t += 64) out[pos + t] = s_rev[n - 1 - skip - t];
@@ -1049,6 +1189,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #endif
             if (err != 0) break;
             tile += SPEC ? 2 : 1;
+            if constexpr (MT == 1 || MT == 2) last_tile = true;      // one tile per job
             }      // (tile not thrown away)
             }      // (tile started)
         }
@@ -1072,10 +1213,16 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         }
 #endif
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if constexpr (MT == 2) {
+            if (threadIdx.x == 0 && err != 0 && a.mt_stat) atomicAdd(&a.mt_stat[2], 1ull);
+        }
+        if (threadIdx.x == 0 && MT != 1 && MT != 2) {
             if (iEnded || err != 0) {
                 a.err[pair] = (int16_t)err;
                 a.aln_len[pair] = (err == 0) ? pos : 0;
+            }
+            if constexpr (MT == 3) {
+                if (a.mt_stat) { atomicAdd(&a.mt_stat[0], (unsigned long long)mtHits); atomicAdd(&a.mt_stat[1], (unsigned long long)mtInline); }
             }
             if constexpr (SPEC) atomicAdd(&a.cells[pair], cells);       // (zeroed by the host) both workgroups add their tiles
             else a.cells[pair] = cells;

@@ -69,9 +69,11 @@ struct Device {
     Buf cols, tb, cells, queue, items, errs, dbg;
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
     Buf team;                                                                    // mailboxes of the speculative tile start
+    Buf mt_chain, mt_rec, mt_seg, mt_spath, mt_stat, mt_jobs;                    // tile-parallel alignment (talco_nuc.hip.h, MT kernels)
     Buf simdump;                                                                 // twl_dp_column_scores: [Q][R] scores written by the DUMP kernels
     bool dump_on = false;
     std::vector<int32_t> dbg_host;
+    std::vector<int32_t> mt_jobs_host;
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
     std::vector<uint64_t> pair_cells;
@@ -210,6 +212,93 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     return TWL_OK;
 }
 
+// Tile-parallel alignment of a level with few pairs (talco_nuc.hip.h, MT kernels): scouts -> chain -> tiles -> stitch, four launches on `st`.
+// `order` = the pairs that run, h_len their lengths on the host.
+int g_mt_perturb = 0;       // twl_debug_set(TWL_DEBUG_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the in-line path of the stitch kernel)
+int g_mt_lead = 384, g_mt_marg = 48;
+int g_mt_max_pairs = 128, g_mt_min_marker = 512;
+
+template <int P, int W, int RPL, int MM, int MINW>
+int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
+              const int32_t *h_len, int *grid_out, int *window_out)
+{
+    using CfgT = twl::NCfg<W, RPL>;
+    static std::atomic<int> cached{0};
+    if (cached.load() == 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 1>), CfgT::THREADS, 0));
+        cached.store(std::max(1, nb));
+    }
+    const int slotsCap = d->num_cu * cached.load();
+    if (window_out) *window_out = CfgT::WINDOW;
+    const int marker = base.marker;
+    const int slots = (2 * base.seq_len) / (marker - 1) + 2;
+    const int segcap = 2 * marker + 16;
+    const int sp_pitch = 2 * base.seq_len + 8;
+    const size_t np = (size_t)base.n_pairs_total;
+    // jobs: scouts for every tile boundary t >= 1 that exists, tiles for t >= 0 (tile-major, so that the tiles of a pair spread over the launch)
+    std::vector<int32_t> &jobs = d->mt_jobs_host;       // scouts first, then tiles (kept with the device: the upload below is asynchronous)
+    jobs.clear();
+    int maxT = 0;
+    std::vector<int> T((size_t)n_run);
+    for (int t = 0; t < n_run; ++t) {
+        const int pr = order[t];
+        const long long RQ = (long long)h_len[2 * pr] + h_len[2 * pr + 1];
+        int n = 1;
+        while (n < slots && (long long)(marker - 1) * n - 1 <= RQ - 2) ++n;
+        T[t] = n; maxT = std::max(maxT, n);
+    }
+    for (int s = 1; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); }
+    const int nScout = (int)(jobs.size() / 2);
+    for (int s = 0; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); }
+    const int nTile = (int)(jobs.size() / 2) - nScout;
+    int rc;
+    if ((rc = d->mt_chain.ensure(np * slots * 2 * sizeof(int32_t)))) return rc;
+    if ((rc = d->mt_rec.ensure(np * slots * twl::kMtRec * sizeof(int32_t)))) return rc;
+    if ((rc = d->mt_seg.ensure(np * slots * (size_t)segcap))) return rc;
+    if ((rc = d->mt_spath.ensure(np * (size_t)sp_pitch * sizeof(int32_t)))) return rc;
+    if ((rc = d->mt_stat.ensure(4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = d->mt_jobs.ensure(jobs.size() * sizeof(int32_t)))) return rc;
+    const int gridMax = std::max(1, std::min(std::max(nTile, n_run), slotsCap));
+    const size_t tbw = ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW;
+    if ((rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)gridMax))) return rc;
+    HIP_TRY(hipMemcpyAsync(d->mt_jobs.p, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d->mt_rec.p, 0, np * slots * twl::kMtRec * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(d->mt_spath.p, 0xFE, np * (size_t)sp_pitch * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(d->mt_stat.p, 0, 4 * sizeof(unsigned long long), st));
+    twl::NArgs a{};
+    a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
+    a.cells = base.cells; a.tb = (uint32_t *)d->tb.p; a.queue = base.queue; a.items = d_items; a.n_items = n_run;
+    a.seq_len = base.seq_len; a.tb_words = (int32_t)tbw; a.dbg = nullptr; a.n_pairs_total = base.n_pairs_total;
+    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char;
+    a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
+    for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
+    a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
+    a.mt_chain = (int32_t *)d->mt_chain.p; a.mt_rec = (int32_t *)d->mt_rec.p; a.mt_seg = (int8_t *)d->mt_seg.p; a.mt_spath = (int32_t *)d->mt_spath.p;
+    a.mt_stat = (unsigned long long *)d->mt_stat.p;
+    a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
+    TRACE("launch mt W=%d RPL=%d pairs=%d scouts=%d tiles=%d slots=%d", W, RPL, n_run, nScout, nTile, slots);
+    if (nScout > 0) {
+        a.mt_jobs = (const int32_t *)d->mt_jobs.p; a.n_items = nScout;
+        HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 2>), dim3(std::min(nScout, slotsCap)), dim3(CfgT::THREADS), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(twl::mt_chain_kernel, dim3((n_run + 63) / 64), dim3(64), 0, st, (const int32_t *)d->mt_spath.p, sp_pitch, base.len, d_items, n_run,
+                       (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb);
+    HIP_TRY(hipGetLastError());
+    a.mt_jobs = (const int32_t *)d->mt_jobs.p + 2 * (size_t)nScout; a.n_items = nTile;
+    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 1>), dim3(std::min(nTile, slotsCap)), dim3(CfgT::THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    a.mt_jobs = nullptr; a.n_items = n_run; a.dbg = base.dbg;
+    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 3>), dim3(std::min(n_run, slotsCap)), dim3(CfgT::THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    *grid_out = std::min(nTile, slotsCap);
+    return TWL_OK;
+}
+
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
@@ -294,6 +383,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
+    bool ranMt = false;
     const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
@@ -410,6 +500,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_run <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
         statMode = mm5 ? 5 : mm;
         statSpec = spec ? 1 : 0;
+        long long sumLen = 0;
+        for (int32_t t = 0; t < n_run; ++t) sumLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
+        const bool mtOk = lean && mm == 2 && !mm5 && !d->dump_on && n_run <= g_mt_max_pairs && p->marker >= g_mt_min_marker &&
+                          sumLen >= 3ll * p->marker * n_run && !getenv("TWL_NO_MT");
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
             if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_run, &grid, &window);
@@ -423,6 +517,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             // 16-wave workgroup per pair; below CUs/2 pairs the 16-wave teams on a CU each are a little faster (16.4 vs 16.9 ms)
             rc = launch_lean<6, 8, 2, 2, 4, true>(d, st, a, items, n_run, &grid, &window);
             statMode = 2; statSpec = 2;
+        }
+        else if (mtOk) {
+            // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
+            rc = launch_mt<6, 16, 1, 2, 1>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            statSpec = 3; ranMt = true;
         }
         else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_run, &grid, &window);
         else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_run, &grid, &window);
@@ -496,6 +595,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t total = 0;
     for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
+    if (ranMt) {
+        unsigned long long ms[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(ms, d->mt_stat.p, sizeof ms, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        d->stats.mt_tiles_predicted = (int32_t)ms[0]; d->stats.mt_tiles_inline = (int32_t)ms[1]; d->stats.mt_scouts_failed = (int32_t)ms[2];
+    }
     if (want_dbg) {
         d->dbg_host.resize((size_t)n_pairs * 16);
         HIP_TRY(hipMemcpy(d->dbg_host.data(), d->dbg.p, d->dbg_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -569,7 +674,7 @@ void twl_shutdown(void)
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
         twl_level_pool_release(d);
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump,
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -822,6 +927,19 @@ void *twl_host_alloc(uint64_t bytes)
 void twl_host_free(void *p)
 {
     if (p) (void)hipHostFree(p);
+}
+
+int twl_set_knob(int key, int value)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    switch (key) {
+    case TWL_KNOB_MT_PERTURB: g_mt_perturb = std::max(0, value); return TWL_OK;
+    case TWL_KNOB_MT_MAX_PAIRS: g_mt_max_pairs = std::max(0, value); return TWL_OK;
+    case TWL_KNOB_MT_MIN_MARKER: g_mt_min_marker = std::max(2, value); return TWL_OK;
+    case TWL_KNOB_MT_LEAD: g_mt_lead = std::max(16, value); return TWL_OK;
+    case TWL_KNOB_MT_MARGIN: g_mt_marg = std::max(2, value); return TWL_OK;
+    default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
+    }
 }
 
 int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)
