@@ -200,31 +200,6 @@ def wallclock_to_msa(tree, fasta, typ, d):
             "note": "twilight-mi355x on the same family files, 1 GPU, time of the whole process (HIP start-up, read FASTA + tree, align, write MSA)"}
 
 
-def variant_of(pairs, num_cu, P, mode=-1, spec=-1):
-    """The DP kernel instantiation the library launched for a level of `pairs` pairs (twl_align.hip, run_device), as rocprofv3 names it: two
-    workgroups per pair with speculative tile start up to CUs/2 pairs (protein: on precomputed scores), one 16-wave workgroup per pair
-    up to CUs, the throughput geometry beyond (two workgroups per CU: 8 waves x 2 blocks, protein 8 waves x 1 block on a 512-row
-    window).  `mode` / `spec` are the level record's matrix_mode / speculative (nucleotide mode 5: single-sequence query sides)."""
-    if P == 22:
-        if pairs <= max(1, num_cu // 2):
-            return "talco_lean_kernel<22, 16, 1, 4, 1, true, false> (precomputed column scores, speculative tile start)"
-        if spec == 2:
-            return "talco_lean_kernel<22, 8, 1, 4, 4, true, false> (precomputed column scores, speculative tile start, 512-row window, two workgroups per CU)"
-        if pairs <= num_cu:
-            return "talco_lean_kernel<22, 16, 1, 3, 1, false, false> (sparse column scores)"
-        return "talco_lean_kernel<22, 8, 1, 3, 4, false, false> (sparse column scores, 512-row window, two workgroups per CU)"
-    mm = mode if mode in (0, 1, 2, 5) else 2
-    note = " (one-letter query rows)" if mm == 5 else ""
-    if spec == 2:
-        return "talco_lean_kernel<6, 8, 2, 2, 4, true, false> (speculative tile start, two workgroups per CU)"
-    is_spec = (2 * pairs <= num_cu) if spec < 0 else bool(spec)
-    if is_spec:
-        return f"talco_lean_kernel<6, 16, 1, {mm}, 1, true, false> (speculative tile start)" + note
-    if pairs <= num_cu:
-        return f"talco_lean_kernel<6, 16, 1, {mm}, 1, false, false>" + note
-    return f"talco_lean_kernel<6, 8, 2, {mm}, {4 if mm in (2, 5) else 2}, false, false>" + note
-
-
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -370,10 +345,16 @@ def main():
             out["dp_kernel"] = {"cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms_per_pass": kernel_ms / steps, "exchange_ms_per_pass": exch_ms / steps,
                                 "share_of_step_time": (kernel_ms / steps) / (dt_max * 1e3 / steps),
                                 "note": "all DP launches of a pass (HIP events on the library's stream; with several ranks the slowest rank of each level)"}
-            out["levels"] = [{"pairs": int(lv.pairs), "cells": int(lv.band_cells), "kernel_ms": round(lv.kernel_ms, 3), "level_ms": round(lv.level_ms, 3)} for lv in levels]
+            out["levels"] = [{"pairs": int(lv.pairs), "cells": int(lv.band_cells), "kernel_ms": round(lv.kernel_ms, 3), "level_ms": round(lv.level_ms, 3),
+                              **({"tiles_predicted": int(lv.mt_tiles_predicted), "tiles_inline": int(lv.mt_tiles_inline)} if int(lv.speculative) == 3 else {})} for lv in levels]
+            tp = sum(int(lv.mt_tiles_predicted) for lv in levels)
+            ti = sum(int(lv.mt_tiles_inline) for lv in levels)
+            out["tile_parallel"] = {"levels": sum(1 for lv in levels if int(lv.speculative) == 3), "tiles_predicted": tp, "tiles_inline": ti,
+                                    "hit_rate": tp / max(1, tp + ti),
+                                    "note": "levels with few pairs: every tile of every pair runs at once from a predicted start cell; a tile whose true start differs is recomputed in line (last report of the timed passes)"}
             by = {}
             for lv in levels:
-                v = by.setdefault(variant_of(lv.pairs, num_cu, cfg["P"], int(lv.matrix_mode), int(lv.speculative)), [0, 0.0, 0])
+                v = by.setdefault(lv.kernel.decode() or "?", [0, 0.0, 0])      # the kernel name comes from the library (twl_stats.kernel)
                 v[0] += 1; v[1] += lv.kernel_ms; v[2] += lv.band_cells
             kernels = [{"kernel": k, "launches": v[0], "avg_ms": v[1] / v[0], "cells_per_launch": v[2] // v[0],
                         "frac": (v[2] * bcell / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[1] > 0 else 0.0} for k, v in by.items()]

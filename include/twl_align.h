@@ -66,6 +66,7 @@ typedef struct twl_stats {
     int32_t  mt_tiles_inline;      /* ... tiles computed in line by the stitch launch (prediction missing or wrong) */
     int32_t  mt_scouts_failed;     /* ... scouts that produced no path sample */
     int32_t  reserved;
+    char     kernel[160];          /* the DP kernel of the first launch, as the profiler names it (template arguments spelled out) */
 } twl_stats;
 
 /* Select devices (HIP ordinals).  n_devices==0 or device_ids==NULL -> device 0 only.
@@ -133,11 +134,15 @@ int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq
 /* Development / test knobs of the launch policy (process-wide; not needed in production).  Returns TWL_ERR_BAD_ARGUMENT for an unknown key.
      TWL_KNOB_MT_PERTURB     n > 0: spoil every n-th predicted tile start of the tile-parallel path, so that its stitch launch has tiles to
                              compute in line (tests of that path); 0 = off (default)
-     TWL_KNOB_MT_MAX_PAIRS   levels with at most this many pairs take the tile-parallel path (default 128; 0 = never)
+     TWL_KNOB_MT_MAX_PAIRS   levels with at most this many pairs may take the tile-parallel path (default 1024; 0 = never): all levels of up to CUs/2 pairs, larger
+                             ones when their pairs fill the last round of the throughput kernel badly
      TWL_KNOB_MT_MIN_MARKER  ... and only with marker >= this (default 512)
-     TWL_KNOB_MT_LEAD        anti-diagonals a scout starts ahead of its tile boundary (default 384)
-     TWL_KNOB_MT_MARGIN      anti-diagonals a scout runs past its tile boundary (default 48) */
-enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5 };
+     TWL_KNOB_MT_LEAD        anti-diagonals a scout starts ahead of its tile boundary (default 320)
+     TWL_KNOB_MT_MARGIN      anti-diagonals a scout runs past its tile boundary (default 40)
+     TWL_KNOB_MT_ROUNDS      rounds of predict / run / verify before the remaining tiles are computed in line (default 2)
+     TWL_KNOB_MT_THR_JOBS    levels with more tiles than this run scouts and tiles on the throughput geometry (default 512) */
+enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
+                TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7 };
 int twl_set_knob(int key, int value);
 
 #ifdef __cplusplus

@@ -32,7 +32,10 @@ typedef struct twl_msa_level {
     double   level_ms;      /* host wall time of the level-kernel call */
     double   exchange_ms;   /* of which: all-gather of the paths between processes */
     int32_t  matrix_mode;   /* column-score mode of the level's DP kernel (twl_stats.matrix_mode; -1 unknown) */
-    int32_t  speculative;   /* the speculative two-workgroup kernel ran the level: 1 a CU per workgroup, 2 two workgroups per CU (twl_stats.speculative) */
+    int32_t  speculative;   /* the speculative two-workgroup kernel ran the level: 1 a CU per workgroup, 2 two workgroups per CU; 3 tile-parallel (twl_stats.speculative) */
+    int32_t  mt_tiles_predicted;   /* tile-parallel levels: tiles whose predicted start cell was the true one */
+    int32_t  mt_tiles_inline;      /* ... tiles the stitch launch computed itself */
+    char     kernel[160];   /* the level's DP kernel as the profiler names it (twl_stats.kernel; device 0 / this rank) */
 } twl_msa_level;
 
 typedef struct twl_msa_totals {

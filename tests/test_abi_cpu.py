@@ -45,7 +45,7 @@ def test_host_library_header_symbols_are_exported(built):
     assert set(declared) == set(msa.exported_symbols())
     for name in declared:
         assert getattr(lib, name) is not None, name
-    assert C.sizeof(msa.MsaLevel) == 2 * 4 + 2 * 8 + 3 * 8 + 2 * 4
+    assert C.sizeof(msa.MsaLevel) == 2 * 4 + 2 * 8 + 3 * 8 + 4 * 4 + 160
     assert C.sizeof(msa.MsaTotals) == 4 * 4 + 3 * 8 + 3 * 8
 
 
@@ -54,7 +54,7 @@ def test_struct_layouts_match_header(built):
 
     # twl_params: int32 + 441 floats + 4 floats + 3 int32; twl_stats: 2 u64 + 3 double + 10 int32
     assert C.sizeof(twl.TwlParams) == 4 + 441 * 4 + 4 * 4 + 3 * 4
-    assert C.sizeof(twl.TwlStats) == 2 * 8 + 3 * 8 + 10 * 4
+    assert C.sizeof(twl.TwlStats) == 2 * 8 + 3 * 8 + 10 * 4 + 160
 
 
 def test_calls_fail_loudly_without_init_or_gpu(built):

@@ -18,10 +18,12 @@ M = synth.nucleotide_matrix()
 def knobs(gpu):
     yield gpu
     gpu.set_knob(api.KNOB_MT_PERTURB, 0)
-    gpu.set_knob(api.KNOB_MT_MAX_PAIRS, 128)
+    gpu.set_knob(api.KNOB_MT_MAX_PAIRS, 1024)
     gpu.set_knob(api.KNOB_MT_MIN_MARKER, 512)
-    gpu.set_knob(api.KNOB_MT_LEAD, 384)
-    gpu.set_knob(api.KNOB_MT_MARGIN, 48)
+    gpu.set_knob(api.KNOB_MT_LEAD, 320)
+    gpu.set_knob(api.KNOB_MT_MARGIN, 40)
+    gpu.set_knob(api.KNOB_MT_ROUNDS, 2)
+    gpu.set_knob(api.KNOB_MT_THR_JOBS, 512)
 
 
 def _compare(twl, batch, **pk):
@@ -47,14 +49,28 @@ def test_tile_parallel_default_params(knobs):
     assert st.mt_tiles_predicted >= 0.8 * ost.tiles, (st.mt_tiles_predicted, st.mt_tiles_inline, st.mt_scouts_failed)
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 4])
 @pytest.mark.parametrize("perturb", [1, 2, 3])
-def test_wrong_predictions_are_computed_in_line(knobs, perturb):
-    """Every n-th predicted start is moved by one cell: those tiles must come from the stitch launch itself, results unchanged."""
+def test_wrong_predictions_are_repaired(knobs, perturb, rounds):
+    """Every n-th predicted start is moved by one cell: each round of predict / run / verify gets a pair past one such tile (the
+    prediction is redone from the true cell), what is left after the last round is computed in line; results unchanged."""
     knobs.set_knob(api.KNOB_MT_PERTURB, perturb)
+    knobs.set_knob(api.KNOB_MT_ROUNDS, rounds)
     batch = synth.make_level_batch(5, 5000, members=((1, 6), (1, 6)), seed=32 + perturb)
     st, ost = _compare(knobs, batch)
     assert st.speculative == 3
-    assert st.mt_tiles_inline >= (ost.tiles - batch.n_pairs) // (perturb + 1), (st.mt_tiles_predicted, st.mt_tiles_inline)
+    assert st.mt_tiles_predicted + st.mt_tiles_inline == ost.tiles
+    if rounds == 1:
+        assert st.mt_tiles_inline >= (ost.tiles - batch.n_pairs) // (perturb + 1), (st.mt_tiles_predicted, st.mt_tiles_inline)
+
+
+def test_throughput_geometry_for_scouts_and_tiles(knobs):
+    """The 8-wave x 2-block geometry (two workgroups per CU) for the scout and tile launches, forced on a small level."""
+    knobs.set_knob(api.KNOB_MT_THR_JOBS, 0)
+    batch = synth.make_level_batch(6, 6000, members=((1, 8), (1, 8)), seed=31)
+    st, ost = _compare(knobs, batch)
+    assert st.speculative == 3 and b"8, 2" in st.kernel
+    assert st.mt_tiles_predicted >= 0.8 * ost.tiles
 
 
 @pytest.mark.parametrize("marker", [128, 250, 600])

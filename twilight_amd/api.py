@@ -28,7 +28,8 @@ class TwlStats(C.Structure):
     _fields_ = [("band_cells", C.c_uint64), ("nominal_cells", C.c_uint64), ("kernel_ms", C.c_double),
                 ("pack_ms", C.c_double), ("total_ms", C.c_double), ("n_launches", C.c_int32),
                 ("n_relaunched", C.c_int32), ("window", C.c_int32), ("grid", C.c_int32), ("matrix_mode", C.c_int32), ("speculative", C.c_int32),
-                ("mt_tiles_predicted", C.c_int32), ("mt_tiles_inline", C.c_int32), ("mt_scouts_failed", C.c_int32), ("reserved", C.c_int32)]
+                ("mt_tiles_predicted", C.c_int32), ("mt_tiles_inline", C.c_int32), ("mt_scouts_failed", C.c_int32), ("reserved", C.c_int32),
+                ("kernel", C.c_char * 160)]
 
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
@@ -137,7 +138,7 @@ def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex
                                       vp(d_err)))
 
 
-KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN = 1, 2, 3, 4, 5
+KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN, KNOB_MT_ROUNDS, KNOB_MT_THR_JOBS = 1, 2, 3, 4, 5, 6, 7
 
 
 def set_knob(key: int, value: int):

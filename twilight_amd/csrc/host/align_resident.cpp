@@ -17,6 +17,7 @@
 // Per level only paths cross PCIe, nothing crosses xGMI.  TWL_TEST_VIRTUAL_DEVICES=k (tests) runs k replicas on the first device.
 #include "align_gpu.hpp"
 
+#include <cstring>
 #include <omp.h>
 
 #include <algorithm>
@@ -350,7 +351,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             callMs[d] += nowMs() - tCall;
             twl_stats st{};
             if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
-                if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; } }
+                if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); } if (d == 0) { rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; } }
             }
             std::vector<int32_t> fetch, fetchLen;
             for (int i = 0; i < n; ++i) {

@@ -116,6 +116,8 @@ int twl_msa_report(twl_msa *m, twl_msa_totals *t, twl_msa_level *levels, int32_t
         levels[i].pairs = recs[i].pairs; levels[i].task = recs[i].task; levels[i].band_cells = recs[i].band_cells;
         levels[i].relaunched = recs[i].relaunched; levels[i].kernel_ms = recs[i].kernel_ms; levels[i].level_ms = recs[i].level_ms;
         levels[i].exchange_ms = recs[i].exchange_ms; levels[i].matrix_mode = recs[i].matrix_mode; levels[i].speculative = recs[i].speculative;
+        levels[i].mt_tiles_predicted = recs[i].mt_predicted; levels[i].mt_tiles_inline = recs[i].mt_inline;
+        memcpy(levels[i].kernel, recs[i].kernel, sizeof levels[i].kernel);
     }
     return 0;
 }

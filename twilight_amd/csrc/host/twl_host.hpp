@@ -252,7 +252,8 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &alnPairs, SequenceDB *databa
 struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0, exchange_ms = 0; };
 extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
 // One level-kernel call, as the reference's per-level report line (progressive.cpp:178-189) plus what the DP did in it.
-struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relaunched = 0; double kernel_ms = 0, level_ms = 0, exchange_ms = 0; int32_t matrix_mode = -1, speculative = 0; };
+struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relaunched = 0; double kernel_ms = 0, level_ms = 0, exchange_ms = 0; int32_t matrix_mode = -1, speculative = 0;
+                     int32_t mt_predicted = 0, mt_inline = 0; char kernel[160] = {0}; };
 // Several processes (one per GPU) aligning ONE family together: every process runs the same host flow on its own replica, aligns
 // the pairs dealt to its rank and receives the other ranks' paths through `exchange` (an all-gather of equal-sized host blocks:
 // send = this rank's block, recv = [world][bytes_per_rank]; returns 0 on success).  twilight_amd/dist.py provides it over

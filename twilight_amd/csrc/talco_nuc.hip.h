@@ -61,7 +61,9 @@ struct NArgs {
     int8_t *mt_seg;           // [pair][mt_slots][mt_segcap] its path segment, forward order
     int32_t *mt_spath;        // [pair][mt_sp_pitch] scouts: query row of the path cell on anti-diagonal d; -1 = the path skips d; < -1 = unknown
     unsigned long long *mt_stat;   // [4] {tiles taken from the records, tiles run in line, scouts that failed, -}
+    int32_t *mt_front;        // [pair][8] how far the stitch launches have come: {0 untouched / 1 suspended at a tile without a record / 2 done, tile, ref_idx, qry_idx, pos, -, cells lo, cells hi}
     int32_t mt_slots, mt_segcap, mt_sp_pitch, mt_lead, mt_marg;
+    int32_t mt_inline;        // MT 3: 1 = a tile without a matching record is computed in line (last round); 0 = the pair is suspended there
 };
 
 typedef float nuc_f4 __attribute__((ext_vector_type(4)));
@@ -182,12 +184,16 @@ __device__ __forceinline__ unsigned score_key(float f)
 //   MT 1  tiles    one workgroup per (pair, tile): the tile from the predicted start, result + path segment into mt_rec / mt_seg
 //   MT 3  stitch   one workgroup per pair runs the ordinary tile loop; a tile whose TRUE start equals the start a record was computed
 //                  from takes the record (same function, same argument), any other tile is computed in line as always.
+// A wrong prediction that also gets the anti-diagonal wrong (marker vs marker - 1) would shift every later boundary of the pair, so the
+// chain / tiles / stitch launches run in ROUNDS: a stitch launch that is not the last one suspends a pair at the first tile without a
+// matching record (mt_front), the next chain launch re-derives the pair's remaining starts from that TRUE cell, the next tile launch runs
+// the tiles whose record does not match the new prediction; the last stitch launch computes whatever is still missing in line.
 // Results are those of the plain loop by construction; predictions only decide how much of it is already done.
 constexpr int kMtRec = 12;     // {1 = valid, start ref, start qry, next ref, next qry, last_tile, segment bytes, tail dir, tail len, band cells, -, -}
 
 // start cells of all tiles of a pair from the scouts' path samples (one thread per pair)
 __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_t *len, const int32_t *items, int n_items, int32_t *chain, int slots,
-                                int marker, int perturb)
+                                int marker, int perturb, const int32_t *front)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= n_items) return;
@@ -195,8 +201,16 @@ __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_
     const int R = len[2 * pair], Q = len[2 * pair + 1];
     const int32_t *sp = spath + (size_t)pair * (size_t)sp_pitch;
     int32_t *ch = chain + (size_t)pair * (size_t)slots * 2;
-    ch[0] = 0; ch[1] = 0;
+    const int32_t *fr = front + (size_t)pair * 8;
+    if (fr[0] == 2) return;                       // the pair is finished
     int s = 0, t = 1;
+    if (fr[0] == 1) {                             // later rounds: from the true start of the first tile without a record
+        t = fr[1];
+        if (t >= slots) return;
+        ch[2 * t] = fr[2]; ch[2 * t + 1] = fr[3];
+        s = fr[2] + fr[3];
+        t += 1;
+    } else { ch[0] = 0; ch[1] = 0; }
     for (; t < slots; ++t) {
         const int d = s + marker;
         if (d > R + Q - 2) break;
@@ -311,6 +325,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 tile = 1;
                 if (ref_idx < 0) last_tile = true;      // no prediction for this tile
             }
+            // later rounds: only the tiles the stitch launches have not passed yet, and only where no record of the predicted start exists
+            const int32_t *fr = a.mt_front + (size_t)pair * 8;
+            const int fs = __builtin_amdgcn_readfirstlane(fr[0]), ft = __builtin_amdgcn_readfirstlane(fr[1]);
+            const int32_t *rc = a.mt_rec + ((size_t)pair * a.mt_slots + slot) * kMtRec;
+            const int rv = __builtin_amdgcn_readfirstlane(rc[0]), rr = __builtin_amdgcn_readfirstlane(rc[1]), rq = __builtin_amdgcn_readfirstlane(rc[2]);
+            if (fs == 2 || (fs == 1 && slot < ft) || (rv == 1 && rr == ref_idx && rq == qry_idx)) last_tile = true;
         }
         if constexpr (MT == 2) {          // the cell of diagonal scoutD0 on the straight line between the corners
             tile = 1;
@@ -325,6 +345,18 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         }
         const int jobRef = ref_idx, jobQry = qry_idx;
         int mtHits = 0, mtInline = 0;
+        bool suspended = false, mtSkip = false;
+        unsigned long long mtCells0 = 0;
+        if constexpr (MT == 3) {          // where the previous stitch launch left this pair
+            const int32_t *fr = a.mt_front + (size_t)pair * 8;
+            const int fs = __builtin_amdgcn_readfirstlane(fr[0]);
+            if (fs == 2) { mtSkip = true; last_tile = true; }
+            else if (fs == 1) {
+                tile = __builtin_amdgcn_readfirstlane(fr[1]); ref_idx = __builtin_amdgcn_readfirstlane(fr[2]); qry_idx = __builtin_amdgcn_readfirstlane(fr[3]);
+                pos = __builtin_amdgcn_readfirstlane(fr[4]);
+                mtCells0 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(fr[6]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(fr[7]) << 32);
+            }
+        }
         int8_t *out = (MT == 1) ? a.mt_seg + ((size_t)pair * a.mt_slots + slot) * (size_t)a.mt_segcap : a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
         unsigned long long cells = 0;
         long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
@@ -405,6 +437,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         }
                     }
                 }
+                if (!memoHit && !a.mt_inline) { suspended = true; break; }      // not the last round: the next one predicts again from here
                 if (!memoHit) mtInline += 1;
             }
             if constexpr (MT == 3) { if (err != 0) break; }
@@ -1216,13 +1249,20 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         if constexpr (MT == 2) {
             if (threadIdx.x == 0 && err != 0 && a.mt_stat) atomicAdd(&a.mt_stat[2], 1ull);
         }
-        if (threadIdx.x == 0 && MT != 1 && MT != 2) {
+        if constexpr (MT == 3) {
+            if (threadIdx.x == 0 && !mtSkip) {
+                int32_t *fr = a.mt_front + (size_t)pair * 8;
+                const unsigned long long c = cells + mtCells0;
+                fr[1] = tile; fr[2] = ref_idx; fr[3] = qry_idx; fr[4] = pos; fr[6] = (int32_t)(unsigned)(c & 0xFFFFFFFFull); fr[7] = (int32_t)(unsigned)(c >> 32);
+                fr[0] = suspended ? 1 : 2;
+                if (a.mt_stat) { atomicAdd(&a.mt_stat[0], (unsigned long long)mtHits); atomicAdd(&a.mt_stat[1], (unsigned long long)mtInline); }
+            }
+            cells += mtCells0;
+        }
+        if (threadIdx.x == 0 && MT != 1 && MT != 2 && !(MT == 3 && (suspended || mtSkip))) {
             if (iEnded || err != 0) {
                 a.err[pair] = (int16_t)err;
                 a.aln_len[pair] = (err == 0) ? pos : 0;
-            }
-            if constexpr (MT == 3) {
-                if (a.mt_stat) { atomicAdd(&a.mt_stat[0], (unsigned long long)mtHits); atomicAdd(&a.mt_stat[1], (unsigned long long)mtInline); }
             }
             if constexpr (SPEC) atomicAdd(&a.cells[pair], cells);       // (zeroed by the host) both workgroups add their tiles
             else a.cells[pair] = cells;

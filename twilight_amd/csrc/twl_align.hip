@@ -74,6 +74,7 @@ struct Device {
     bool dump_on = false;
     std::vector<int32_t> dbg_host;
     std::vector<int32_t> mt_jobs_host;
+    char kname[160] = {0};                                                       // the kernel of the first DP launch of the call in flight
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
     std::vector<uint64_t> pair_cells;
@@ -141,6 +142,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     }
 #endif
     TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
+    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_kernel<%d, %d, %d, %s, %s, %s, %d, %d>", P, W, RPL, PRE ? "true" : "false", REFLDS ? "true" : "false", QREG ? "true" : "false", MINW, MM);
     hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
@@ -197,6 +199,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
         a.team = (unsigned long long *)d->team.p;
     }
     TRACE("launch lean P=%d W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", P, W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
+    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, %d, %s, %s, 0>", P, W, RPL, MM, MINW, SPEC ? "true" : "false", DUMP ? "true" : "false");
     a.simdump = DUMP ? (float *)d->simdump.p : nullptr;
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
@@ -212,25 +215,41 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     return TWL_OK;
 }
 
-// Tile-parallel alignment of a level with few pairs (talco_nuc.hip.h, MT kernels): scouts -> chain -> tiles -> stitch, four launches on `st`.
-// `order` = the pairs that run, h_len their lengths on the host.
-int g_mt_perturb = 0;       // twl_debug_set(TWL_DEBUG_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the in-line path of the stitch kernel)
-int g_mt_lead = 384, g_mt_marg = 48;
-int g_mt_max_pairs = 128, g_mt_min_marker = 512;
-
-template <int P, int W, int RPL, int MM, int MINW>
-int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
-              const int32_t *h_len, int *grid_out, int *window_out)
+// One launch of a tile-parallel kernel (MT 1 tiles / 2 scouts / 3 stitch) of geometry <W, RPL>; the caller has filled the NArgs.
+template <int P, int W, int RPL, int MM, int MINW, int MT>
+int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *grid_out = nullptr)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};
     if (cached.load() == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 1>), CfgT::THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
-    const int slotsCap = d->num_cu * cached.load();
-    if (window_out) *window_out = CfgT::WINDOW;
+    const int grid = std::max(1, std::min(n_items, d->num_cu * cached.load()));
+    const size_t tbw = ((size_t)(a.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
+    int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
+    if (rc) return rc;
+    a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
+    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    if (grid_out) *grid_out = grid;
+    return TWL_OK;
+}
+
+// Tile-parallel alignment of a level with few pairs (talco_nuc.hip.h, MT kernels): scouts, then rounds of chain -> tiles -> stitch, on `st`.
+// `order` = the pairs that run, h_len their lengths on the host.  Scouts and tiles run on the 16-wave geometry (one workgroup per CU, the
+// shortest diagonal step) while they fit the device about twice over, on the throughput geometry (8 waves x 2 blocks, two per CU) beyond.
+int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
+int g_mt_lead = 320, g_mt_marg = 40;
+int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 512;
+
+template <int P, int MM>
+int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
+              const int32_t *h_len, int *grid_out, int *window_out)
+{
+    if (window_out) *window_out = twl::NCfg<16, 1>::WINDOW;
     const int marker = base.marker;
     const int slots = (2 * base.seq_len) / (marker - 1) + 2;
     const int segcap = 2 * marker + 16;
@@ -257,45 +276,45 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     if ((rc = d->mt_rec.ensure(np * slots * twl::kMtRec * sizeof(int32_t)))) return rc;
     if ((rc = d->mt_seg.ensure(np * slots * (size_t)segcap))) return rc;
     if ((rc = d->mt_spath.ensure(np * (size_t)sp_pitch * sizeof(int32_t)))) return rc;
-    if ((rc = d->mt_stat.ensure(4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = d->mt_stat.ensure(4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t)))) return rc;      // counters, then the per-pair frontier
     if ((rc = d->mt_jobs.ensure(jobs.size() * sizeof(int32_t)))) return rc;
-    const int gridMax = std::max(1, std::min(std::max(nTile, n_run), slotsCap));
-    const size_t tbw = ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW;
-    if ((rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)gridMax))) return rc;
     HIP_TRY(hipMemcpyAsync(d->mt_jobs.p, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d->mt_rec.p, 0, np * slots * twl::kMtRec * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(d->mt_spath.p, 0xFE, np * (size_t)sp_pitch * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(d->mt_stat.p, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(d->mt_stat.p, 0, 4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t), st));
     twl::NArgs a{};
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
-    a.cells = base.cells; a.tb = (uint32_t *)d->tb.p; a.queue = base.queue; a.items = d_items; a.n_items = n_run;
-    a.seq_len = base.seq_len; a.tb_words = (int32_t)tbw; a.dbg = nullptr; a.n_pairs_total = base.n_pairs_total;
+    a.cells = base.cells; a.queue = base.queue; a.items = d_items;
+    a.seq_len = base.seq_len; a.dbg = nullptr; a.n_pairs_total = base.n_pairs_total;
     a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char;
     a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
     for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
     a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
     a.mt_chain = (int32_t *)d->mt_chain.p; a.mt_rec = (int32_t *)d->mt_rec.p; a.mt_seg = (int8_t *)d->mt_seg.p; a.mt_spath = (int32_t *)d->mt_spath.p;
     a.mt_stat = (unsigned long long *)d->mt_stat.p;
+    a.mt_front = (int32_t *)((unsigned long long *)d->mt_stat.p + 4);
     a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
-    TRACE("launch mt W=%d RPL=%d pairs=%d scouts=%d tiles=%d slots=%d", W, RPL, n_run, nScout, nTile, slots);
+    const bool thr = nTile > g_mt_thr_jobs;
+    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, thr ? "8x2" : "16x1");
+    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %s, %d, %s, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, thr ? "8, 2" : "16, 1", MM, thr ? "4" : "1");
     if (nScout > 0) {
-        a.mt_jobs = (const int32_t *)d->mt_jobs.p; a.n_items = nScout;
-        HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 2>), dim3(std::min(nScout, slotsCap)), dim3(CfgT::THREADS), 0, st, a);
-        HIP_TRY(hipGetLastError());
+        a.mt_jobs = (const int32_t *)d->mt_jobs.p;
+        rc = thr ? launch_mt_kernel<P, 8, 2, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL(twl::mt_chain_kernel, dim3((n_run + 63) / 64), dim3(64), 0, st, (const int32_t *)d->mt_spath.p, sp_pitch, base.len, d_items, n_run,
-                       (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb);
-    HIP_TRY(hipGetLastError());
-    a.mt_jobs = (const int32_t *)d->mt_jobs.p + 2 * (size_t)nScout; a.n_items = nTile;
-    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 1>), dim3(std::min(nTile, slotsCap)), dim3(CfgT::THREADS), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    a.mt_jobs = nullptr; a.n_items = n_run; a.dbg = base.dbg;
-    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, 3>), dim3(std::min(n_run, slotsCap)), dim3(CfgT::THREADS), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    *grid_out = std::min(nTile, slotsCap);
+    const int rounds = std::max(1, g_mt_rounds);
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(twl::mt_chain_kernel, dim3((n_run + 63) / 64), dim3(64), 0, st, (const int32_t *)d->mt_spath.p, sp_pitch, base.len, d_items, n_run,
+                           (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
+        HIP_TRY(hipGetLastError());
+        a.mt_jobs = (const int32_t *)d->mt_jobs.p + 2 * (size_t)nScout;
+        rc = thr ? launch_mt_kernel<P, 8, 2, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, 16, 1, MM, 1, 1>(d, st, a, nTile, grid_out);
+        if (rc) return rc;
+        a.mt_jobs = nullptr;
+        a.mt_inline = (r == rounds - 1) ? 1 : 0;
+        a.dbg = a.mt_inline ? base.dbg : nullptr;
+        if ((rc = launch_mt_kernel<P, 16, 1, MM, 1, 3>(d, st, a, n_run))) return rc;
+    }
     return TWL_OK;
 }
 
@@ -309,6 +328,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     // d_packed: the level's columns already in the packed [P+2] layout (device-resident level path); no packing pass then
     HIP_TRY(hipSetDevice(d->id));
     d->stats = twl_stats{};
+    d->kname[0] = 0;
     d->pair_cells.assign((size_t)n_pairs, 0);
     if (n_pairs == 0) return TWL_OK;
 
@@ -502,8 +522,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         statSpec = spec ? 1 : 0;
         long long sumLen = 0;
         for (int32_t t = 0; t < n_run; ++t) sumLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
+        // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the
+        // pairs fill the last round of the throughput kernel badly (2 * CUs persistent workgroups: 646 pairs = 1.26 rounds cost 2) --
+        // tiles spread evenly, at the price of the scouts (~1.2x the work)
+        const double roundsThr = (double)n_run / (2.0 * d->num_cu);
         const bool mtOk = lean && mm == 2 && !mm5 && !d->dump_on && n_run <= g_mt_max_pairs && p->marker >= g_mt_min_marker &&
-                          sumLen >= 3ll * p->marker * n_run && !getenv("TWL_NO_MT");
+                          sumLen >= 3ll * p->marker * n_run && (2 * n_run <= d->num_cu || std::ceil(roundsThr) >= 1.2 * roundsThr);
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
             if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_run, &grid, &window);
@@ -511,17 +535,17 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_run, &grid, &window);
         }
+        else if (mtOk) {
+            // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
+            rc = launch_mt<6, 2>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            statSpec = 3; ranMt = true;
+        }
         else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || getenv("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED")) {      // (TWL_SPEC_SHARED_ALL: development knob)
             // CUs/2 < pairs <= CUs: still two workgroups per pair taking the tiles in turn, but of the throughput geometry, two to a CU
             // (all 2n resident at once, as the teams wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one
             // 16-wave workgroup per pair; below CUs/2 pairs the 16-wave teams on a CU each are a little faster (16.4 vs 16.9 ms)
             rc = launch_lean<6, 8, 2, 2, 4, true>(d, st, a, items, n_run, &grid, &window);
             statMode = 2; statSpec = 2;
-        }
-        else if (mtOk) {
-            // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
-            rc = launch_mt<6, 16, 1, 2, 1>(d, st, a, items, order, n_run, h_len, &grid, &window);
-            statSpec = 3; ranMt = true;
         }
         else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_run, &grid, &window);
         else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_run, &grid, &window);
@@ -555,6 +579,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     d->stats.window = window;
     d->stats.matrix_mode = statMode;
     d->stats.speculative = statSpec;
+    memcpy(d->stats.kernel, d->kname, sizeof d->stats.kernel);
 
     // Pairs whose band outgrew a window are re-run, bit-identically, by the next stage: 1024-row fast window ->
     // 2048-row window (16 waves x 2 blocks, LDS ring) -> 4608-row window (covers flen = 4096; columns from L2/HBM).
@@ -664,6 +689,14 @@ int twl_init(const int *device_ids, int n_devices)
     }
     g_devs = devs;
     g_init = true;
+#ifdef TWL_DEV      // development builds (__graft_entry__.build() with TWL_DEV_BUILD=1): the knobs of twl_set_knob from the environment
+    if (const char *v = getenv("TWL_MT_MAX_PAIRS")) g_mt_max_pairs = atoi(v);
+    if (const char *v = getenv("TWL_MT_LEAD")) g_mt_lead = atoi(v);
+    if (const char *v = getenv("TWL_MT_MARGIN")) g_mt_marg = atoi(v);
+    if (const char *v = getenv("TWL_MT_PERTURB")) g_mt_perturb = atoi(v);
+    if (const char *v = getenv("TWL_MT_ROUNDS")) g_mt_rounds = atoi(v);
+    if (const char *v = getenv("TWL_MT_THR_JOBS")) g_mt_thr_jobs = atoi(v);
+#endif
     return TWL_OK;
 }
 
@@ -938,6 +971,8 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_MIN_MARKER: g_mt_min_marker = std::max(2, value); return TWL_OK;
     case TWL_KNOB_MT_LEAD: g_mt_lead = std::max(16, value); return TWL_OK;
     case TWL_KNOB_MT_MARGIN: g_mt_marg = std::max(2, value); return TWL_OK;
+    case TWL_KNOB_MT_ROUNDS: g_mt_rounds = std::max(1, std::min(8, value)); return TWL_OK;
+    case TWL_KNOB_MT_THR_JOBS: g_mt_thr_jobs = std::max(0, value); return TWL_OK;
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }

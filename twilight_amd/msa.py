@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("TWL_HOST_LIB") or os.path.join(_HERE, "libtwl_host.so
 class MsaLevel(C.Structure):
     """twl_msa_level -- one level-kernel call (the reference's per-level report line, progressive.cpp:178-189)."""
     _fields_ = [("pairs", C.c_int32), ("task", C.c_int32), ("band_cells", C.c_uint64), ("relaunched", C.c_uint64),
-                ("kernel_ms", C.c_double), ("level_ms", C.c_double), ("exchange_ms", C.c_double), ("matrix_mode", C.c_int32), ("speculative", C.c_int32)]
+                ("kernel_ms", C.c_double), ("level_ms", C.c_double), ("exchange_ms", C.c_double), ("matrix_mode", C.c_int32), ("speculative", C.c_int32),
+                ("mt_tiles_predicted", C.c_int32), ("mt_tiles_inline", C.c_int32), ("kernel", C.c_char * 160)]
 
 
 class MsaTotals(C.Structure):

@@ -223,7 +223,8 @@ def path_consumes(aln: np.ndarray, n: int) -> tuple[int, int]:
     return int(np.count_nonzero(a != 1)), int(np.count_nonzero(a != 2))
 
 
-def make_family(n_leaves: int, length: int, *, P: int = NUC_P, seed: int = 1, sub: float = 0.015, indel: float = 0.001):
+def make_family(n_leaves: int, length: int, *, P: int = NUC_P, seed: int = 1, sub: float = 0.015, indel: float = 0.001,
+                sub_range: tuple[float, float] | None = None):
     """A synthetic sequence family for end-to-end runs: (newick, [(name, sequence), ...]).
 
     A root sequence is evolved down a random binary tree (Yule-like splits); branch lengths are the per-branch
@@ -244,7 +245,8 @@ def make_family(n_leaves: int, length: int, *, P: int = NUC_P, seed: int = 1, su
         left = int(rng.integers(1, n))
         parts = []
         for k in (left, n - left):
-            b = float(rng.uniform(0.5, 1.5) * sub)
+            # per-branch substitution probability: sub x U(0.5, 1.5), or U(lo, hi) when sub_range is given (0.03-0.10)
+            b = float(rng.uniform(sub_range[0], sub_range[1])) if sub_range else float(rng.uniform(0.5, 1.5) * sub)
             parts.append(f"{grow(_mutate(seq, rng, n_letters, b, indel, bg), k)}:{b:.6f}")
         return "(" + ",".join(parts) + ")"
 
