@@ -72,6 +72,8 @@ typedef struct twl_stats {
 /* Select devices (HIP ordinals).  n_devices==0 or device_ids==NULL -> device 0 only.
    With several devices the pairs of a batch are dealt to them in cost order (no collective). */
 int  twl_init(const int *device_ids, int n_devices);
+/* Releases every device buffer and stream.  Stores of twl_level.h must have been destroyed before: with any of them alive the call
+   is refused (a message on stderr) and the library stays initialised. */
 void twl_shutdown(void);
 const char *twl_last_error(void);
 const char *twl_version(void);
@@ -140,9 +142,17 @@ int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq
      TWL_KNOB_MT_LEAD        anti-diagonals a scout starts ahead of its tile boundary (default 320)
      TWL_KNOB_MT_MARGIN      anti-diagonals a scout runs past its tile boundary (default 40)
      TWL_KNOB_MT_ROUNDS      rounds of predict / run / verify before the remaining tiles are computed in line (default 2)
-     TWL_KNOB_MT_THR_JOBS    levels with more tiles than this run scouts and tiles on the throughput geometry (default 512) */
+     TWL_KNOB_MT_THR_JOBS    levels with more tiles than this run scouts and tiles on the throughput geometry (default 512)
+     TWL_KNOB_FAIL_ROW_ALLOCS  the next n device allocations for the row planes of a store (include/twl_level.h) fail: tests of the
+                             fallback to the minimal pitch
+     TWL_KNOB_PROT_MODE      force a protein kernel variant: 0 auto (default), 1 dense, 2 sparse, 3 precomputed scores, 4 the round-1 kernel,
+                             5 lean sparse, 6 lean precomputed -- every variant computes the same sums (tests hold each to the oracle)
+     TWL_KNOB_ASSUME_ONEHOT_QUERY  1: the caller promises that every query row of twl_align_batch has at most one non-zero letter
+                             (single sequences), which selects the four-product column score; the device-resident level path
+                             (twl_level.h) knows this by itself */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
-                TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7 };
+                TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10 };
 int twl_set_knob(int key, int value);
 
 #ifdef __cplusplus

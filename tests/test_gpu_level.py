@@ -284,3 +284,29 @@ def test_geometry_follows_the_pairs_that_run(gpu):
         else:
             assert n_m[i] == 0 and err_m[i] == 0, f"masked-out pair {i}"
     st.close()
+
+
+def test_row_planes_fall_back_to_the_minimal_pitch_together(gpu):
+    """grow_rows: when an allocation at the generous pitch fails, BOTH planes are retried at the pitch that is needed (one pitch for
+    both planes); a failure there too is reported, not half applied.  The write-back that follows re-pitches again and must still be
+    right."""
+    import twilight_amd as twl
+    from twilight_amd import api, level as L
+
+    cases = [LC.make_case("n", seed, cached=0, length=90 + 17 * seed) for seed in range(5)]
+    seqs, pairs, ids = _level(cases)
+    p = twl.make_params(LC.matrix_of("n"))
+    twl.set_knob(api.KNOB_FAIL_ROW_ALLOCS, 2)       # generous pitch fails, and so does the retry
+    with pytest.raises(Exception):
+        L.Store(seqs, "n")
+    twl.set_knob(api.KNOB_FAIL_ROW_ALLOCS, 1)       # generous pitch fails on the first plane: both planes at the minimal pitch
+    st = L.Store(seqs, "n")
+    twl.set_knob(api.KNOB_FAIL_ROW_ALLOCS, 0)
+    st.prepare(p, pairs, gappy_threshold=0.95)
+    exps = [LC.expected(c) for c in cases]
+    st.commit([e["path_full"] for e in exps])       # longer rows than the minimal pitch holds: grows again
+    rows = st.rows()
+    for i, e in enumerate(exps):
+        for sid, want in zip(ids[i][0] + ids[i][1], e["rows_after"]):
+            assert rows[sid] == want, f"pair {i}: row {sid} after write-back"
+    st.close()

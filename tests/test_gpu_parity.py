@@ -3,11 +3,19 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from twilight_amd import synth
+from twilight_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
 M = synth.nucleotide_matrix()
+
+
+@pytest.fixture(autouse=True)
+def _reset_knobs(gpu):
+    """Tests that force a kernel variant (twl_set_knob) leave the defaults behind them."""
+    yield
+    gpu.set_knob(api.KNOB_PROT_MODE, 0)
+    gpu.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 0)
 
 
 def _compare(twl, batch, matrix=None, **pk):
@@ -207,7 +215,7 @@ def test_config2_rnasim_leaf_level_band512(gpu):
 def test_protein_score_modes_match_oracle(gpu, mode, monkeypatch):
     """The three protein column-score paths (dense loop, loop over non-zero reference letters, scores precomputed by
     score_matrix_kernel) are the same arithmetic in the same order: each must reproduce the oracle bit for bit."""
-    monkeypatch.setenv("TWL_PROT_CFG", mode)
+    gpu.set_knob(api.KNOB_PROT_MODE, api.PROT_MODES[mode])
     PM = synth.protein_matrix()
     for seed, members, length in ((3, (1, 1), 500), (4, ((2, 9), (1, 6)), 700), (5, ((20, 40), (20, 40)), 300)):
         batch = synth.make_level_batch(6, length, members=members, seed=seed, P=22, sub=0.25)
@@ -293,7 +301,7 @@ def test_scores_inside_the_dp_kernel_match_oracle(gpu, kind, monkeypatch):
         # single-sequence query sides (profiles on the reference side): the device-resident level path tells the kernels, which then take
         # the one-letter form of the column score (matrix mode 5); through this entry the test has to say so itself
         members = ((2, 7), 1)
-        monkeypatch.setenv("TWL_ASSUME_ONEHOT_QUERY", "1")
+        gpu.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 1)
     b = synth.make_level_batch(2, 700, members=members, seed=37, P=P, sub=0.1, gap_col_rate=0.1)
     for gap_char in (None, 0.0):
         pk = dict(marker=128)          # several tiles: the tile offsets of the dump are exercised too
@@ -352,7 +360,7 @@ def _blosum(which):
 def test_blosum80_asymmetric_entry_is_indexed_like_the_reference(gpu, mode, monkeypatch):
     """5 x BLOSUM80 as the reference ships it has [I][V] = 15 but [V][I] = 5 (blosum.hpp:65,75).  Profiles rich in I and V make the
     entry count; a kernel that indexed M[m][l] would score these pairs differently from the oracle (which follows the x86 order)."""
-    monkeypatch.setenv("TWL_PROT_CFG", mode)
+    gpu.set_knob(api.KNOB_PROT_MODE, api.PROT_MODES[mode])
     m80 = _blosum("80")
     assert m80[7, 17] == 15 and m80[17, 7] == 5
     batch = synth.make_level_batch(6, 500, members=((1, 4), (1, 4)), seed=80, P=22, sub=0.3)

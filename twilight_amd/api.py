@@ -138,7 +138,9 @@ def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex
                                       vp(d_err)))
 
 
-KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN, KNOB_MT_ROUNDS, KNOB_MT_THR_JOBS = 1, 2, 3, 4, 5, 6, 7
+KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN, KNOB_MT_ROUNDS, KNOB_MT_THR_JOBS, KNOB_FAIL_ROW_ALLOCS = 1, 2, 3, 4, 5, 6, 7, 8
+KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY = 9, 10
+PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 
 
 def set_knob(key: int, value: int):

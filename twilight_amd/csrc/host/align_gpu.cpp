@@ -21,7 +21,6 @@ namespace msa {
 namespace progressive {
 namespace gpu {
 
-LevelTotals g_totals;
 static std::vector<int> g_devices;
 
 // Page-locked when the library can give it (copies at link speed), else plain memory.  Pinned blocks are not returned at process exit:
@@ -87,6 +86,7 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
         return;
     }
     static RunCtx::Raw sendStage, recvStage;      // (one run aligns at a time per process)
+    constexpr uint64_t kBlockMagic = 0x54574C50ull << 32;      // "TWLP"
     const double t0 = nowMs();
     const int n = (int)owner.size();
     std::vector<std::vector<int>> mine(sh.world);
@@ -108,7 +108,7 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
     const size_t blockBytes = (size_t)*std::max_element(sizes.begin(), sizes.end());
     char *send = sendStage.get(blockBytes), *recv = recvStage.get(blockBytes * (size_t)sh.world);
     {
-        uint64_t h[4] = {rec.band_cells, rec.relaunched, 0, 0};
+        uint64_t h[4] = {rec.band_cells, rec.relaunched, 0, kBlockMagic | (uint64_t)(uint32_t)ctx.levels.size()};      // (magic, level number)
         memcpy(&h[2], &rec.kernel_ms, sizeof(double));
         memcpy(send, h, sizeof h);
         size_t at = head;
@@ -126,6 +126,8 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
     for (int r = 0; r < sh.world; ++r) {
         const char *blk = &recv[blockBytes * (size_t)r];
         uint64_t h[4]; memcpy(h, blk, sizeof h);
+        // the receive staging is never zero-filled: a block that is not this level's (a collective that failed without saying so) must not parse
+        if (h[3] != (kBlockMagic | (uint64_t)(uint32_t)ctx.levels.size())) { std::cerr << "ERROR: path block of rank " << r << " does not belong to this level.\n"; exit(1); }
         double km; memcpy(&km, &h[2], sizeof(double));
         rec.band_cells += h[0]; rec.relaunched += h[1]; kmax = std::max(kmax, km);      // the ranks ran concurrently
         size_t at = head;
@@ -224,11 +226,11 @@ static void runBatch(RunCtx &ctx, LevelRecord &rec, const twl_params &tp, const 
     const size_t sl = (size_t)stride;
     int8_t *aln = g_stage.aln + (size_t)first * 2 * sl;
     const double tCall = nowMs();
-    g_totals.stage_ms += tCall - tStage;
+    ctx.totals.stage_ms += tCall - tStage;
     int rc = twl_align_batch(&tp, n, stride, g_stage.freq + (size_t)first * 2 * sl * P, g_stage.gop + (size_t)first * 2 * sl,
                              g_stage.gex + (size_t)first * 2 * sl, len.data(), num.data(), aln, alnLen.data(), err.data());
     if (rc != TWL_OK) { std::cerr << "ERROR: twl_align_batch failed (" << rc << "): " << twl_last_error() << '\n'; exit(1); }
-    g_totals.call_ms += nowMs() - tCall;
+    ctx.totals.call_ms += nowMs() - tCall;
     double kms = 0, tms = 0;
     for (int dev : g_devices) {      // the devices of one call run concurrently: cells add up, times do not
         twl_stats st{};
@@ -237,7 +239,7 @@ static void runBatch(RunCtx &ctx, LevelRecord &rec, const twl_params &tp, const 
             rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; }
     }
     rec.kernel_ms += kms;
-    g_totals.total_ms += tms; ctx.totals.total_ms += tms;
+    ctx.totals.total_ms += tms;
     for (int id : ids) {
         const int t = id - first;
         errs[id] = err[t];
@@ -257,7 +259,7 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
     const int P = param.matrixSize + 1;
     std::vector<PairInputs> in(n);
     const double tPrep = nowMs();
-    const LevelTotals before = g_totals;
+    const LevelTotals before = ctx.totals;
     // wide levels: one pair per thread; narrow levels (upper tree): pairs in turn, the helpers' own column/sequence loops fan out
     const bool acrossPairs = n >= omp_get_max_threads();
     int stride = 1;
@@ -269,7 +271,7 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
         preparePair(nodes[i], database, option, param, in[i], g_stage.freq + (size_t)i * 2 * sl * P, g_stage.gop + (size_t)i * 2 * sl,
                     g_stage.gex + (size_t)i * 2 * sl, stride);
 
-    g_totals.prepare_ms += nowMs() - tPrep;
+    ctx.totals.prepare_ms += nowMs() - tPrep;
 
     std::vector<alnPath> paths(n);
     std::vector<int16_t> errs(n, 0);
@@ -329,17 +331,16 @@ void alignmentKernel_GPU(Tree *, NodePairVec &nodes, SequenceDB *database, Optio
         finishPair(nodes[i], database, option, param, in[i], paths[i]);
         in[i] = PairInputs();                                                                   // release the profile buffers early
     }
-    g_totals.finish_ms += nowMs() - tFin;
+    ctx.totals.finish_ms += nowMs() - tFin;
     for (int i = 0; i < n; ++i)
         if (deferred[i]) fallbackPairs.push_back(i);
     if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
     rec.level_ms = nowMs() - tPrep;
-    g_totals.pairs += (uint64_t)n; g_totals.band_cells += rec.band_cells; g_totals.relaunched += rec.relaunched; g_totals.kernel_ms += rec.kernel_ms; g_totals.exchange_ms += rec.exchange_ms;
     ctx.totals.pairs += (uint64_t)n; ctx.totals.band_cells += rec.band_cells; ctx.totals.relaunched += rec.relaunched; ctx.totals.kernel_ms += rec.kernel_ms; ctx.totals.exchange_ms += rec.exchange_ms;
     ctx.levels.push_back(rec);
     if (option->printDetail)
-        std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " stage " << g_totals.stage_ms - before.stage_ms << " call "
-                  << g_totals.call_ms - before.call_ms << " (kernel " << g_totals.kernel_ms - before.kernel_ms << ") finish " << g_totals.finish_ms - before.finish_ms
+        std::cerr << "  phases (ms): prepare " << ctx.totals.prepare_ms - before.prepare_ms << " stage " << ctx.totals.stage_ms - before.stage_ms << " call "
+                  << ctx.totals.call_ms - before.call_ms << " (kernel " << ctx.totals.kernel_ms - before.kernel_ms << ") finish " << ctx.totals.finish_ms - before.finish_ms
                   << " whole " << nowMs() - tPrep << '\n';
 }
 

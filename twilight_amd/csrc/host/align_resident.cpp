@@ -207,7 +207,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (ctx.shard.world > 1 && g_stores.size() > 1) { std::cerr << "ERROR: several processes with several device replicas each are not supported.\n"; exit(1); }
     LevelRecord rec;
     rec.pairs = (int32_t)nodes.size();
-    const LevelTotals before = g_totals;
+    const LevelTotals before = ctx.totals;
     const double tPrep = nowMs();
     const int n = (int)nodes.size();
     static const char bases[] = {'A', 'C', 'G', 'T', 'N'};
@@ -301,7 +301,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             runsAndConsensus(&info[((size_t)2 * t + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
         }
     }
-    g_totals.prepare_ms += nowMs() - tPrep;
+    ctx.totals.prepare_ms += nowMs() - tPrep;
 
     // ---- DP with the reference's grouping and retry/defer policy (alignment-cpu.cpp:88-130) ----
     std::vector<alnPath> paths(n);
@@ -330,7 +330,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
     // One device, one process, and few pairs lost columns: the paths of all the others never leave HBM (addGappyColumnsBack is the
     // identity for them): the DP output is committed in place, only the pairs that need editing are fetched.
-    const bool inPlace = (nd == 1 && !procs && !ctx.shard.exchange && needInfo.size() * 4 <= (size_t)n && !getenv("TWL_NO_INPLACE_COMMIT"));
+    const bool inPlace = (nd == 1 && !procs && !ctx.shard.exchange && needInfo.size() * 4 <= (size_t)n);
     std::vector<char> needsHost(n, 0);
     for (int i : needInfo) needsHost[i] = 1;
     std::vector<uint8_t> fromDp(n, 0);
@@ -372,7 +372,8 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         return (int)TWL_OK;
     });
     (void)nPlain; (void)nZero;
-    if (const char *dump = getenv("TWL_DUMP_SCHEDULE")) {      // development: one line per pair for tools/sim_schedule.py
+#ifdef TWL_DEV      // development builds: one line per pair for tools/sim_schedule.py
+    if (const char *dump = getenv("TWL_DUMP_SCHEDULE")) {
         if (FILE *f = fopen(dump, "a")) {
             std::vector<uint64_t> pc(n, 0);
             if (nd == 1) (void)twl_get_pair_cells(g_storeDev[0], pc.data(), n);
@@ -382,8 +383,9 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             fclose(f);
         }
     }
-    g_totals.call_ms += *std::max_element(callMs.begin(), callMs.end());           // the replicas run concurrently
-    g_totals.total_ms += *std::max_element(totMs.begin(), totMs.end());
+#endif
+    ctx.totals.call_ms += *std::max_element(callMs.begin(), callMs.end());           // the replicas run concurrently
+    ctx.totals.total_ms += *std::max_element(totMs.begin(), totMs.end());
     rec.kernel_ms = *std::max_element(kernMs.begin(), kernMs.end());
     for (uint64_t c : cellsOf) rec.band_cells += c;
     for (uint64_t c : redoOf) rec.relaunched += c;
@@ -404,7 +406,8 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     int8_t *finalPaths = reinterpret_cast<int8_t *>(g_finalStage.get((size_t)n * pathStride));
     std::vector<int32_t> finalLen(n, 0);
     std::vector<char> deferred(n, 0);
-#pragma omp parallel for schedule(dynamic, 1)
+    // (few pairs -- the top of the tree, paths of 10^5 columns: one pair at a time, addGappyColumnsBack spreads its runs over the threads itself)
+#pragma omp parallel for schedule(dynamic, 1) if (n >= 8)
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
         deferred[i] = ((s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144
@@ -441,22 +444,21 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         a->seqsIncluded.insert(a->seqsIncluded.end(), b->seqsIncluded.begin(), b->seqsIncluded.end());
         b->seqsIncluded.clear();
     }
-    g_totals.finish_ms += nowMs() - tFin;
+    ctx.totals.finish_ms += nowMs() - tFin;
     double devPrep = 0, devCommit = 0;
     twl_level_timing(g_store, &devPrep, &devCommit);
-    g_totals.dev_prepare_ms += devPrep;
-    g_totals.dev_commit_ms += devCommit;
+    ctx.totals.dev_prepare_ms += devPrep;
+    ctx.totals.dev_commit_ms += devCommit;
     for (int i = 0; i < n; ++i)
         if (deferred[i]) fallbackPairs.push_back(i);
     if (!fallbackPairs.empty()) alignment_helper::fallback2cpu(fallbackPairs, nodes, database, option);
     rec.level_ms = nowMs() - tPrep;
-    g_totals.pairs += (uint64_t)n; g_totals.band_cells += rec.band_cells; g_totals.relaunched += rec.relaunched; g_totals.kernel_ms += rec.kernel_ms; g_totals.exchange_ms += rec.exchange_ms;
     ctx.totals.pairs += (uint64_t)n; ctx.totals.band_cells += rec.band_cells; ctx.totals.relaunched += rec.relaunched; ctx.totals.kernel_ms += rec.kernel_ms; ctx.totals.exchange_ms += rec.exchange_ms;
     ctx.levels.push_back(rec);
     if (option->printDetail)
-        std::cerr << "  phases (ms): prepare " << g_totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << g_totals.call_ms - before.call_ms
-                  << " (kernel " << rec.kernel_ms << ", exchange " << rec.exchange_ms << ") finish " << g_totals.finish_ms - before.finish_ms << " (device " << devCommit
-                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << g_totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << "; gappy columns back " << tGappy << " ms\n";
+        std::cerr << "  phases (ms): prepare " << ctx.totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << ctx.totals.call_ms - before.call_ms
+                  << " (kernel " << rec.kernel_ms << ", exchange " << rec.exchange_ms << ") finish " << ctx.totals.finish_ms - before.finish_ms << " (device " << devCommit
+                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << ctx.totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << "; gappy columns back " << tGappy << " ms\n";
 }
 
 }  // namespace gpu

@@ -83,7 +83,7 @@ bool parseCommandLine(int argc, char **argv, Option &o)
     return true;
 }
 
-int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput)
+int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput, const std::function<void(SequenceDB *)> &atEnd)
 {
     auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = clk();
@@ -102,6 +102,7 @@ int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferred
     if (writeOutput) io::writeFinalMSA(&database, &option, alnLen);        // :165
     if (option.printDetail)
         std::cerr << "Driver phases (s): tree " << t1 - t0 << ", read " << t2 - t1 << ", align " << t3 - t2 << ", write " << clk() - t3 << '\n';
+    if (atEnd) atEnd(&database);
     delete subT;
     delete T;
     return alnLen;

@@ -18,9 +18,9 @@ int main(int argc, char **argv)
     // both passes run on the GPU level kernel (the reference hard-wires its CPU kernel for the deferred pass)
     msa::alnFunction kernel = msa::progressive::gpu::alignmentKernel_Resident;
     if (option.hostStaged) kernel = msa::progressive::gpu::alignmentKernel_GPU;
-    const int alnLen = msa::runDefaultAlignment(option, kernel, kernel);
+    msa::progressive::gpu::LevelTotals g;      // the run's totals (they live with the run's SequenceDB)
+    const int alnLen = msa::runDefaultAlignment(option, kernel, kernel, true, [&](msa::SequenceDB *db) { g = msa::progressive::gpu::runTotals(db); });
     const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-    const auto &g = msa::progressive::gpu::g_totals;
     std::cerr << "Wrote " << option.outFile << " (length " << alnLen << ") in " << secs << " s; level kernel: " << g.pairs << " pairs, " << g.band_cells
               << " band cells, " << g.relaunched << " pairs re-run in a wider window, " << g.kernel_ms << " ms DP kernel, " << g.total_ms << " ms incl. transfers\n";
     if (option.printDetail)

@@ -250,7 +250,6 @@ void beginInit(Option *option);   // optional: start device initialisation early
 // for the deferred pass (currentTask != 0), after bringing the rows back.
 void alignmentKernel_Resident(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
 struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0, exchange_ms = 0; };
-extern LevelTotals g_totals;      // summed over every level-kernel call of the process (for the run summary)
 // One level-kernel call, as the reference's per-level report line (progressive.cpp:178-189) plus what the DP did in it.
 struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relaunched = 0; double kernel_ms = 0, level_ms = 0, exchange_ms = 0; int32_t matrix_mode = -1, speculative = 0;
                      int32_t mt_predicted = 0, mt_inline = 0; char kernel[160] = {0}; };
@@ -276,7 +275,9 @@ void downloadRows(SequenceDB *database, Tree *T);
 
 // DEFAULT_ALN driver shared by the product CLI and the oracle's end-to-end checker (twilight-main.cpp:121-176,
 // single partition): tree -> partition -> reroot -> read sequences -> msaOnSubtree -> write MSA.  Returns the MSA length.
-int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput = true);
+// atEnd (optional) sees the run's SequenceDB after the output was written and before it is destroyed (the CLI reads the run's totals there)
+int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput = true,
+                        const std::function<void(SequenceDB *)> &atEnd = nullptr);
 bool parseCommandLine(int argc, char **argv, Option &option);
 
 }  // namespace msa

@@ -150,7 +150,9 @@ __device__ __forceinline__ unsigned long long team_word(unsigned tag, unsigned f
 }
 __device__ __forceinline__ unsigned long long team_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void team_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// one lane waits (bounded: ~2 s) until the word carries the tag; 0 = gave up (the caller turns that into errorType 3)
+// one lane waits (bounded: ~2 s) until the word carries the tag; 0 = gave up: the partner is not co-resident or far too slow (a GPU
+// shared with another process, a profiler serialising the workgroups).  That is a scheduling condition, not an alignment error: the
+// caller reports the internal re-run code (kErrOverflow), the host re-runs the pair on the plain kernel of the next stage
 __device__ __forceinline__ unsigned long long team_wait(const unsigned long long *p, unsigned tag, const unsigned long long *alt = nullptr)
 {
     for (int spin = 0; spin < (1 << 21); ++spin) {
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         // SPEC: this workgroup runs the tiles of its parity; `confirmed` = the start of the tile in flight is the true one
         unsigned long long *team = SPEC ? a.team + (size_t)item * kTeamWords : nullptr;
         const int role = SPEC ? (int)(blockIdx.x & 1) : 0;
-        bool confirmed = true, teamExit = false, redo = false, iEnded = false;
+        bool confirmed = true, teamExit = false, redo = false, iEnded = false, timedOut = false;
         if constexpr (SPEC) tile = role;
         // broadcast of a 64-bit word from thread 0 to the workgroup
         auto bcast = [&](unsigned long long v) __attribute__((always_inline)) -> unsigned long long {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             unsigned long long v = 0ull;
             if (threadIdx.x == 0) v = team_wait(&team[kTeamTruth + (tile & 3)], (unsigned)(tile + 1));
             v = bcast(v);
-            if (v == 0ull) { err = 3; return 2; }
+            if (v == 0ull) { err = kErrOverflow; timedOut = true; return 2; }
             const unsigned fl = (unsigned)(v >> 32) & 0xFFFFu;
             if (fl & (kTeamLast | kTeamErr)) return 2;
             const int tr = (int)((v >> 16) & 0xFFFFu), tq = (int)(v & 0xFFFFu);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if (threadIdx.x == 0) v = team_wait(&team[kTeamTruth + (tile & 3)], (unsigned)(tile + 1), &team[kTeamGuess + (tile & 3)]);
                     v = bcast(v);
                     const unsigned fl = (unsigned)(v >> 32) & 0x7FFFu;
-                    if (v == 0ull) { err = 3; teamExit = true; }
+                    if (v == 0ull) { err = kErrOverflow; timedOut = true; teamExit = true; }
                     else if (!(v & (1ull << 47)) && (fl & (kTeamLast | kTeamErr))) teamExit = true;
                     else { ref_idx = (int)((v >> 16) & 0xFFFFu); qry_idx = (int)(v & 0xFFFFu); confirmed = !(v & (1ull << 47)); }
                 }
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         unsigned long long pv = 0ull;
                         if (lane == 0) pv = team_wait(&team[kTeamPos + (tile & 3)], (unsigned)(tile + 1));
                         pos = __builtin_amdgcn_readfirstlane((int)(pv & 0xFFFFFFFFu));
-                        if (__builtin_amdgcn_readfirstlane((int)(pv >> 32)) == 0) err = 3;
+                        if (__builtin_amdgcn_readfirstlane((int)(pv >> 32)) == 0) { err = kErrOverflow; timedOut = true; }
                     }
                 }
                 int n = 0;
@@ -1227,7 +1229,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             }      // (tile started)
         }
         if constexpr (SPEC) {
-            if (err != 0 && !teamExit) {       // this workgroup fails the pair: tell the partner (it may be waiting for a start)
+            if (err != 0 && (!teamExit || timedOut)) {       // this workgroup fails the pair: tell the partner (it may be waiting for a start)
                 iEnded = true;
                 if (threadIdx.x == 0) {
                     team_store(&team[kTeamTruth + ((tile + 1) & 3)], team_word((unsigned)(tile + 2), kTeamErr, 0u, 0u));

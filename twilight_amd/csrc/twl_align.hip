@@ -30,6 +30,13 @@ thread_local std::string g_err;
 std::mutex g_mu;
 
 static bool dbg_on() { static const bool v = getenv("TWL_DEBUG") != nullptr; return v; }
+// Development knobs of the launch policy exist in TWL_DEV builds only (__graft_entry__.build() with TWL_DEV_BUILD=1); what tests
+// need goes through twl_set_knob.
+#ifdef TWL_DEV
+static const char *dev_env(const char *name) { return getenv(name); }
+#else
+static const char *dev_env(const char *) { return nullptr; }
+#endif
 #define TRACE(...) do { if (dbg_on()) { fprintf(stderr, "[twl trace] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 #define HIP_TRY(expr)                                                                                          \
@@ -74,6 +81,7 @@ struct Device {
     bool dump_on = false;
     std::vector<int32_t> dbg_host;
     std::vector<int32_t> mt_jobs_host;
+    int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
     char kname[160] = {0};                                                       // the kernel of the first DP launch of the call in flight
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
@@ -119,7 +127,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
             cached.store(std::max(1, nb));
         }
         blocks_per_cu = cached.load();
-        if (const char *cap = getenv("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));   // development knob
+        if (const char *cap = dev_env("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));
     }
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
@@ -172,7 +180,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
         cached.store(std::max(1, nb));
     }
     int blocks_per_cu = cached.load();
-    if (const char *cap = getenv("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));   // development knob
+    if (const char *cap = dev_env("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * blocks_per_cu);
     if (grid < 1) grid = 1;
@@ -203,7 +211,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     a.simdump = DUMP ? (float *)d->simdump.p : nullptr;
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
-    if (SPEC && (dbg_on() || getenv("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
+    if (SPEC && (dbg_on() || dev_env("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
         std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
         HIP_TRY(hipMemcpyAsync(tw.data(), d->team.p, tw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -244,6 +252,8 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 512;
+int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
+int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 
 template <int P, int MM>
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
@@ -404,8 +414,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
     bool ranMt = false;
-    const bool force_wide = getenv("TWL_FORCE_WIDE") != nullptr;
-    const char *cfg = getenv("TWL_FAST_CFG");      // development knob: pick the fast-path geometry (nucleotide only)
+    const bool force_wide = dev_env("TWL_FORCE_WIDE") != nullptr;
+    const char *cfg = dev_env("TWL_FAST_CFG");      // pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
     const int32_t *items = (const int32_t *)d->items.p;
     auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
@@ -416,8 +426,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else if (force_wide) rc = launch_wide(items, n_run, &grid, &window);
     else if (prot) {
         // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
-        const char *pc = getenv("TWL_PROT_CFG");      // development knob
-        const std::string pcs = pc ? pc : "auto";          // auto | dense | sparse | presim | r1 (round-1 kernels) | lean_sparse | lean_presim
+        // TWL_KNOB_PROT_MODE: auto | dense | sparse | presim | r1 (round-1 kernels) | lean_sparse | lean_presim
+        static const char *const kProtModes[] = {"auto", "dense", "sparse", "presim", "r1", "lean_sparse", "lean_presim"};
+        const std::string pcs = kProtModes[std::max(0, std::min(6, g_prot_mode))];
         // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]
         bool divOk = true;
         auto inRange = [](float x) { const float ax = std::fabs(x); return x == 0.0f || (ax >= 0.0009765625f && ax <= 1024.0f); };
@@ -453,8 +464,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
             // CUs/2 < pairs <= CUs: speculative teams of the 512-row geometry, two workgroups per CU, on precomputed scores (as the nucleotide
             // path does with its throughput geometry)
-            const bool sharedSpec = lean && pcs == "auto" && (!few || getenv("TWL_SPEC_SHARED_ALL")) && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on &&
-                                    !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED");
+            const bool sharedSpec = lean && pcs == "auto" && (!few || dev_env("TWL_SPEC_SHARED_ALL")) && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on &&
+                                    !dev_env("TWL_NO_SPEC") && !dev_env("TWL_NO_SPEC_SHARED");
             const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few) || sharedSpec) && fits && !d->dump_on;
             statMode = presim ? 4 : 3;
             if (presim) {
@@ -472,15 +483,15 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
-                statSpec = sharedSpec ? 2 : ((lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) ? 1 : 0);
+                statSpec = sharedSpec ? 2 : ((lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !dev_env("TWL_NO_SPEC")) ? 1 : 0);
                 if (sharedSpec) { rc = launch_lean<22, 8, 1, 4, 4, true>(d, st, a, items, n_run, &grid, &window); protSmall = true; }
-                else if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !getenv("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
+                else if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !dev_env("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_run, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_run, 0, &grid, &window);
             } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
                 if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
                 rc = launch_lean<22, 16, 1, 3, 1, false, true>(d, st, a, items, n_run, &grid, &window);
-            } else if (lean && n_run > d->num_cu && !getenv("TWL_PROT_NO_SMALL")) {
+            } else if (lean && n_run > d->num_cu && !dev_env("TWL_PROT_NO_SMALL")) {
                 // more pairs than CUs: the 512-row window (8 waves, one block each; protein bands of 2 kaa pairs are ~270 rows wide, ~400
                 // at most) keeps the ring at 61 KB, so two workgroups share a CU like in the nucleotide throughput kernel; a pair
                 // whose band outgrows it goes to the 1024-row kernel below
@@ -500,7 +511,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         for (int t = 0; t < 5; ++t) nz = nz && M[20 + t] == 0.0f && M[5 * t + 4] == 0.0f;
         for (int l = 0; l < 4; ++l)
             for (int m = 0; m < 4; ++m) st3 = st3 && M[5 * l + m] == ((l == m) ? M[0] : (((l ^ m) == 2) ? M[2] : M[1]));
-        const char *mmEnv = getenv("TWL_MATRIX_MODE");
+        const char *mmEnv = dev_env("TWL_MATRIX_MODE");
         int mm = nz ? (st3 ? 2 : 1) : 0;
         if (mmEnv) mm = std::min(mm, atoi(mmEnv));          // development knob: force a more general mode
         // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]; anything else takes the IEEE-division kernel
@@ -510,14 +521,14 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         divOk = divOk && inRange(p->gap_char);
         const bool lean = (c != "w8r2") && divOk;
         // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
-        const bool few = (c == "nuc16") || (c == "nuc" && n_run <= d->num_cu && !getenv("TWL_NO_FEW"));
+        const bool few = (c == "nuc16") || (c == "nuc" && n_run <= d->num_cu && !dev_env("TWL_NO_FEW"));
         // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
         int32_t maxLen = 0;
         for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLen = std::max(maxLen, h_len[t]);
         // (the mailbox words of the speculative start carry absolute positions in 16 bits each)
         // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
-        const bool mm5 = lean && mm >= 1 && (qry_onehot || getenv("TWL_ASSUME_ONEHOT_QUERY") != nullptr) && !getenv("TWL_NO_ONEHOT");
-        const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_run <= d->num_cu && maxLen <= 65535 && !getenv("TWL_NO_SPEC");
+        const bool mm5 = lean && mm >= 1 && (qry_onehot || g_assume_onehot_query) && !dev_env("TWL_NO_ONEHOT");
+        const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_run <= d->num_cu && maxLen <= 65535 && !dev_env("TWL_NO_SPEC");
         statMode = mm5 ? 5 : mm;
         statSpec = spec ? 1 : 0;
         long long sumLen = 0;
@@ -540,7 +551,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             rc = launch_mt<6, 2>(d, st, a, items, order, n_run, h_len, &grid, &window);
             statSpec = 3; ranMt = true;
         }
-        else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || getenv("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !getenv("TWL_NO_SPEC") && !getenv("TWL_NO_SPEC_SHARED")) {      // (TWL_SPEC_SHARED_ALL: development knob)
+        else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || dev_env("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !dev_env("TWL_NO_SPEC") && !dev_env("TWL_NO_SPEC_SHARED")) {
             // CUs/2 < pairs <= CUs: still two workgroups per pair taking the tiles in turn, but of the throughput geometry, two to a CU
             // (all 2n resident at once, as the teams wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one
             // 16-wave workgroup per pair; below CUs/2 pairs the 16-wave teams on a CU each are a little faster (16.4 vs 16.9 ms)
@@ -564,13 +575,6 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_run, 0, &grid, &window);
         else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_run, 0, &grid, &window);
     }
-    else if (c == "w8r2m6") rc = launch_dp<6, 8, 2, false, true, true, 6>(d, st, a, items, n_run, 0, &grid, &window);
-    else if (c == "w8r2m5") rc = launch_dp<6, 8, 2, false, true, true, 5>(d, st, a, items, n_run, 0, &grid, &window);
-    else if (c == "w16") rc = launch_dp<6, 16, 1, true, true>(d, st, a, items, n_run, 0, &grid, &window);
-    else if (c == "w16m2") rc = launch_dp<6, 16, 1, false, true, true, 1, 2>(d, st, a, items, n_run, 0, &grid, &window);
-    else if (c == "w16prem1") rc = launch_dp<6, 16, 1, true, true, true, 1, 1>(d, st, a, items, n_run, 0, &grid, &window);
-    else if (c == "w8") rc = launch_dp<6, 8, 1, true, true>(d, st, a, items, n_run, 0, &grid, &window);
-    else if (c == "w4r4") rc = launch_dp<6, 4, 4, false, true>(d, st, a, items, n_run, 0, &grid, &window);
     else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(d->ev[2], st));
@@ -650,6 +654,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 }  // namespace
 
 static void twl_level_pool_release(Device *d);      // twl_level.inc.hip: the level buffers the device lent to its stores
+namespace { extern int g_fail_next_row_allocs; }
 
 extern "C" {
 
@@ -703,6 +708,14 @@ int twl_init(const int *device_ids, int n_devices)
 void twl_shutdown(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    // stores (twl_level.h) point into their device's state and pool: with any of them alive the library stays up (destroy them first)
+    for (auto *d : g_devs) {
+        std::lock_guard<std::mutex> dl(d->mu);
+        if (d->live_stores > 0) {
+            fprintf(stderr, "twl_shutdown: %d store(s) still alive on device %d; the library stays initialised (twl_store_destroy them first)\n", d->live_stores, d->id);
+            return;
+        }
+    }
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
@@ -973,6 +986,9 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_MARGIN: g_mt_marg = std::max(2, value); return TWL_OK;
     case TWL_KNOB_MT_ROUNDS: g_mt_rounds = std::max(1, std::min(8, value)); return TWL_OK;
     case TWL_KNOB_MT_THR_JOBS: g_mt_thr_jobs = std::max(0, value); return TWL_OK;
+    case TWL_KNOB_FAIL_ROW_ALLOCS: g_fail_next_row_allocs = std::max(0, value); return TWL_OK;
+    case TWL_KNOB_PROT_MODE: if (value < 0 || value > 6) { g_err = "protein mode 0..6"; return TWL_ERR_BAD_ARGUMENT; } g_prot_mode = value; return TWL_OK;
+    case TWL_KNOB_ASSUME_ONEHOT_QUERY: g_assume_onehot_query = value ? 1 : 0; return TWL_OK;
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }

@@ -123,28 +123,49 @@ int64_t rows_budget_cap(twl_store *s)
     return std::max<int64_t>(256, budget / (2 * std::max<int64_t>(1, s->n_seqs)));
 }
 
+int g_fail_next_row_allocs = 0;      // twl_set_knob(TWL_KNOB_FAIL_ROW_ALLOCS, n): the next n allocations of grow_rows fail (test of its fallback)
+
 int grow_rows(twl_store *s, int64_t need, int64_t want = 0)
 {
     if (need <= s->cap) return TWL_OK;
     Device *d = s->d;
+    const int64_t minCap = (need + 255) & ~(int64_t)255;
     int64_t ncap = std::max(need, std::min(std::max(want, need + need / 2), rows_budget_cap(s)));
     ncap = (ncap + 255) & ~(int64_t)255;
-    for (int pl = 0; pl < 2; ++pl) {
-        Buf nb;
-        int rc = nb.ensure((size_t)s->n_seqs * (size_t)ncap);
-        if (rc && ncap > ((need + 255) & ~(int64_t)255)) {      // not that much room: take what is needed
-            ncap = (need + 255) & ~(int64_t)255;
-            rc = nb.ensure((size_t)s->n_seqs * (size_t)ncap);
+    // Both planes must end up with ONE pitch: both new buffers are allocated before either plane is touched; if either allocation
+    // fails at the generous pitch, both are given back and both are retried at the pitch that is needed.
+    Buf nb[2];
+    auto alloc_both = [&](int64_t cap) {
+        for (int pl = 0; pl < 2; ++pl) {
+            int rc = TWL_ERR_HIP;
+            if (g_fail_next_row_allocs > 0) { --g_fail_next_row_allocs; g_err = "row allocation failed (test knob)"; }
+            else rc = nb[pl].ensure((size_t)s->n_seqs * (size_t)cap);
+            if (rc) { nb[0].release(); nb[1].release(); (void)hipGetLastError(); return rc; }      // (the failed hipMalloc's error is not left behind)
         }
-        if (rc) return rc;
+        return (int)TWL_OK;
+    };
+    int rc = alloc_both(ncap);
+    if (rc && ncap > minCap) { ncap = minCap; rc = alloc_both(ncap); }
+    if (rc) return rc;
+    for (int pl = 0; pl < 2; ++pl)
         if (s->rows[pl].p)
-            HIP_TRY(hipMemcpy2DAsync(nb.p, (size_t)ncap, s->rows[pl].p, (size_t)s->cap, (size_t)s->cap, (size_t)s->n_seqs, hipMemcpyDeviceToDevice, d->stream));
-        HIP_TRY(hipStreamSynchronize(d->stream));
-        s->rows[pl].release();
-        s->rows[pl] = nb;
-    }
+            HIP_TRY(hipMemcpy2DAsync(nb[pl].p, (size_t)ncap, s->rows[pl].p, (size_t)s->cap, (size_t)s->cap, (size_t)s->n_seqs, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (int pl = 0; pl < 2; ++pl) { s->rows[pl].release(); s->rows[pl] = nb[pl]; }
     s->cap = ncap;
     return TWL_OK;
+}
+
+// (callers hold s->d->mu)
+void store_destroy_locked(twl_store *s)
+{
+    (void)hipSetDevice(s->d->id);
+    for (auto &kv : s->cache) { kv.second->buf.release(); delete kv.second; }
+    release_level(s->lv);
+    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
+        b->release();
+    s->d->live_stores -= 1;
+    delete s;
 }
 
 template <class T>
@@ -170,6 +191,7 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
     std::lock_guard<std::mutex> lk(d->mu);
     HIP_TRY(hipSetDevice(d->id));
     auto *s = new twl_store();
+    d->live_stores += 1;
     s->d = d;
     s->type = type;
     s->P = (type == 'n') ? 6 : 22;
@@ -186,7 +208,7 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
     // synthetic families; 8 x log10(n) - 16, between 8x and 48x, within grow_rows' budget)
     const double lg = std::log10((double)std::max<int32_t>(n_seqs, 10));
     const int64_t factor = (int64_t)std::min(48.0, std::max(8.0, 8.0 * lg - 16.0));
-    if ((rc = grow_rows(s, maxLen + 1, factor * maxLen + 256))) { twl_store_destroy(s); return rc; }
+    if ((rc = grow_rows(s, maxLen + 1, factor * maxLen + 256))) { store_destroy_locked(s); return rc; }
     if (n_seqs > 0) {
         const size_t hp = (size_t)maxLen;
         std::unique_ptr<char[]> img(new char[(size_t)n_seqs * hp]);
@@ -195,7 +217,7 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
     }
     uint8_t lut[256];
     build_lut(type, lut);
-    if ((rc = s->lut.ensure(256))) { twl_store_destroy(s); return rc; }
+    if ((rc = s->lut.ensure(256))) { store_destroy_locked(s); return rc; }
     HIP_TRY(hipMemcpy(s->lut.p, lut, 256, hipMemcpyHostToDevice));
     *out = s;
     return TWL_OK;
@@ -204,12 +226,8 @@ int twl_store_create(int device, char type, int32_t n_seqs, const char *const *s
 void twl_store_destroy(twl_store *s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->d->id);
-    for (auto &kv : s->cache) { kv.second->buf.release(); delete kv.second; }
-    release_level(s->lv);
-    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
-        b->release();
-    delete s;
+    std::lock_guard<std::mutex> lk(s->d->mu);      // (the level-buffer pool and the store count belong to the device)
+    store_destroy_locked(s);
 }
 
 int twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out)

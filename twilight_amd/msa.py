@@ -76,7 +76,19 @@ class Msa:
         """Align this family together with `world` - 1 other processes.  `exchange(send_ptr, bytes_per_rank, recv_ptr) -> 0` is an
         all-gather of host blocks (twilight_amd.dist.make_exchange)."""
         if world > 1 or exchange is not None:
-            self._cb = EXCHANGE_FN(lambda user, send, nbytes, recv: int(exchange(send, nbytes, recv)))
+            def _cb(user, send, nbytes, recv):
+                # ctypes swallows exceptions raised inside a callback and hands the C side an undefined return value: every failure
+                # must come back as a non-zero code, which the host library turns into a fatal error of the run
+                try:
+                    return int(exchange(send, nbytes, recv))
+                except BaseException as ex:  # noqa: BLE001
+                    import sys
+                    import traceback
+                    traceback.print_exc()
+                    print(f"twilight_amd: the exchange callback failed: {ex!r}", file=sys.stderr, flush=True)
+                    return 1
+
+            self._cb = EXCHANGE_FN(_cb)
             self._check(self._lib.twl_msa_shard(self._h, rank, world, self._cb, None), "twl_msa_shard")
         return self
 
