@@ -131,3 +131,44 @@ def test_long_pair_100k(knobs):
     batch = synth.make_level_batch(2, 100000, members=((1, 3), (1, 3)), seed=77, sub=0.03, indel=0.002)
     st, ost = _compare(knobs, batch)
     assert st.speculative == 3 and st.mt_tiles_predicted > 150
+
+
+# ---- protein (P = 22): tile-parallel on the precomputed column scores ----
+PM = synth.protein_matrix()
+
+
+def _compare_p(twl, batch, **pk):
+    p = twl.make_params(PM, **pk)
+    aln, n, err = twl.align_batch(p, batch)
+    st = twl.get_stats(0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(PM, **pk), batch, threads=8)
+    assert np.array_equal(err, oerr) and np.array_equal(n, on), (err.tolist(), oerr.tolist(), n.tolist(), on.tolist())
+    for i in range(batch.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[i, : on[i]]), f"pair {i}: path differs"
+    if np.all(oerr == 0):
+        assert st.band_cells == ost.cells, f"band cells gpu {st.band_cells} oracle {ost.cells}"
+    return st, ost
+
+
+@pytest.mark.parametrize("thr_jobs", [512, 0])
+def test_protein_tile_parallel(knobs, thr_jobs):
+    """5 pairs x ~2500 aa (5-6 tiles each), on either geometry of the scout / tile launches."""
+    knobs.set_knob(api.KNOB_MT_THR_JOBS, thr_jobs)
+    batch = synth.make_level_batch(5, 2500, P=22, members=((1, 6), (1, 6)), seed=91, sub=0.15)
+    st, ost = _compare_p(knobs, batch)
+    assert st.speculative == 3 and st.matrix_mode == 4
+    assert st.mt_tiles_predicted + st.mt_tiles_inline == ost.tiles
+
+
+def test_protein_tile_parallel_with_spoiled_predictions(knobs):
+    knobs.set_knob(api.KNOB_MT_PERTURB, 2)
+    batch = synth.make_level_batch(4, 3000, P=22, members=((2, 5), (2, 5)), seed=92, sub=0.2)
+    st, ost = _compare_p(knobs, batch)
+    assert st.speculative == 3 and st.mt_tiles_inline >= 1
+
+
+def test_protein_tile_parallel_small_marker_and_blosum80(knobs):
+    knobs.set_knob(api.KNOB_MT_MIN_MARKER, 64)
+    batch = synth.make_level_batch(4, 1500, P=22, members=((1, 4), (1, 4)), seed=93, sub=0.25)
+    st, ost = _compare_p(knobs, batch, marker=200)
+    assert st.speculative == 3

@@ -406,8 +406,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     int8_t *finalPaths = reinterpret_cast<int8_t *>(g_finalStage.get((size_t)n * pathStride));
     std::vector<int32_t> finalLen(n, 0);
     std::vector<char> deferred(n, 0);
-    // (few pairs -- the top of the tree, paths of 10^5 columns: one pair at a time, addGappyColumnsBack spreads its runs over the threads itself)
-#pragma omp parallel for schedule(dynamic, 1) if (n >= 8)
+#pragma omp parallel for schedule(dynamic, 1)
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
         deferred[i] = ((s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144

@@ -173,18 +173,23 @@ void getConsensus(Option *option, float *profile, std::string &consensus, int le
     }
 }
 
-// alignment-helper.cpp:243-322: small affine NW over two consensus substrings, free leading gaps, traceback prefers M, then Y(1), then X(2)
-void pairwiseGlobal(const std::string &seq1, const std::string &seq2, alnPath &path, Params &param)
+// alignment-helper.cpp:243-322: small affine NW over two consensus substrings, free leading gaps, traceback prefers M, then Y(1), then X(2).
+// Raw form: the two substrings by pointer, the path (forward order) into `out` (room for m + n codes), matrices in the caller's scratch
+// (addGappyColumnsBack calls this thousands of times per pair at the top of the tree: no allocation per call).
+struct PairwiseScratch { std::vector<float> M, X, Y; std::vector<int8_t> tb; std::vector<int> idx2; };
+static int pairwiseGlobalRaw(const char *seq1, int m, const char *seq2, int n, int8_t *out, Params &param, PairwiseScratch &sc)
 {
-    const int m = (int)seq1.size(), n = (int)seq2.size();
     const char type = (param.matrixSize == 5) ? 'n' : 'p';
     const float gap_open = param.gapOpen, gap_extend = param.gapExtend;
-    const size_t W = (size_t)n + 1;
-    std::vector<float> M((m + 1) * W, 0.0f), X((m + 1) * W, 0.0f), Y((m + 1) * W, 0.0f);
-    std::vector<int8_t> tb((m + 1) * W, 0);
+    const size_t W = (size_t)n + 1, cellsN = ((size_t)m + 1) * W;
+    if (sc.M.size() < cellsN) { sc.M.resize(cellsN); sc.X.resize(cellsN); sc.Y.resize(cellsN); sc.tb.resize(cellsN); }
+    if (sc.idx2.size() < (size_t)n + 1) sc.idx2.resize((size_t)n + 1);
+    float *M = sc.M.data(), *X = sc.X.data(), *Y = sc.Y.data();
+    int8_t *tb = sc.tb.data();
+    M[0] = X[0] = Y[0] = 0.0f; tb[0] = 0;
     for (int i = 1; i <= m; ++i) { M[i * W] = 0; X[i * W] = M[i * W]; Y[i * W] = -1e9; tb[i * W] = 2; }
     for (int j = 1; j <= n; ++j) { M[j] = 0; Y[j] = M[j]; X[j] = -1e9; tb[j] = 1; }
-    std::vector<int> idx2(n);      // (letter indices once per letter, not once per cell)
+    int *idx2 = sc.idx2.data();      // (letter indices once per letter, not once per cell)
     for (int j = 0; j < n; ++j) idx2[j] = letterIdx(type, (char)toupper((unsigned char)seq2[j]));
     for (int i = 1; i <= m; ++i) {
         const int a = letterIdx(type, (char)toupper((unsigned char)seq1[i - 1]));
@@ -199,15 +204,24 @@ void pairwiseGlobal(const std::string &seq1, const std::string &seq2, alnPath &p
             tb[c] = (best == M[c]) ? 0 : ((best == Y[c]) ? 1 : 2);
         }
     }
-    path.clear();
+    int len = 0;
     for (int i = m, j = n; i > 0 || j > 0;) {
         const int8_t d = tb[i * W + j];
-        path.push_back(d);
+        out[len++] = d;
         if (d == 0) { --i; --j; }
         else if (d == 1) --j;
         else --i;
     }
-    std::reverse(path.begin(), path.end());
+    std::reverse(out, out + len);
+    return len;
+}
+
+void pairwiseGlobal(const std::string &seq1, const std::string &seq2, alnPath &path, Params &param)
+{
+    PairwiseScratch sc;
+    path.resize(seq1.size() + seq2.size());
+    const int len = pairwiseGlobalRaw(seq1.data(), (int)seq1.size(), seq2.data(), (int)seq2.size(), path.data(), param, sc);
+    path.resize((size_t)len);
 }
 
 // alignment-helper.cpp:324-375.  The reference walks the path once, keeping the ORIGINAL column index of either side, and inserts a removed
@@ -248,17 +262,30 @@ void addGappyColumnsBack(alnPath &before, alnPath &after, std::pair<IntPairVec, 
         else if (i >= aR.size() || aQ[j] < aR[i]) { ev.push_back({aQ[j], -1, (int)j}); ++j; }
         else { ev.push_back({aR[i], (int)i, (int)j}); ++i; ++j; }
     }
-    // the segment of every event; runs of both sides at one step are aligned to each other
-    std::vector<alnPath> both(ev.size());
-    std::vector<size_t> segLen(ev.size());
-    const bool nested = omp_in_parallel();
-#pragma omp parallel for schedule(dynamic, 1) if (!nested && ev.size() > 64)
+    // the segment of every event; runs of both sides at one step are aligned to each other (thousands of small alignments per pair at the
+    // top of the tree: their paths go into one arena, a contiguous share of them per thread, scratch matrices per thread)
+    std::vector<size_t> segLen(ev.size()), arenaOff(ev.size(), 0);
+    std::vector<int> bothIdx;
+    size_t arenaBytes = 0;
     for (size_t e = 0; e < ev.size(); ++e) {
         if (ev[e].r >= 0 && ev[e].q >= 0) {
-            const IntPair &rr = gappy.first[ev[e].r], &qq = gappy.second[ev[e].q];
-            pairwiseGlobal(orgSeqs.first.substr(rr.first, rr.second), orgSeqs.second.substr(qq.first, qq.second), both[e], param);
-            segLen[e] = both[e].size();
+            bothIdx.push_back((int)e);
+            arenaOff[e] = arenaBytes;
+            arenaBytes += (size_t)gappy.first[ev[e].r].second + (size_t)gappy.second[ev[e].q].second;
         } else segLen[e] = (size_t)(ev[e].r >= 0 ? gappy.first[ev[e].r].second : gappy.second[ev[e].q].second);
+    }
+    std::vector<int8_t> arena(arenaBytes);
+    const bool nested = omp_in_parallel();
+    const int nBoth = (int)bothIdx.size();
+#pragma omp parallel if (!nested && nBoth > 20000)
+    {
+        PairwiseScratch sc;
+#pragma omp for schedule(static)
+        for (int b = 0; b < nBoth; ++b) {
+            const size_t e = (size_t)bothIdx[b];
+            const IntPair &rr = gappy.first[ev[e].r], &qq = gappy.second[ev[e].q];
+            segLen[e] = (size_t)pairwiseGlobalRaw(orgSeqs.first.data() + rr.first, rr.second, orgSeqs.second.data() + qq.first, qq.second, arena.data() + arenaOff[e], param, sc);
+        }
     }
     // output offsets: the path elements before an event's step, then its segment
     std::vector<size_t> off(ev.size() + 1);
@@ -268,15 +295,14 @@ void addGappyColumnsBack(alnPath &before, alnPath &after, std::pair<IntPairVec, 
     const size_t base = after.size();
     after.resize(base + total);
     int8_t *out = after.data() + base;
-#pragma omp parallel for schedule(static) if (!nested && total > (1u << 16))
-    for (size_t e = 0; e <= ev.size(); ++e) {
+    for (size_t e = 0; e <= ev.size(); ++e) {      // (a few hundred KB of block copies at most: one thread)
         // the stretch of the path between the previous event's step and this one's (or the end)
         const size_t a0 = e ? ev[e - 1].a : 0, a1 = (e < ev.size()) ? ev[e].a : n;
         const size_t dst = e ? off[e - 1] + segLen[e - 1] : 0;
         if (a1 > a0) std::memcpy(out + dst, before.data() + a0, a1 - a0);
         if (e < ev.size()) {
             int8_t *seg = out + off[e];
-            if (ev[e].r >= 0 && ev[e].q >= 0) { if (segLen[e]) std::memcpy(seg, both[e].data(), segLen[e]); }
+            if (ev[e].r >= 0 && ev[e].q >= 0) { if (segLen[e]) std::memcpy(seg, arena.data() + arenaOff[e], segLen[e]); }
             else std::memset(seg, ev[e].r >= 0 ? 2 : 1, segLen[e]);
         }
     }

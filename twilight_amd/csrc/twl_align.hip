@@ -255,7 +255,7 @@ int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 
-template <int P, int MM>
+template <int P, int MM, int TRPL>      // TRPL: 64-row blocks per wave of the throughput geometry (nucleotide 2: 1024 rows, protein 1: 512 rows)
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
               const int32_t *h_len, int *grid_out, int *window_out)
 {
@@ -305,11 +305,14 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.mt_front = (int32_t *)((unsigned long long *)d->mt_stat.p + 4);
     a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
     const bool thr = nTile > g_mt_thr_jobs;
-    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, thr ? "8x2" : "16x1");
-    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %s, %d, %s, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, thr ? "8, 2" : "16, 1", MM, thr ? "4" : "1");
+    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, thr ? "8 waves, 2 per CU" : "16x1");
+    if (!d->kname[0]) {
+        if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 8, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TRPL, MM, P, MM);
+        else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, 1, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, MM);
+    }
     if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
-        rc = thr ? launch_mt_kernel<P, 8, 2, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
+        rc = thr ? launch_mt_kernel<P, 8, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
         if (rc) return rc;
     }
     const int rounds = std::max(1, g_mt_rounds);
@@ -318,7 +321,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
                            (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
         HIP_TRY(hipGetLastError());
         a.mt_jobs = (const int32_t *)d->mt_jobs.p + 2 * (size_t)nScout;
-        rc = thr ? launch_mt_kernel<P, 8, 2, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, 16, 1, MM, 1, 1>(d, st, a, nTile, grid_out);
+        rc = thr ? launch_mt_kernel<P, 8, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, 16, 1, MM, 1, 1>(d, st, a, nTile, grid_out);
         if (rc) return rc;
         a.mt_jobs = nullptr;
         a.mt_inline = (r == rounds - 1) ? 1 : 0;
@@ -484,7 +487,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
                 statSpec = sharedSpec ? 2 : ((lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !dev_env("TWL_NO_SPEC")) ? 1 : 0);
-                if (sharedSpec) { rc = launch_lean<22, 8, 1, 4, 4, true>(d, st, a, items, n_run, &grid, &window); protSmall = true; }
+                long long sumLenP = 0;
+                for (int32_t t = 0; t < n_run; ++t) sumLenP += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
+                // tile-parallel (talco_nuc.hip.h, MT kernels) on the precomputed scores: pairs of 2 kaa have 4-5 tiles each
+                const bool mtOkP = lean && pcs == "auto" && n_run <= g_mt_max_pairs && n_run <= d->num_cu && p->marker >= g_mt_min_marker && sumLenP >= 3ll * p->marker * n_run;
+                if (mtOkP) { rc = launch_mt<22, 4, 1>(d, st, a, items, order, n_run, h_len, &grid, &window); statSpec = 3; ranMt = true; protSmall = false; }
+                else if (sharedSpec) { rc = launch_lean<22, 8, 1, 4, 4, true>(d, st, a, items, n_run, &grid, &window); protSmall = true; }
                 else if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !dev_env("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_run, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_run, 0, &grid, &window);
@@ -548,7 +556,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         }
         else if (mtOk) {
             // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
-            rc = launch_mt<6, 2>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            rc = launch_mt<6, 2, 2>(d, st, a, items, order, n_run, h_len, &grid, &window);
             statSpec = 3; ranMt = true;
         }
         else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || dev_env("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !dev_env("TWL_NO_SPEC") && !dev_env("TWL_NO_SPEC_SHARED")) {
