@@ -91,6 +91,21 @@ int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len);
 int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, int8_t *out, int32_t out_stride);
 
 /*
+ * alignment_helper::addGappyColumnsBack (+ pairwiseGlobal for runs removed on both sides at one step; alignment-helper.cpp:324-375,
+ * :243-322) on the device, for the n_sel pairs listed in pairs[] of the prepared and aligned level: the columns removeGappyColumns took
+ * out go back into their DP paths.  The level's DP paths (every pair's) are staged in the level's path buffer at row pitch out_stride
+ * (>= the longest final path: refLen + qryLen before removal), the restored ones replace their rows there, and
+ * final_len_out[t] = the final length of pairs[t] -- or -1 when that pair has a two-sided run too large for the device's per-thread
+ * scratch ((m + 1) x (n + 1) > 4096 cells or n > 127): the caller then restores it on the host (twl_level_read_paths /
+ * twl_level_read_colinfo_many) and hands the result to the commit as a host row.  The commit that follows must be
+ * twl_level_commit_from_dp with path_stride == out_stride and from_dp[i] == 2 for the pairs restored here (1 still means: final as the
+ * DP left it).  May be called several times per level (after each twl_level_align of a gap-character group), always with one out_stride.
+ */
+int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out);
+/* Diagnostics: the first `len` codes of pair `pair`'s row of the staged path buffer (after twl_level_restore). */
+int twl_level_read_final(twl_store *s, int32_t pair, int8_t *out, int32_t len);
+
+/*
  * Apply the final paths (gappy columns restored) to the rows of both nodes of every pair and merge cached profiles.
  *   paths     [n_pairs][path_stride]   codes 0/1/2;  path_len[i] == 0 leaves pair i untouched (deferred pair)
  * After the call every member row of pair i has length path_len[i]; if both sides had a cache (cache_id or store_id) the
@@ -102,7 +117,7 @@ int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len,
  * Same, with the paths of the pairs marked in from_dp[] taken from the level's own DP output in HBM (path_len[i] = the length
  * twl_level_align returned): for pairs in which no gappy column was removed addGappyColumnsBack (alignment-helper.cpp:243-289) is the
  * identity, so their paths never have to leave the device.  Rows of `paths` of marked pairs are ignored; paths may be NULL when every
- * pair with path_len > 0 is marked.  from_dp == NULL is twl_level_commit.
+ * pair with path_len > 0 is marked.  from_dp[i] == 2: the row was put there by twl_level_restore.  from_dp == NULL is twl_level_commit.
  */
 int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride, const uint8_t *from_dp);
 

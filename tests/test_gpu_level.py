@@ -310,3 +310,38 @@ def test_row_planes_fall_back_to_the_minimal_pitch_together(gpu):
         for sid, want in zip(ids[i][0] + ids[i][1], e["rows_after"]):
             assert rows[sid] == want, f"pair {i}: row {sid} after write-back"
     st.close()
+
+
+@pytest.mark.parametrize("seq_type", ["n", "p"])
+def test_gappy_columns_back_on_the_device(gpu, seq_type):
+    """twl_level_restore == addGappyColumnsBack + pairwiseGlobal (alignment-helper.cpp:324-375, :243-322) as oracle/level_oracle.py walks
+    them, on the DP paths the device itself produced; the write-back that follows takes the restored rows straight from HBM."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    cases = [LC.make_case(seq_type, seed, cached=0, length=60 + 41 * seed, thr=(0.6 if seed % 3 == 0 else 0.95)) for seed in range(1, 9)]
+    cases = [c for c in cases if c.thr == 0.6] + [LC.make_case(seq_type, 40 + k, cached=0, length=900 + 300 * k, thr=0.6) for k in range(3)]
+    seqs, pairs, ids = _level(cases)
+    p = twl.make_params(LC.matrix_of(seq_type))
+    st = L.Store(seqs, seq_type)
+    lens, info = st.prepare(p, pairs, gappy_threshold=0.6)
+    n, err = st.align_in_hbm(p)
+    assert not err.any()
+    stride = max(len(c.sides[0].rows[0]) + len(c.sides[1].rows[0]) for c in cases)
+    lost = [i for i, c in enumerate(cases) if tuple(lens[i]) != (len(c.sides[0].rows[0]), len(c.sides[1].rows[0]))]
+    assert len(lost) >= len(cases) - 1      # a 0.6 threshold removes columns nearly everywhere
+    fin = st.restore(p, lost, stride)
+    assert (fin > 0).all(), fin
+    exps = {}
+    for t, i in enumerate(lost):
+        e = LC.expected(cases[i], path_wo_gc=st.read_path(i, int(n[i])))
+        exps[i] = e
+        got = st.read_final(i, int(fin[t]))
+        assert len(e["path_full"]) == fin[t] and np.array_equal(got, e["path_full"]), f"pair {i}: restored path"
+    plen = [int(fin[lost.index(i)]) if i in exps else int(n[i]) for i in range(len(cases))]
+    st.commit_from_dp([None] * len(cases), plen, stride=stride, restored=lost)
+    rows = st.rows()
+    for i, e in exps.items():
+        for sid, want in zip(ids[i][0] + ids[i][1], e["rows_after"]):
+            assert rows[sid] == want, f"pair {i}: row {sid} after write-back"
+    st.close()

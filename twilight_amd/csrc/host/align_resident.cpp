@@ -280,7 +280,23 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         s.lens = {lens[2 * i], lens[2 * i + 1]};
         if (s.lens.first != s.refLen || s.lens.second != s.qryLen) needInfo.push_back(i);
     }
-    if (needInfo.size() * 8 > (size_t)n) {        // most pairs: one transfer of the level's block
+    // One device, one process: the paths never leave HBM -- pairs that lost no column commit their DP path as it is, the others get their
+    // columns back on the device (twl_level_restore); the column info comes to the host only for a pair the device hands back (below).
+    const bool procs = ctx.shard.world > 1;
+    const bool inPlace = (nd == 1 && !procs && !ctx.shard.exchange);
+    auto infoOf = [&](const std::vector<int> &which) {      // consensus + removed runs of these pairs, one synchronisation
+        uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * which.size() * stride));
+        const int rc = twl_level_read_colinfo_many(g_store, (int32_t)which.size(), which.data(), info);
+        if (rc != TWL_OK) die("twl_level_read_colinfo_many", rc);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int t = 0; t < (int)which.size(); ++t) {
+            PairState &s = ps[which[t]];
+            runsAndConsensus(&info[((size_t)2 * t) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
+            runsAndConsensus(&info[((size_t)2 * t + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
+        }
+    };
+    if (inPlace) {}
+    else if (needInfo.size() * 8 > (size_t)n) {        // most pairs: one transfer of the level's block
         uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * n * stride));
         const int rc = twl_level_read_colinfo(g_store, -1, 0, info);
         if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
@@ -290,17 +306,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             runsAndConsensus(&info[((size_t)2 * needInfo[t]) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
             runsAndConsensus(&info[((size_t)2 * needInfo[t] + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
         }
-    } else if (!needInfo.empty()) {             // a few pairs: their blocks only, one synchronisation
-        uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * needInfo.size() * stride));
-        const int rc = twl_level_read_colinfo_many(g_store, (int32_t)needInfo.size(), needInfo.data(), info);
-        if (rc != TWL_OK) die("twl_level_read_colinfo_many", rc);
-#pragma omp parallel for schedule(dynamic, 4)
-        for (int t = 0; t < (int)needInfo.size(); ++t) {
-            PairState &s = ps[needInfo[t]];
-            runsAndConsensus(&info[((size_t)2 * t) * stride], s.refLen, removal, letters, s.gappy.first, s.consensus.first);
-            runsAndConsensus(&info[((size_t)2 * t + 1) * stride], s.qryLen, removal, letters, s.gappy.second, s.consensus.second);
-        }
-    }
+    } else if (!needInfo.empty()) infoOf(needInfo);      // a few pairs: their blocks only
     ctx.totals.prepare_ms += nowMs() - tPrep;
 
     // ---- DP with the reference's grouping and retry/defer policy (alignment-cpu.cpp:88-130) ----
@@ -320,7 +326,6 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<char> takesPart(n, 0);
     std::vector<long long> cost(n, 0);
     for (int i = 0; i < n; ++i) { takesPart[i] = (maskPlain[i] || maskZero[i]) ? 1 : 0; cost[i] = (long long)ps[i].lens.first + ps[i].lens.second; }
-    const bool procs = ctx.shard.world > 1;
     const std::vector<int> owner = dealPairs(cost, takesPart, procs ? ctx.shard.world : nd);
     const int meBase = procs ? ctx.shard.rank : 0;       // replica d of this process aligns the pairs of owner meBase + d
     twl_params tz = tp;
@@ -328,13 +333,12 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (g_alnStage.size() < (size_t)nd) g_alnStage.resize((size_t)nd);
     std::vector<double> callMs(nd, 0), kernMs(nd, 0), totMs(nd, 0);
     std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
-    // One device, one process, and few pairs lost columns: the paths of all the others never leave HBM (addGappyColumnsBack is the
-    // identity for them): the DP output is committed in place, only the pairs that need editing are fetched.
-    const bool inPlace = (nd == 1 && !procs && !ctx.shard.exchange && needInfo.size() * 4 <= (size_t)n);
     std::vector<char> needsHost(n, 0);
     for (int i : needInfo) needsHost[i] = 1;
-    std::vector<uint8_t> fromDp(n, 0);
+    std::vector<uint8_t> fromDp(n, 0);       // 1: the DP path is the final path; 2: twl_level_restore made the final path, in HBM
     std::vector<int32_t> dpLen(n, 0);
+    int pathStride = 1;                      // row pitch of the final paths: refLen + qryLen before removal bounds every path
+    for (int i = 0; i < n; ++i) pathStride = std::max(pathStride, ps[i].refLen + ps[i].qryLen);
     onAllStores(ctx, "twl_level_align", [&](int d) {
         int8_t *aln = inPlace ? nullptr : reinterpret_cast<int8_t *>(g_alnStage[d].get((size_t)n * 2 * stride));
         std::vector<int32_t> alnLen(n);
@@ -353,16 +357,29 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
                 if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); } if (d == 0) { rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; } }
             }
-            std::vector<int32_t> fetch, fetchLen;
+            std::vector<int32_t> fetch, fetchLen, restore, restoreLen;
             for (int i = 0; i < n; ++i) {
                 if (!mask[i]) continue;
                 errs[i] = err[i];
                 const int32_t len = (err[i] == 0) ? alnLen[i] : 0;
                 if (!inPlace) paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + len);
-                else if (needsHost[i]) { if (len > 0) { fetch.push_back(i); fetchLen.push_back(len); } else paths[i].clear(); }
+                else if (needsHost[i]) {
+                    const bool lowQ = (ps[i].refNum == 1 || ps[i].qryNum == 1) && (ps[i].lowQ_r || ps[i].lowQ_q);      // (deferred below: its path is dropped)
+                    if (len > 0 && !lowQ) { restore.push_back(i); restoreLen.push_back(len); } else paths[i].clear();
+                }
                 else if (len > 0) { fromDp[i] = 1; dpLen[i] = len; }
             }
-            if (!fetch.empty()) {               // the pairs the host has to edit: their paths only, one synchronisation
+            if (!restore.empty()) {             // gappy columns back on the device: these paths never leave HBM either
+                std::vector<int32_t> fin(restore.size(), -1);
+                const int r3 = twl_level_restore(g_stores[d], grp ? &tz : &tp, (int32_t)restore.size(), restore.data(), pathStride, fin.data());
+                if (r3 != TWL_OK) return r3;
+                for (size_t t = 0; t < restore.size(); ++t) {
+                    if (fin[t] > 0) { fromDp[restore[t]] = 2; dpLen[restore[t]] = fin[t]; }
+                    else { fetch.push_back(restore[t]); fetchLen.push_back(restoreLen[t]); }      // a two-sided run too large for the device: on the host, as before
+                }
+            }
+            if (!fetch.empty()) {               // the pairs the host has to edit: their column info and paths only
+                infoOf(std::vector<int>(fetch.begin(), fetch.end()));
                 int8_t *blk = reinterpret_cast<int8_t *>(g_alnStage[d].get(fetch.size() * (size_t)2 * stride));
                 const int r2 = twl_level_read_paths(g_stores[d], (int32_t)fetch.size(), fetch.data(), fetchLen.data(), blk, 2 * stride);
                 if (r2 != TWL_OK) return r2;
@@ -401,8 +418,6 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
 
     // ---- gappy columns back, then the write-back on the device ----
     const double tFin = nowMs();
-    int pathStride = 1;
-    for (int i = 0; i < n; ++i) pathStride = std::max(pathStride, ps[i].refLen + ps[i].qryLen);
     int8_t *finalPaths = reinterpret_cast<int8_t *>(g_finalStage.get((size_t)n * pathStride));
     std::vector<int32_t> finalLen(n, 0);
     std::vector<char> deferred(n, 0);

@@ -1,0 +1,215 @@
+// twilight_amd/csrc/restore_kernels.hip.h -- alignment_helper::addGappyColumnsBack + pairwiseGlobal on the device
+// (/root/reference/src/alignment-helper.cpp:324-375, :243-322), so that the paths of a level never leave HBM.
+//
+// The reference walks the DP path once, keeping the ORIGINAL column index of either side, and inserts a removed run of columns when
+// that index reaches the run's start: 2s for a reference run, 1s for a query run, and when both sides have a run at the same step
+// the two runs (their consensus letters) are aligned to each other by a small affine Needleman-Wunsch.  As a data-parallel program:
+//   * a removed run of side s lies immediately before kept column j of that side (or after the last one); its length is
+//     orig_idx[j] - orig_idx[j-1] - 1, where orig_idx[j] is the original index of kept column j (restore_index_kernel);
+//   * "the index reaches the run's start" at path boundary a (between elements a-1 and a) iff a == 0 or element a-1 consumed a column
+//     of that side, and then j = the number of columns of that side the path has consumed before a (restore_runs_kernel: two scans);
+//   * boundaries with a run on both sides are aligned by ONE thread each (restore_align_kernel; the runs are a few columns long,
+//     thousands of them per pair at the top of a tree), same operations in the same order as the host mirror's pairwiseGlobal
+//     (twilight_amd/csrc/host/helpers.cpp); a pair with a two-sided boundary too large for the per-thread scratch is flagged and
+//     restored by the host instead;
+//   * the output position of boundary a's segment is a + (lengths of the segments before it): one more scan (restore_write_kernel).
+// Checked against the host mirror on every level of the end-to-end tests (tests/test_gpu_level.py, tests/test_gpu_msa.py).
+#pragma once
+#include "level_kernels.hip.h"
+
+namespace twl {
+
+constexpr int kNwCells = 4096;      // (m + 1) * (n + 1) of a two-sided boundary one thread aligns
+constexpr int kNwRow = 128;         // n + 1
+
+struct RestoreArgs {
+    const int8_t *aln;        // [n_pairs][aln_stride] DP paths of the level (codes 0 / 1 / 2)
+    const int32_t *aln_len;   // [n_pairs]
+    int32_t aln_stride;
+    const uint8_t *colinfo;   // [2 * n_pairs][stride] consensus letter index | 0x80 when the column was removed
+    int32_t stride;
+    const SideDesc *sides;    // .len = columns before removal
+    const int32_t *len_red;   // [2 * n_pairs] columns after removal
+    const int32_t *sel;       // [n_sel] the pairs to restore
+    int32_t n_sel;
+    // work arrays, one slot per SELECTED pair (slot = index into sel)
+    int32_t *orig_idx;        // [2 * n_sel][stride + 1]
+    int32_t *run;             // [n_sel][4][bstride] per boundary: run length ref, run length query, run start ref, run start query
+    int32_t *seg;             // [n_sel][bstride] segment length per boundary
+    int32_t *aoff;            // [n_sel][bstride] arena offset of a two-sided boundary
+    int8_t *arena;            // [n_sel][out_stride] the aligned two-sided segments, reversed
+    int32_t bstride;
+    int8_t *out;              // [n_pairs][out_stride] final paths
+    int32_t out_stride;
+    int32_t *out_len;         // [n_pairs] final length; -1 = the host has to restore this pair
+    int8_t *tbs;              // [grid * 256][kNwCells] per-thread traceback scratch
+    float *rows;              // [grid * 256][6 * kNwRow] per-thread rolling rows
+    float M[441];             // scoringMatrix[a][b], row-major ms x ms
+    int32_t ms;
+    float gap_open, gap_extend;
+};
+
+// exclusive prefix sum of one int per thread over a 256-thread workgroup; *total = the sum
+__device__ __forceinline__ int block_scan_int_256(int v, int *total, int *s_wave)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    int base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; if (w < wave) base += c; sum += c; }
+    *total = sum;
+    return base + x - v;
+}
+
+// grid: 2 * n_sel workgroups of 256 threads: original index of every kept column of one side (+ the side's original length as a sentinel)
+__global__ void __launch_bounds__(256) restore_index_kernel(RestoreArgs a)
+{
+    __shared__ int s_wave[4];
+    const int side = 2 * a.sel[blockIdx.x >> 1] + (blockIdx.x & 1);
+    const int len = a.sides[side].len;
+    int32_t *oi = a.orig_idx + (size_t)blockIdx.x * (size_t)(a.stride + 1);
+    int base = 0;
+    for (int c0 = 0; c0 < len; c0 += 256) {
+        const int t = c0 + threadIdx.x;
+        const bool keep = t < len && !(a.colinfo[(size_t)side * a.stride + t] & 0x80);
+        int total;
+        const int dst = base + block_scan_256(keep, &total, s_wave);
+        if (keep) oi[dst] = t;
+        base += total;
+    }
+    if (threadIdx.x == 0) oi[base] = len;      // (base == len_red[side])
+}
+
+// grid: n_sel workgroups: the runs at every boundary of the DP path, and where the two-sided ones go in the arena
+__global__ void __launch_bounds__(256) restore_runs_kernel(RestoreArgs a)
+{
+    __shared__ int s_wave[4];
+    const int pair = a.sel[blockIdx.x];
+    const int n = a.aln_len[pair];
+    const int8_t *path = a.aln + (size_t)pair * a.aln_stride;
+    const int32_t *oiR = a.orig_idx + (size_t)(2 * blockIdx.x) * (size_t)(a.stride + 1), *oiQ = oiR + (a.stride + 1);
+    int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride, *stR = runQ + a.bstride, *stQ = stR + a.bstride;
+    int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride, *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
+    int baseR = 0, baseQ = 0, baseA = 0;
+    bool tooBig = false;
+    for (int c0 = 0; c0 <= n; c0 += 256) {
+        const int b = c0 + threadIdx.x;                 // boundary b: between elements b - 1 and b
+        const int prev = (b >= 1 && b <= n) ? path[b - 1] : 3;
+        const bool fR = (prev == 0 || prev == 2), fQ = (prev == 0 || prev == 1);
+        int totR, totQ, totA;
+        const int cR = baseR + block_scan_256(fR, &totR, s_wave) + (fR ? 1 : 0);      // reference columns consumed before boundary b
+        const int cQ = baseQ + block_scan_256(fQ, &totQ, s_wave) + (fQ ? 1 : 0);
+        int rR = 0, rQ = 0, sR = 0, sQ = 0;
+        if (b <= n) {
+            if (b == 0 || fR) { sR = cR ? oiR[cR - 1] + 1 : 0; rR = oiR[cR] - sR; }
+            if (b == 0 || fQ) { sQ = cQ ? oiQ[cQ - 1] + 1 : 0; rQ = oiQ[cQ] - sQ; }
+        }
+        const bool both = rR > 0 && rQ > 0;
+        if (both && ((long long)(rR + 1) * (rQ + 1) > kNwCells || rQ + 1 > kNwRow)) tooBig = true;
+        const int off = baseA + block_scan_int_256(both ? rR + rQ : 0, &totA, s_wave);
+        if (b <= n) {
+            runR[b] = rR; runQ[b] = rQ; stR[b] = sR; stQ[b] = sQ;
+            seg[b] = both ? -1 : rR + rQ;
+            aoff[b] = off;
+        }
+        baseR += totR; baseQ += totQ; baseA += totA;
+    }
+    // (every thread votes: a.out_len is written by one)
+    __syncthreads();
+    if (threadIdx.x == 0) s_wave[0] = 0;
+    __syncthreads();
+    if (tooBig) s_wave[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) a.out_len[pair] = s_wave[0] ? -1 : 0;
+}
+
+// grid: n_sel workgroups: every two-sided boundary aligned by one thread (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322)
+__global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
+{
+    const int pair = a.sel[blockIdx.x];
+    if (a.out_len[pair] < 0) return;
+    const int n = a.aln_len[pair];
+    const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride, *stR = runQ + a.bstride, *stQ = stR + a.bstride;
+    int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride;
+    const int32_t *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
+    const uint8_t *cR = a.colinfo + (size_t)(2 * pair) * a.stride, *cQ = cR + a.stride;
+    int8_t *arena = a.arena + (size_t)blockIdx.x * a.out_stride;
+    int8_t *tb = a.tbs + ((size_t)blockIdx.x * 256 + threadIdx.x) * kNwCells;
+    float *rw = a.rows + ((size_t)blockIdx.x * 256 + threadIdx.x) * (6 * kNwRow);
+    const float go = a.gap_open, ge = a.gap_extend;
+    const int ms = a.ms;
+    for (int b = threadIdx.x; b <= n; b += 256) {
+        if (seg[b] >= 0) continue;
+        const int m = runR[b], nn = runQ[b];
+        const uint8_t *s1 = cR + stR[b], *s2 = cQ + stQ[b];
+        const int W = nn + 1;
+        float *Mp = rw, *Xp = rw + kNwRow, *Yp = rw + 2 * kNwRow, *Mc = rw + 3 * kNwRow, *Xc = rw + 4 * kNwRow, *Yc = rw + 5 * kNwRow;
+        Mp[0] = 0.0f; Xp[0] = 0.0f; Yp[0] = 0.0f; tb[0] = 0;
+        for (int j = 1; j <= nn; ++j) { Mp[j] = 0.0f; Yp[j] = 0.0f; Xp[j] = -1e9f; tb[j] = 1; }
+        for (int i = 1; i <= m; ++i) {
+            const float *row = a.M + (size_t)(s1[i - 1] & 0x7f) * ms;
+            Mc[0] = 0.0f; Xc[0] = 0.0f; Yc[0] = -1e9f; tb[i * W] = 2;
+            for (int j = 1; j <= nn; ++j) {
+                const float base = row[s2[j - 1] & 0x7f];
+                const float mv = base + fmaxf(fmaxf(Mp[j - 1], Xp[j - 1]), Yp[j - 1]);
+                const float xv = fmaxf(Mp[j] + go, Xp[j] + ge);
+                const float yv = fmaxf(Mc[j - 1] + go, Yc[j - 1] + ge);
+                const float best = fmaxf(fmaxf(mv, xv), yv);
+                Mc[j] = mv; Xc[j] = xv; Yc[j] = yv;
+                tb[i * W + j] = (best == mv) ? 0 : ((best == yv) ? 1 : 2);
+            }
+            float *t;
+            t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Yp; Yp = Yc; Yc = t;
+        }
+        int8_t *dst = arena + aoff[b];       // reversed: the write kernel turns it round
+        int len = 0;
+        for (int i = m, j = nn; i > 0 || j > 0;) {
+            const int8_t d = tb[i * W + j];
+            dst[len++] = d;
+            if (d == 0) { --i; --j; }
+            else if (d == 1) --j;
+            else --i;
+        }
+        seg[b] = len;
+    }
+}
+
+// grid: n_sel workgroups: the final path = for every boundary its segment, then the path element behind it
+__global__ void __launch_bounds__(256) restore_write_kernel(RestoreArgs a)
+{
+    __shared__ int s_wave[4];
+    const int pair = a.sel[blockIdx.x];
+    if (a.out_len[pair] < 0) return;
+    const int n = a.aln_len[pair];
+    const int8_t *path = a.aln + (size_t)pair * a.aln_stride;
+    const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride;
+    const int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride, *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
+    const int8_t *arena = a.arena + (size_t)blockIdx.x * a.out_stride;
+    int8_t *out = a.out + (size_t)pair * a.out_stride;
+    int base = 0;
+    for (int c0 = 0; c0 <= n; c0 += 256) {
+        const int b = c0 + threadIdx.x;
+        const int sl = (b <= n) ? seg[b] : 0;
+        int total;
+        const int pos = base + block_scan_int_256((b <= n) ? sl + (b < n ? 1 : 0) : 0, &total, s_wave);
+        if (b <= n && pos + sl + (b < n ? 1 : 0) <= a.out_stride) {
+            if (sl > 0) {
+                if (runR[b] > 0 && runQ[b] > 0) { const int8_t *src = arena + aoff[b]; for (int t = 0; t < sl; ++t) out[pos + t] = src[sl - 1 - t]; }
+                else { const int8_t code = runR[b] > 0 ? 2 : 1; for (int t = 0; t < sl; ++t) out[pos + t] = code; }
+            }
+            if (b < n) out[pos + sl] = path[b];
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) a.out_len[pair] = (base <= a.out_stride) ? base : -1;
+}
+
+}  // namespace twl

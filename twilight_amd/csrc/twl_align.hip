@@ -5,6 +5,7 @@
 #include "../../include/twl_align.h"
 #include "../../include/twl_level.h"
 #include "level_kernels.hip.h"
+#include "restore_kernels.hip.h"
 #include "talco_kernel.hip.h"
 #include "talco_nuc.hip.h"
 

@@ -24,11 +24,12 @@ struct CacheEntry {
 struct LevelBufs {
     Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
     Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew;
+    Buf r_sel, r_oidx, r_run, r_seg, r_aoff, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
     bool busy = false;
     void release_all()
     {
         for (Buf *b : {&d_sides, &d_mseq, &d_mw, &d_mplane, &d_tab, &d_raw, &d_colinfo, &d_cols, &d_len, &d_lenmask, &d_num, &d_aln, &d_alnlen, &d_err,
-                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew})
+                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_arena, &r_outlen, &r_tb, &r_rows})
             b->release();
     }
 };
@@ -79,6 +80,7 @@ struct twl_store {
     std::vector<int32_t> members;
     std::vector<int32_t> h_len, h_num;
     LevelBufs *lv = nullptr;     // the level's device buffers, held from prepare to commit (from the device's pool, see LevelBufs)
+    int32_t staged_stride = 0;   // > 0: twl_level_restore put this level's DP paths (and the restored ones) into lv->d_paths at this row pitch
     Buf d_gather, d_off, d_plane, d_rowlen;
     double prepare_ms = 0, commit_ms = 0;
 };
@@ -527,6 +529,73 @@ int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, cons
     return TWL_OK;
 }
 
+// addGappyColumnsBack for the pairs `pairs` of the prepared and aligned level, on the device (restore_kernels.hip.h): their final paths go
+// into the level's path buffer (row pitch out_stride, the pitch the commit must then be given), final_len_out[t] = the final length of
+// pairs[t], or -1 when that pair holds a two-sided run too large for the device (the caller restores it on the host, as before).
+int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out)
+{
+    if (!s || !s->prepared || !s->lv || !s->lv->d_aln.p) { g_err = "twl_level_align has not been called"; return TWL_ERR_BAD_ARGUMENT; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    const int32_t n = s->n_pairs;
+    if (n_sel < 0 || (n_sel > 0 && (!pairs || !final_len_out)) || out_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    for (int32_t t = 0; t < n_sel; ++t) if (pairs[t] < 0 || pairs[t] >= n) { g_err = "pair index out of range"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    LevelBufs *lv = s->lv;
+    const size_t sl = (size_t)s->seq_len, bstride = 2 * sl + 1;
+    // the restored paths go straight into the rows of the level's path buffer (the commit leaves those rows alone); several calls per
+    // level (one per gap-character group, after that group's twl_level_align) share the buffer and must agree on its pitch
+    if (s->staged_stride && s->staged_stride != out_stride) { g_err = "twl_level_restore: one row pitch per level"; return TWL_ERR_BAD_ARGUMENT; }
+    if ((rc = lv->d_paths.ensure((size_t)n * (size_t)out_stride))) return rc;
+    s->staged_stride = out_stride;
+    if (n_sel == 0) return TWL_OK;
+    const size_t ns = (size_t)n_sel;
+    { std::vector<int32_t> v(pairs, pairs + n_sel); if ((rc = upload(lv->r_sel, v, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    if ((rc = lv->r_oidx.ensure(2 * ns * (sl + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_run.ensure(ns * 4 * bstride * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_seg.ensure(ns * bstride * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return rc;
+    if ((rc = lv->r_outlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_tb.ensure(ns * 256 * (size_t)twl::kNwCells))) return rc;
+    if ((rc = lv->r_rows.ensure(ns * 256 * 6 * (size_t)twl::kNwRow * sizeof(float)))) return rc;
+    twl::RestoreArgs a{};
+    a.aln = (const int8_t *)lv->d_aln.p; a.aln_len = (const int32_t *)lv->d_alnlen.p; a.aln_stride = (int32_t)(2 * sl);
+    a.colinfo = (const uint8_t *)lv->d_colinfo.p; a.stride = s->seq_len;
+    a.sides = (const twl::SideDesc *)lv->d_sides.p; a.len_red = (const int32_t *)lv->d_len.p;
+    a.sel = (const int32_t *)lv->r_sel.p; a.n_sel = n_sel;
+    a.orig_idx = (int32_t *)lv->r_oidx.p; a.run = (int32_t *)lv->r_run.p; a.seg = (int32_t *)lv->r_seg.p; a.aoff = (int32_t *)lv->r_aoff.p;
+    a.arena = (int8_t *)lv->r_arena.p; a.bstride = (int32_t)bstride;
+    a.out = (int8_t *)lv->d_paths.p; a.out_stride = out_stride; a.out_len = (int32_t *)lv->r_outlen.p;
+    a.tbs = (int8_t *)lv->r_tb.p; a.rows = (float *)lv->r_rows.p;
+    a.ms = p->P - 1;
+    for (int t = 0; t < a.ms * a.ms; ++t) a.M[t] = p->matrix[t];
+    a.gap_open = p->gap_open; a.gap_extend = p->gap_extend;
+    hipLaunchKernelGGL(twl::restore_index_kernel, dim3(2 * (unsigned)n_sel), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_runs_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> all((size_t)n);
+    HIP_TRY(hipMemcpyAsync(all.data(), lv->r_outlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int32_t t = 0; t < n_sel; ++t) final_len_out[t] = all[pairs[t]];
+    return TWL_OK;
+}
+
+int twl_level_read_final(twl_store *s, int32_t pair, int8_t *out, int32_t len)
+{
+    if (!s || !s->prepared || !out || pair < 0 || pair >= s->n_pairs || len < 0 || !s->lv || !s->staged_stride || len > s->staged_stride) { g_err = "bad argument (twl_level_restore first)"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    if (len) HIP_TRY(hipMemcpy(out, (const int8_t *)s->lv->d_paths.p + (size_t)pair * (size_t)s->staged_stride, (size_t)len, hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
 int twl_level_commit(twl_store *s, const int8_t *paths, const int32_t *path_len, int32_t path_stride)
 {
     return twl_level_commit_from_dp(s, paths, path_len, path_stride, nullptr);
@@ -537,8 +606,12 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
     const int32_t n = s->n_pairs;
     s->prepared = false;
+    const int32_t staged = s->staged_stride;
+    s->staged_stride = 0;
     if (n == 0) return TWL_OK;
     if ((!paths && !from_dp) || !path_len || path_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (staged && (!from_dp || staged != path_stride)) { g_err = "commit after twl_level_restore: from_dp and the restore's row pitch are required"; return TWL_ERR_BAD_ARGUMENT; }
+    if (from_dp && !staged) for (int32_t i = 0; i < n; ++i) if (from_dp[i] == 2) { g_err = "from_dp == 2 without twl_level_restore"; return TWL_ERR_BAD_ARGUMENT; }
     if (from_dp) {
         for (int32_t i = 0; i < n; ++i) {
             if (from_dp[i] && (!s->lv || !s->lv->d_aln.p || path_len[i] > 2 * s->seq_len)) { g_err = "from_dp without a DP output of this level"; return TWL_ERR_BAD_ARGUMENT; }
@@ -597,8 +670,16 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if (!from_dp) HIP_TRY(hipMemcpyAsync(s->lv->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
     else {
         // the DP output of this level, row by row, inside HBM; then the (few) rows the caller brought
+        // (from_dp[i] == 2: twl_level_restore has put pair i's final path into its row already)
         const size_t width = std::min((size_t)path_stride, 2 * (size_t)s->seq_len);
-        HIP_TRY(hipMemcpy2DAsync(s->lv->d_paths.p, (size_t)path_stride, s->lv->d_aln.p, 2 * (size_t)s->seq_len, width, (size_t)n, hipMemcpyDeviceToDevice, st));
+        for (int32_t i = 0; i < n;) {
+            if (from_dp[i] != 1) { ++i; continue; }
+            int32_t j = i;
+            while (j < n && from_dp[j] == 1) ++j;
+            HIP_TRY(hipMemcpy2DAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, (size_t)path_stride, (const int8_t *)s->lv->d_aln.p + (size_t)i * 2 * (size_t)s->seq_len,
+                                     2 * (size_t)s->seq_len, width, (size_t)(j - i), hipMemcpyDeviceToDevice, st));
+            i = j;
+        }
         for (int32_t i = 0; i < n; ++i)
             if (!from_dp[i] && path_len[i] > 0)
                 HIP_TRY(hipMemcpyAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));

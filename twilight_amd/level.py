@@ -17,7 +17,8 @@ class TwlSide(C.Structure):
 
 
 _SYMBOLS = ["twl_store_create", "twl_store_destroy", "twl_store_read_rows", "twl_store_read_cache", "twl_store_drop_cache",
-            "twl_level_prepare", "twl_level_read_colinfo", "twl_level_read_colinfo_many", "twl_level_align", "twl_level_read_path", "twl_level_read_paths", "twl_level_commit", "twl_level_commit_from_dp", "twl_level_read_columns", "twl_level_timing"]
+            "twl_level_prepare", "twl_level_read_colinfo", "twl_level_read_colinfo_many", "twl_level_align", "twl_level_read_path", "twl_level_read_paths", "twl_level_commit", "twl_level_commit_from_dp", "twl_level_read_columns", "twl_level_timing",
+            "twl_level_restore", "twl_level_read_final"]
 
 
 def exported_symbols():
@@ -148,15 +149,28 @@ class Store:
         api._check(_lib().twl_level_read_path(self._h, C.c_int32(pair), out.ctypes.data_as(C.POINTER(C.c_int8)), C.c_int32(length)))
         return out[:length]
 
-    def commit_from_dp(self, paths: Sequence[Optional[np.ndarray]], path_len: Sequence[int]):
-        """twl_level_commit_from_dp: paths[i] is None -> pair i's path is the DP output in HBM, path_len[i] long."""
+    def restore(self, params: api.TwlParams, pairs: Sequence[int], out_stride: int) -> np.ndarray:
+        """twl_level_restore: gappy columns back into the DP paths of `pairs`, on the device; returns their final lengths (-1: host must do it)."""
+        sel = np.asarray(list(pairs), dtype=np.int32)
+        out = np.zeros(max(1, len(sel)), dtype=np.int32)
+        api._check(_lib().twl_level_restore(self._h, C.byref(params), C.c_int32(len(sel)), sel.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(out_stride),
+                                            out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[: len(sel)]
+
+    def read_final(self, pair: int, length: int) -> np.ndarray:
+        out = np.zeros(max(1, length), dtype=np.int8)
+        api._check(_lib().twl_level_read_final(self._h, C.c_int32(pair), out.ctypes.data_as(C.POINTER(C.c_int8)), C.c_int32(length)))
+        return out[:length]
+
+    def commit_from_dp(self, paths: Sequence[Optional[np.ndarray]], path_len: Sequence[int], stride: Optional[int] = None, restored: Sequence[int] = ()):
+        """twl_level_commit_from_dp: paths[i] is None -> pair i's path is in HBM already (the DP output, or what twl_level_restore made of it), path_len[i] long."""
         n = self._n_pairs
-        stride = max([1] + [int(x) for x in path_len])
+        stride = int(stride) if stride else max([1] + [int(x) for x in path_len])
         flat = np.zeros((n, stride), dtype=np.int8)
         plen = np.asarray(path_len, dtype=np.int32).copy()
         from_dp = np.zeros(n, dtype=np.uint8)
         for i, p in enumerate(paths):
-            if p is None: from_dp[i] = 1 if plen[i] > 0 else 0
+            if p is None: from_dp[i] = (2 if i in set(restored) else 1) if plen[i] > 0 else 0
             else: flat[i, : len(p)] = p
         api._check(_lib().twl_level_commit_from_dp(self._h, flat.ctypes.data_as(C.POINTER(C.c_int8)), plen.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(stride),
                                                    from_dp.ctypes.data_as(C.POINTER(C.c_uint8))))
