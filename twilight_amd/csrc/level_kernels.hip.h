@@ -108,6 +108,26 @@ __device__ inline int block_scan_256(bool flag, int *total, int *s_wave /*[4]*/)
     return base + before;
 }
 
+// exclusive prefix sum of one int per thread over a 256-thread workgroup; *total = the sum
+__device__ __forceinline__ int block_scan_int_256(int v, int *total, int *s_wave)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    int base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; if (w < wave) base += c; sum += c; }
+    *total = sum;
+    return base + x - v;
+}
+
 // grid: 2 * n_pairs workgroups of 256 threads; a workgroup walks its side in 256-column chunks with a running output index.
 template <int P>
 __global__ void __launch_bounds__(256) compact_kernel(LevelArgs a)
@@ -189,22 +209,31 @@ __global__ void __launch_bounds__(256) path_scan_kernel(CommitArgs a)
     }
 }
 
-// grid: (n_work, n_chunks), 256 threads: one 256-column chunk of the new rows for a group of members of one side.
-// New row: letter of the old row where the path keeps this side (code 0 or the side's own code), '-' elsewhere
-// (alignment-helper.cpp:389-400, 436-447).
+// grid: (n_work, ceil(n_chunks / 4)), 256 threads: 1024 columns of the new rows for a group of members of one side, four columns
+// (one 32-bit store) per thread.  New row: letter of the old row where the path keeps this side (code 0 or the side's own code), '-'
+// elsewhere (alignment-helper.cpp:389-400, 436-447).  Rows start at multiples of the planes' pitch (a multiple of 256): the stores
+// are aligned; bytes behind the path's end within the last word are padding of the row's capacity.
 __global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
 {
     __shared__ int s_wave[4];
     const int32_t *w = a.work + (size_t)blockIdx.x * 3;
     const int side = w[0], pair = side >> 1, isQ = side & 1;
     const int n = a.path_len[pair];
-    const int c0 = blockIdx.y * 256;
+    const int c0 = blockIdx.y * 1024;
     if (c0 >= n) return;
-    const int c = c0 + threadIdx.x;
-    const int code = (c < n) ? a.paths[(size_t)pair * a.path_stride + c] : 3;
-    const bool keep = (code == 0) || (code == (isQ ? 1 : 2));
+    const int c = c0 + 4 * threadIdx.x;
+    const int own = isQ ? 1 : 2;
+    const int8_t *path = a.paths + (size_t)pair * a.path_stride;
+    bool keep[4];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int code = (c + k < n) ? path[c + k] : 3;
+        keep[k] = (code == 0) || (code == own);
+        cnt += keep[k] ? 1 : 0;
+    }
     int tot;
-    const int src = a.chunk_base[((size_t)pair * a.n_chunks + blockIdx.y) * 2 + isQ] + block_scan_256(keep, &tot, s_wave);
+    int src = a.chunk_base[((size_t)pair * a.n_chunks + 4 * blockIdx.y) * 2 + isQ] + block_scan_int_256(cnt, &tot, s_wave);
     if (c >= n) return;
     const SideDesc sd = a.sides[side];
     for (int m = w[1]; m < w[1] + w[2]; ++m) {
@@ -213,7 +242,15 @@ __global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
         const bool pl = a.member_plane[mi];
         const char *from = (pl ? a.rows1 : a.rows0) + off;
         char *to = (pl ? a.rows0 : a.rows1) + off;
-        to[c] = keep ? from[src] : '-';
+        uint32_t word = 0;
+        int sidx = src;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ch = keep[k] ? (uint32_t)(uint8_t)from[sidx] : (uint32_t)'-';
+            sidx += keep[k] ? 1 : 0;
+            word |= ch << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(to + c) = word;
     }
 }
 

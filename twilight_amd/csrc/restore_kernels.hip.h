@@ -42,32 +42,12 @@ struct RestoreArgs {
     int8_t *out;              // [n_pairs][out_stride] final paths
     int32_t out_stride;
     int32_t *out_len;         // [n_pairs] final length; -1 = the host has to restore this pair
-    int8_t *tbs;              // [grid * 256][kNwCells] per-thread traceback scratch
-    float *rows;              // [grid * 256][6 * kNwRow] per-thread rolling rows
+    int8_t *tbs;              // [n_sel * nb * 256][kNwCells] per-thread traceback scratch of restore_align_kernel
+    float *rows;              // [n_sel * nb * 256][6 * kNwRow] per-thread rolling rows
     float M[441];             // scoringMatrix[a][b], row-major ms x ms
     int32_t ms;
     float gap_open, gap_extend;
 };
-
-// exclusive prefix sum of one int per thread over a 256-thread workgroup; *total = the sum
-__device__ __forceinline__ int block_scan_int_256(int v, int *total, int *s_wave)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) s_wave[wave] = x;
-    __syncthreads();
-    int base = 0, sum = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = s_wave[w]; if (w < wave) base += c; sum += c; }
-    *total = sum;
-    return base + x - v;
-}
 
 // grid: 2 * n_sel workgroups of 256 threads: original index of every kept column of one side (+ the side's original length as a sentinel)
 __global__ void __launch_bounds__(256) restore_index_kernel(RestoreArgs a)
@@ -131,7 +111,8 @@ __global__ void __launch_bounds__(256) restore_runs_kernel(RestoreArgs a)
     if (threadIdx.x == 0) a.out_len[pair] = s_wave[0] ? -1 : 0;
 }
 
-// grid: n_sel workgroups: every two-sided boundary aligned by one thread (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322)
+// grid: (n_sel, nb) workgroups: every two-sided boundary aligned by one thread (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322);
+// the boundaries of a pair are dealt to the nb * 256 threads of its workgroups (thousands of small alignments per pair at the top of a tree)
 __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
 {
     const int pair = a.sel[blockIdx.x];
@@ -142,11 +123,12 @@ __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
     const int32_t *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
     const uint8_t *cR = a.colinfo + (size_t)(2 * pair) * a.stride, *cQ = cR + a.stride;
     int8_t *arena = a.arena + (size_t)blockIdx.x * a.out_stride;
-    int8_t *tb = a.tbs + ((size_t)blockIdx.x * 256 + threadIdx.x) * kNwCells;
-    float *rw = a.rows + ((size_t)blockIdx.x * 256 + threadIdx.x) * (6 * kNwRow);
+    const size_t thr = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
+    int8_t *tb = a.tbs + thr * kNwCells;
+    float *rw = a.rows + thr * (6 * kNwRow);
     const float go = a.gap_open, ge = a.gap_extend;
     const int ms = a.ms;
-    for (int b = threadIdx.x; b <= n; b += 256) {
+    for (int b = blockIdx.y * 256 + threadIdx.x; b <= n; b += 256 * gridDim.y) {
         if (seg[b] >= 0) continue;
         const int m = runR[b], nn = runQ[b];
         const uint8_t *s1 = cR + stR[b], *s2 = cQ + stQ[b];

@@ -560,8 +560,9 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return rc;
     if ((rc = lv->r_outlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
-    if ((rc = lv->r_tb.ensure(ns * 256 * (size_t)twl::kNwCells))) return rc;
-    if ((rc = lv->r_rows.ensure(ns * 256 * 6 * (size_t)twl::kNwRow * sizeof(float)))) return rc;
+    const unsigned nb = (unsigned)std::max(1, std::min(32, 1024 / n_sel));      // workgroups per pair of the small alignments (<= ~1.8 GB of scratch)
+    if ((rc = lv->r_tb.ensure(ns * nb * 256 * (size_t)twl::kNwCells))) return rc;
+    if ((rc = lv->r_rows.ensure(ns * nb * 256 * 6 * (size_t)twl::kNwRow * sizeof(float)))) return rc;
     twl::RestoreArgs a{};
     a.aln = (const int8_t *)lv->d_aln.p; a.aln_len = (const int32_t *)lv->d_alnlen.p; a.aln_stride = (int32_t)(2 * sl);
     a.colinfo = (const uint8_t *)lv->d_colinfo.p; a.stride = s->seq_len;
@@ -576,7 +577,7 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     a.gap_open = p->gap_open; a.gap_extend = p->gap_extend;
     hipLaunchKernelGGL(twl::restore_index_kernel, dim3(2 * (unsigned)n_sel), dim3(256), 0, st, a);
     hipLaunchKernelGGL(twl::restore_runs_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel, nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> all((size_t)n);
@@ -709,7 +710,7 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     a.merge_w = (const float *)s->lv->d_mergew.p;
     hipLaunchKernelGGL(twl::path_scan_kernel, dim3((unsigned)n), dim3(256), 0, st, a);
     const unsigned nWork = (unsigned)(work.size() / 3), nMerge = (unsigned)(merge.size() / 4);
-    if (nWork) hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)nChunks), dim3(256), 0, st, a);
+    if (nWork) hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)((nChunks + 3) / 4)), dim3(256), 0, st, a);
     if (nMerge) {
         if (s->P == 6) hipLaunchKernelGGL(twl::merge_cache_kernel<6>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(twl::merge_cache_kernel<22>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
