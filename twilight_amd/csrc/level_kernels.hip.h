@@ -49,47 +49,71 @@ struct LevelArgs {
     float gap_open, gap_extend, scale, min_gap_open, min_gap_extend;   // calculatePSGP constants (:171-176)
 };
 
-// grid: (2 * n_pairs, ceil(stride / 256)), 256 threads; thread = one column of one side.
+// grid: (2 * n_pairs, ceil(stride / 1024)), 256 threads; thread = FOUR consecutive columns of one side: one 32-bit load per member row
+// (rows start at multiples of the planes' pitch, a multiple of 256; bytes behind a row's length are '-' padding and are not stored),
+// so the per-member table reads are shared by four columns.  Members are visited in the reference's order: the fp32 sums round identically.
 template <int P>
 __global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
 {
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = a.lut[threadIdx.x];
+    __syncthreads();
     const int side = blockIdx.x;
     const SideDesc sd = a.sides[side];
-    const int t = blockIdx.y * 256 + threadIdx.x;
-    if (t >= sd.len) return;
-    float acc[P];
+    const int t0 = 4 * (blockIdx.y * 256 + threadIdx.x);
+    if (t0 >= sd.len) return;
+    const int nc = min(4, sd.len - t0);
+    float acc[4][P];
 #pragma unroll
-    for (int v = 0; v < P; ++v) acc[v] = 0.0f;
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < P; ++v) acc[k][v] = 0.0f;
     const float fnum = (float)sd.num;
     if (sd.cache_slot >= 0) {                                            // :16-21  msaFreq / weight * num
-        const float *c = a.cache[sd.cache_slot] + (size_t)t * P;
+        const float *c = a.cache[sd.cache_slot] + (size_t)t0 * P;
 #pragma unroll
-        for (int v = 0; v < P; ++v) acc[v] = c[v] / sd.weight * fnum;
+        for (int k = 0; k < 4; ++k)
+            if (k < nc) {
+#pragma unroll
+                for (int v = 0; v < P; ++v) acc[k][v] = c[k * P + v] / sd.weight * fnum;
+            }
     } else {                                                             // :23-34  member by member
         for (int m = 0; m < sd.n_members; ++m) {
             const int mi = sd.member_off + m;
             const char *row = (a.member_plane[mi] ? a.rows1 : a.rows0) + (size_t)a.member_seq[mi] * a.cap;
-            const int li = a.lut[(uint8_t)row[t]];
+            const uint32_t four = *reinterpret_cast<const uint32_t *>(row + t0);
             const float w = a.member_w[mi];
 #pragma unroll
-            for (int v = 0; v < P; ++v) acc[v] += (li == v) ? w : 0.0f;    // x + 0 is exact (accumulators are never -0)
+            for (int k = 0; k < 4; ++k) {
+                const int li = s_lut[(four >> (8 * k)) & 0xFFu];
+#pragma unroll
+                for (int v = 0; v < P; ++v) acc[k][v] += (li == v) ? w : 0.0f;    // x + 0 is exact (accumulators are never -0)
+            }
         }
         if (sd.store_slot >= 0) {                                        // :35-40  cache = profile / num * weight
-            float *c = a.cache[sd.store_slot] + (size_t)t * P;
+            float *c = a.cache[sd.store_slot] + (size_t)t0 * P;
 #pragma unroll
-            for (int v = 0; v < P; ++v) c[v] = acc[v] / fnum * sd.weight;
+            for (int k = 0; k < 4; ++k)
+                if (k < nc) {
+#pragma unroll
+                    for (int v = 0; v < P; ++v) c[k * P + v] = acc[k][v] / fnum * sd.weight;
+                }
         }
     }
-    float *dst = a.raw + ((size_t)side * a.stride + t) * P;
+    float *dst = a.raw + ((size_t)side * a.stride + t0) * P;
 #pragma unroll
-    for (int v = 0; v < P; ++v) dst[v] = acc[v];
-    int best = P - 2;                                                    // getConsensus: first strict maximum, all-zero -> N / X
-    float bestCount = 0.0f;
+    for (int k = 0; k < 4; ++k) {
+        if (k >= nc) continue;
 #pragma unroll
-    for (int v = 0; v < P - 2; ++v)
-        if (acc[v] > bestCount) { bestCount = acc[v]; best = v; }
-    const bool gappy = (acc[P - 1] / fnum > a.gappy_thr);                // :84,105
-    a.colinfo[(size_t)side * a.stride + t] = (uint8_t)(best | (gappy ? 0x80 : 0));
+        for (int v = 0; v < P; ++v) dst[k * P + v] = acc[k][v];
+        int best = P - 2;                                                // getConsensus: first strict maximum, all-zero -> N / X
+        float bestCount = 0.0f;
+#pragma unroll
+        for (int v = 0; v < P - 2; ++v)
+            if (acc[k][v] > bestCount) { bestCount = acc[k][v]; best = v; }
+        const bool gappy = (acc[k][P - 1] / fnum > a.gappy_thr);         // :84,105
+        a.colinfo[(size_t)side * a.stride + t0 + k] = (uint8_t)(best | (gappy ? 0x80 : 0));
+    }
 }
 
 // Workgroup-wide exclusive scan of one flag per thread (256 threads = 4 waves); returns the thread's offset, *total = sum.

@@ -402,7 +402,7 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     a.min_gap_open = p->gap_open * 0.1;                                  // :175
     int32_t maxLen = 1;
     for (size_t i = 0; i < ns; ++i) maxLen = std::max(maxLen, sides[i].len);
-    const dim3 gridP((unsigned)ns, (unsigned)((maxLen + 255) / 256));
+    const dim3 gridP((unsigned)ns, (unsigned)((maxLen + 1023) / 1024));
     if (s->P == 6) {
         hipLaunchKernelGGL(twl::profile_kernel<6>, gridP, dim3(256), 0, st, a);
         hipLaunchKernelGGL(twl::compact_kernel<6>, dim3((unsigned)ns), dim3(256), 0, st, a);
