@@ -116,6 +116,12 @@ int twl_align_batch_device(int device, void *stream, const twl_params *p, int32_
 void *twl_host_alloc(uint64_t bytes);
 void  twl_host_free(void *p);
 
+/* Plain synchronous copies between host memory and memory of `device` (for callers that hold device pointers of the library -- the exchange
+   blocks of twl_level.h -- but do not link the HIP runtime themselves).  2-D form: `rows` rows of `width` bytes, pitches in bytes. */
+int twl_copy_to_device(int device, void *dst_dev, const void *src, uint64_t bytes);
+int twl_copy_from_device(int device, void *dst, const void *src_dev, uint64_t bytes);
+int twl_copy_rows_from_device(int device, void *dst, uint64_t dst_pitch, const void *src_dev, uint64_t src_pitch, uint64_t width, uint64_t rows);
+
 int twl_get_stats(int device, twl_stats *out);
 
 /* Per-pair band-cell counts of the last call on `device` (n entries, host buffer). */

@@ -102,6 +102,20 @@ int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, cons
  * DP left it).  May be called several times per level (after each twl_level_align of a gap-character group), always with one out_stride.
  */
 int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out);
+/*
+ * Final paths between processes without leaving HBM (several processes align one family, include/twl_msa.h): after twl_level_restore
+ * (n_sel may be 0: it fixes the row pitch of the level's path buffer) a rank packs the final paths of ITS pairs into one contiguous device
+ * block, hands the block to a device all-gather, and unpacks the other ranks' paths into their rows of the path buffer; the commit then
+ * takes every row from HBM (from_dp[i] == 2).
+ *   twl_level_exchange_buffers  device scratch for the blocks (grow-only, owned by the level): send_bytes, recv_bytes
+ *   twl_level_paths_to_block    row of pair pairs[t] (where[t] == 1: as the DP left it, 2: from the path buffer), lens[t] bytes -> blk + blk_off[t]
+ *   twl_level_paths_from_block  blk + blk_off[t], lens[t] bytes -> the path-buffer row of pair pairs[t]
+ *   twl_level_write_final       a path the host restored (twl_level_restore returned -1 for it) into its row of the path buffer
+ */
+int twl_level_exchange_buffers(twl_store *s, int64_t send_bytes, int64_t recv_bytes, void **send_dev, void **recv_dev);
+int twl_level_paths_to_block(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, const uint8_t *where, void *blk_dev, const int64_t *blk_off);
+int twl_level_paths_from_block(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, const void *blk_dev, const int64_t *blk_off);
+int twl_level_write_final(twl_store *s, int32_t pair, const int8_t *path, int32_t len);
 /* Diagnostics: the first `len` codes of pair `pair`'s row of the staged path buffer (after twl_level_restore). */
 int twl_level_read_final(twl_store *s, int32_t pair, int8_t *out, int32_t len);
 

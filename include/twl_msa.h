@@ -62,6 +62,12 @@ int  twl_msa_open(int argc, const char *const *argv, twl_msa **out);
    `rank` and gets the others' paths through `exchange` once per level (twilight_amd/dist.py: torch.distributed all_gather, backend
    nccl = RCCL over xGMI on GPUs, gloo in CPU tests).  Call before twl_msa_align; world == 1 is the default. */
 int  twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange, void *user);
+/* The same with an all-gather of DEVICE blocks (send_dev / recv_dev live in the HBM of this process's GPU; same signature): the
+   device-resident level kernel then keeps every path in HBM from the DP to the write-back -- one collective per level and no host
+   staging (twilight_amd/dist.py: make_device_exchange, RCCL over xGMI).  The library has synchronised its stream before the call; the
+   collective must have completed when the function returns.  `exchange` (host blocks) may be given too: the host-staged level kernel
+   (--host-staged, and the deferred pass) uses it. */
+int  twl_msa_shard_device(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange_dev, void *user_dev, twl_msa_exchange_fn exchange, void *user);
 /* Device-resident path: put the sequences into HBM now (otherwise the first level does it). */
 int  twl_msa_upload(twl_msa *m);
 /* The progressive alignment: every level of the main pass and the deferred pass. */

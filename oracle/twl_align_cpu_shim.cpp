@@ -62,5 +62,15 @@ int twl_level_read_paths(twl_store *, int32_t, const int32_t *, const int32_t *,
 int twl_level_read_colinfo_many(twl_store *, int32_t, const int32_t *, uint8_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_read_columns(twl_store *, int32_t, int32_t, float *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_timing(twl_store *, double *, double *) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_restore(twl_store *, const twl_params *, int32_t, const int32_t *, int32_t, int32_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_read_final(twl_store *, int32_t, int8_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_exchange_buffers(twl_store *, int64_t, int64_t, void **, void **) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_paths_to_block(twl_store *, int32_t, const int32_t *, const int32_t *, const uint8_t *, void *, const int64_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_paths_from_block(twl_store *, int32_t, const int32_t *, const int32_t *, const void *, const int64_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_write_final(twl_store *, int32_t, const int8_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_copy_to_device(int, void *, const void *, uint64_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_copy_from_device(int, void *, const void *, uint64_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_copy_rows_from_device(int, void *, uint64_t, const void *, uint64_t, uint64_t, uint64_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_set_knob(int, int) { return TWL_ERR_UNSUPPORTED; }
 
 }  // extern "C"

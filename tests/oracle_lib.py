@@ -101,3 +101,40 @@ def column_score(params: Params, r, q, denom):
     r = np.ascontiguousarray(r, dtype=np.float32)
     q = np.ascontiguousarray(q, dtype=np.float32)
     return float(lib().twlo_column_score(C.byref(params), _fp(r), _fp(q), C.c_float(denom)))
+
+
+_FLIB = None
+
+
+def faithful_lib():
+    """oracle/libtwl_faithful.so: the checker's algorithm in the reference's data layout and allocation pattern (what bench.py times as the
+    reference's own code); held to the checker bit for bit by tests/test_oracle_cpu.py."""
+    global _FLIB
+    if _FLIB is None:
+        so = os.path.join(ORACLE_DIR, "libtwl_faithful.so")
+        src = os.path.join(ORACLE_DIR, "talco_faithful.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libtwl_faithful.so"], stdout=subprocess.DEVNULL)
+        _FLIB = C.CDLL(so)
+        _FLIB.twlf_align_batch.restype = C.c_int
+    return _FLIB
+
+
+def align_batch_faithful(params: Params, batch, threads: int = 1):
+    """Same outputs as align_batch (paths, lengths, error codes) + the band-cell count, from the reference-layout restatement."""
+    n, sl = batch.n_pairs, batch.seq_len
+    aln = np.zeros((n, 2 * sl), dtype=np.int8)
+    aln_len = np.zeros(n, dtype=np.int32)
+    err = np.zeros(n, dtype=np.int16)
+    cells = C.c_uint64(0)
+    freq = np.ascontiguousarray(batch.freq, dtype=np.float32)
+    go = np.ascontiguousarray(batch.gap_open, dtype=np.float32)
+    ge = np.ascontiguousarray(batch.gap_extend, dtype=np.float32)
+    ln = np.ascontiguousarray(batch.len, dtype=np.int32)
+    nm = np.ascontiguousarray(batch.num, dtype=np.int32)
+    rc = faithful_lib().twlf_align_batch(C.byref(params), C.c_int32(n), C.c_int32(sl), _fp(freq), _fp(go), _fp(ge),
+                                         ln.ctypes.data_as(C.POINTER(C.c_int32)), nm.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         aln.ctypes.data_as(C.POINTER(C.c_int8)), aln_len.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         err.ctypes.data_as(C.POINTER(C.c_int16)), C.c_int32(threads), C.byref(cells))
+    assert rc == 0
+    return aln, aln_len, err, int(cells.value)

@@ -1,0 +1,76 @@
+"""N > 1 on the hardware there is: TWO processes share ONE MI355X (both on cuda:0), deal the pairs of every level between them, align
+their shares with the device-resident level kernel and exchange the paths (gloo between the processes: RCCL refuses two ranks on one
+device).  Expected: every rank writes the MSA of the independent replay's fixture (tests/golden/e2e_variants.json) and the band cells
+of the two ranks add up to the fixture's.  Families with gappy-column runs, deferred pairs, cached profiles and compressed groups."""
+import hashlib
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from variants import VARIANTS, write_family  # noqa: E402
+
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_variants.json")))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exchange):
+    sys.path.insert(0, ROOT)
+    os.environ.update(env)                      # (the thresholds are read when the host library loads)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from twilight_amd import dist as tdist
+    from twilight_amd import msa
+
+    out = os.path.join(out_dir, f"rank{rank}.aln")
+    m = msa.Msa(["-t", tree, "-i", fasta, "-o", out, "--type", typ, "--gpu-index", "0"] + list(flags))
+    if device_exchange:
+        # device blocks for every level of the main pass; host blocks for the deferred pass (host-staged level kernel)
+        m.shard(rank, world, tdist.make_exchange(None), exchange_device=tdist.make_device_exchange(torch.device("cuda:0")))
+    else:
+        m.shard(rank, world, tdist.make_exchange(None))
+    m.upload()
+    m.align()
+    tot, levels = m.report()
+    m.write()
+    m.close()
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([tot.band_cells, tot.pairs, tot.n_levels] + [lv.pairs for lv in levels], dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("device_exchange", [False, True])
+@pytest.mark.parametrize("name", ["nuc_default", "nuc_r0.7", "nuc_deferrals_cache_compress", "nuc_length_deviation_filter", "prot_cache_and_compress"])
+def test_two_processes_on_one_gpu_write_the_fixture_msa(built, tmp_path, name, device_exchange):
+    import torch.multiprocessing as mp
+
+    _, fam, ins, flags, env = [v for v in VARIANTS if v[0] == name][0]
+    d = str(tmp_path)
+    t, f, typ = write_family(d, fam, ins)
+    mp.start_processes(_worker, args=(2, _free_port(), t, f, d, typ, flags, env, device_exchange), nprocs=2, join=True, start_method="spawn")
+    fx = FIX[name]
+    for rank in range(2):
+        assert hashlib.md5(open(os.path.join(d, f"rank{rank}.aln"), "rb").read()).hexdigest() == fx["md5"], f"rank {rank}"
+        rep = np.load(os.path.join(d, f"rank{rank}.npy"))
+        assert int(rep[0]) == fx["band_cells"], f"rank {rank}: band cells (sum over the ranks of every level)"
+        assert list(rep[3:3 + len(fx["pairs_per_level"])]) == fx["pairs_per_level"]

@@ -113,3 +113,30 @@ def test_psgp_matches_reference_formula():
     assert go[1] == np.float32(min(np.float32(-5.0), np.float32(-25.0 * (3.0 / 4.0))))
     assert ge[2] == np.float32(min(np.float32(-1.0), np.float32(-5.0 * (1.5 / 4.0))))
     assert go[3] == np.float32(-5.0)      # tiny remaining fraction clamps to 0.1*gapOpen
+
+
+@pytest.mark.parametrize("kind", ["nuc", "nuc_profiles", "prot", "small_marker", "err2", "err1"])
+def test_reference_layout_restatement_equals_the_checker(kind):
+    """oracle/talco_faithful.cpp (vector<vector<float>>, 14 new[] per tile, AVX2 masked loads -- the reference's layout and allocation
+    pattern, timed by bench.py as the reference's own code) against the checker: paths, error codes, band cells."""
+    from twilight_amd import synth
+
+    pk = {}
+    if kind == "prot":
+        M, batch = synth.protein_matrix(), synth.make_level_batch(4, 300, P=22, members=((1, 5), (1, 5)), seed=5, sub=0.2)
+    else:
+        M = synth.nucleotide_matrix()
+        members = (1, 1) if kind in ("nuc", "err2", "err1") else ((2, 6), (1, 4))
+        batch = synth.make_level_batch(5, 700, members=members, seed=17, **({"sub": 0.75, "indel": 0.05} if kind == "err1" else {}))
+        if kind == "small_marker": pk = dict(marker=100)
+        if kind == "err2": pk = dict(flen=96)
+        if kind == "err1": pk = dict(xdrop=40)
+    p = O.make_params(M, **pk)
+    a, n, e, st = O.align_batch(p, batch, threads=2)
+    fa, fn, fe, cells = O.align_batch_faithful(p, batch, threads=2)
+    assert np.array_equal(e, fe) and np.array_equal(n, fn)
+    for i in range(batch.n_pairs):
+        assert np.array_equal(a[i, : n[i]], fa[i, : fn[i]]), f"pair {i}"
+    assert cells == st.cells
+    if kind == "err2": assert (e == 2).any()
+    if kind == "err1": assert (e == 1).any()

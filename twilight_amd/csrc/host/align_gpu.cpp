@@ -142,6 +142,83 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
     rec.exchange_ms += nowMs() - t0;
 }
 
+void exchangeFinalPaths(RunCtx &ctx, twl_store *store, int device, const twl_params &tp, const std::vector<int> &owner, const std::vector<char> &takesPart,
+                        const std::vector<int32_t> &bound, int pathStride, std::vector<uint8_t> &fromDp, std::vector<int32_t> &dpLen, std::vector<int16_t> &errs,
+                        LevelRecord &rec)
+{
+    const Shard &sh = ctx.shard;
+    const double t0 = nowMs();
+    auto die = [](const char *what, int rc) { std::cerr << "ERROR: " << what << " failed (" << rc << "): " << twl_last_error() << '\n'; exit(1); };
+    constexpr uint64_t kBlockMagic = 0x54574C44ull << 32;      // "TWLD"
+    const int n = (int)owner.size(), world = sh.world;
+    std::vector<std::vector<int>> mine(world);
+    for (int i = 0; i < n; ++i) if (takesPart[i]) mine[owner[i]].push_back(i);
+    auto pad8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    // block of rank r: {band cells, relaunched, kernel ms, magic | level} + {length, errorType} per pair of r + the paths, each padded to 8
+    std::vector<size_t> hdr(world);
+    size_t blockMax = 0, hdrMax = 0;
+    for (int r = 0; r < world; ++r) {
+        hdr[r] = 32 + 8 * mine[r].size();
+        size_t cap = hdr[r];
+        for (int i : mine[r]) cap += pad8((size_t)bound[i]);
+        blockMax = std::max(blockMax, cap); hdrMax = std::max(hdrMax, hdr[r]);
+    }
+    blockMax = (blockMax + 255) & ~(size_t)255;
+    int rc = twl_level_restore(store, &tp, 0, nullptr, pathStride, nullptr);      // (fixes the row pitch of the path buffer if no pair was restored)
+    if (rc != TWL_OK) die("twl_level_restore", rc);
+    void *send = nullptr, *recv = nullptr;
+    if ((rc = twl_level_exchange_buffers(store, (int64_t)blockMax, (int64_t)(blockMax * (size_t)world), &send, &recv)) != TWL_OK) die("twl_level_exchange_buffers", rc);
+    const std::vector<int> &me = mine[sh.rank];
+    {
+        std::vector<char> h(hdr[sh.rank]);
+        uint64_t h4[4] = {rec.band_cells, rec.relaunched, 0, kBlockMagic | (uint64_t)(uint32_t)ctx.levels.size()};
+        memcpy(&h4[2], &rec.kernel_ms, sizeof(double));
+        memcpy(h.data(), h4, sizeof h4);
+        std::vector<int32_t> prs, lens;
+        std::vector<uint8_t> where;
+        std::vector<int64_t> off;
+        size_t at = hdr[sh.rank];
+        for (size_t t = 0; t < me.size(); ++t) {
+            const int i = me[t];
+            const int32_t len = (errs[i] == 0 && fromDp[i]) ? dpLen[i] : 0, e = errs[i];
+            memcpy(&h[32 + 8 * t], &len, 4); memcpy(&h[32 + 8 * t + 4], &e, 4);
+            if (len > 0) { prs.push_back(i); lens.push_back(len); where.push_back(fromDp[i]); off.push_back((int64_t)at); at += pad8((size_t)len); }
+        }
+        if (at > blockMax) { std::cerr << "ERROR: final paths longer than their bound.\n"; exit(1); }
+        if ((rc = twl_copy_to_device(device, send, h.data(), h.size())) != TWL_OK) die("twl_copy_to_device", rc);
+        if ((rc = twl_level_paths_to_block(store, (int32_t)prs.size(), prs.data(), lens.data(), where.data(), send, off.data())) != TWL_OK) die("twl_level_paths_to_block", rc);
+    }
+    const int xrc = sh.exchangeDev(sh.userDev, send, (int64_t)blockMax, recv);
+    if (xrc != 0) { std::cerr << "ERROR: device exchange of the level's paths failed (" << xrc << ").\n"; exit(1); }
+    std::vector<char> hb(hdrMax * (size_t)world);
+    if ((rc = twl_copy_rows_from_device(device, hb.data(), hdrMax, recv, blockMax, hdrMax, (uint64_t)world)) != TWL_OK) die("twl_copy_rows_from_device", rc);
+    rec.band_cells = 0; rec.relaunched = 0;
+    double kmax = 0;
+    std::vector<int32_t> prs, lens;
+    std::vector<int64_t> off;
+    for (int r = 0; r < world; ++r) {
+        const char *blk = &hb[hdrMax * (size_t)r];
+        uint64_t h4[4]; memcpy(h4, blk, sizeof h4);
+        if (h4[3] != (kBlockMagic | (uint64_t)(uint32_t)ctx.levels.size())) { std::cerr << "ERROR: path block of rank " << r << " does not belong to this level.\n"; exit(1); }
+        double km; memcpy(&km, &h4[2], sizeof(double));
+        rec.band_cells += h4[0]; rec.relaunched += h4[1]; kmax = std::max(kmax, km);
+        size_t at = hdr[r];
+        for (size_t t = 0; t < mine[r].size(); ++t) {
+            const int i = mine[r][t];
+            int32_t len, e; memcpy(&len, blk + 32 + 8 * t, 4); memcpy(&e, blk + 32 + 8 * t + 4, 4);
+            if (len < 0 || len > bound[i] || at + pad8((size_t)len) > blockMax) { std::cerr << "ERROR: malformed path block from rank " << r << ".\n"; exit(1); }
+            if (r != sh.rank) {
+                errs[i] = (int16_t)e; dpLen[i] = len; fromDp[i] = len > 0 ? 2 : 0;
+                if (len > 0) { prs.push_back(i); lens.push_back(len); off.push_back((int64_t)(blockMax * (size_t)r + at)); }
+            }
+            at += pad8((size_t)len);
+        }
+    }
+    if ((rc = twl_level_paths_from_block(store, (int32_t)prs.size(), prs.data(), lens.data(), recv, off.data())) != TWL_OK) die("twl_level_paths_from_block", rc);
+    rec.kernel_ms = kmax;
+    rec.exchange_ms += nowMs() - t0;
+}
+
 const std::vector<int> &selectedDevices() { return g_devices; }
 
 static std::future<std::pair<int, std::string>> g_initJob;   // (return code, twl_last_error() of the helper thread)

@@ -29,6 +29,14 @@ std::vector<int> dealPairs(const std::vector<long long> &cost, const std::vector
 // All-gather of the paths the ranks aligned: on return paths/errs hold every pair of the level on every rank.
 void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector<char> &takesPart, int pathCap, std::vector<alnPath> &paths,
                    std::vector<int16_t> &errs, LevelRecord &rec);
+// The same for the device-resident level kernel when the processes can all-gather DEVICE blocks (Shard::exchangeDev): every rank's final
+// paths (gappy columns already restored, in the store's path buffer / DP output) are packed into one device block, all-gathered, and the
+// other ranks' paths unpacked into their rows of the path buffer -- HBM to HBM, one collective per level.  bound[i] = refLen + qryLen of
+// pair i before removal (every rank knows it: the block size is agreed on without a collective).  On return fromDp / dpLen / errs describe
+// every pair of the level on every rank (fromDp 2 = row in the path buffer).
+void exchangeFinalPaths(RunCtx &ctx, twl_store *store, int device, const twl_params &tp, const std::vector<int> &owner, const std::vector<char> &takesPart,
+                        const std::vector<int32_t> &bound, int pathStride, std::vector<uint8_t> &fromDp, std::vector<int32_t> &dpLen, std::vector<int16_t> &errs,
+                        LevelRecord &rec);
 const std::vector<int> &selectedDevices();
 twl_params baseParams(Params &param);          // == Talco_xdrop::Params(msa::Params&), TALCO-XDrop.cpp:36-53
 inline double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -283,7 +283,10 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     // One device, one process: the paths never leave HBM -- pairs that lost no column commit their DP path as it is, the others get their
     // columns back on the device (twl_level_restore); the column info comes to the host only for a pair the device hands back (below).
     const bool procs = ctx.shard.world > 1;
-    const bool inPlace = (nd == 1 && !procs && !ctx.shard.exchange);
+    // ... and so it is with several processes when they can all-gather device blocks (Shard::exchangeDev): each rank restores its own
+    // pairs on its device, the final paths travel HBM to HBM (exchangeFinalPaths below), every rank commits all of them from HBM.
+    const bool devX = (nd == 1 && ctx.shard.exchangeDev != nullptr);
+    const bool inPlace = (nd == 1 && ((!procs && !ctx.shard.exchange) || devX));
     auto infoOf = [&](const std::vector<int> &which) {      // consensus + removed runs of these pairs, one synchronisation
         uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * which.size() * stride));
         const int rc = twl_level_read_colinfo_many(g_store, (int32_t)which.size(), which.data(), info);
@@ -335,6 +338,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<uint64_t> cellsOf(nd, 0), redoOf(nd, 0);
     std::vector<char> needsHost(n, 0);
     for (int i : needInfo) needsHost[i] = 1;
+    std::vector<int> handedBack;             // in-place mode: pairs the device handed back to the host (twl_level_restore returned -1)
     std::vector<uint8_t> fromDp(n, 0);       // 1: the DP path is the final path; 2: twl_level_restore made the final path, in HBM
     std::vector<int32_t> dpLen(n, 0);
     int pathStride = 1;                      // row pitch of the final paths: refLen + qryLen before removal bounds every path
@@ -380,6 +384,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             }
             if (!fetch.empty()) {               // the pairs the host has to edit: their column info and paths only
                 infoOf(std::vector<int>(fetch.begin(), fetch.end()));
+                handedBack.insert(handedBack.end(), fetch.begin(), fetch.end());
                 int8_t *blk = reinterpret_cast<int8_t *>(g_alnStage[d].get(fetch.size() * (size_t)2 * stride));
                 const int r2 = twl_level_read_paths(g_stores[d], (int32_t)fetch.size(), fetch.data(), fetchLen.data(), blk, 2 * stride);
                 if (r2 != TWL_OK) return r2;
@@ -406,7 +411,33 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     rec.kernel_ms = *std::max_element(kernMs.begin(), kernMs.end());
     for (uint64_t c : cellsOf) rec.band_cells += c;
     for (uint64_t c : redoOf) rec.relaunched += c;
-    exchangePaths(ctx, owner, takesPart, 2 * stride, paths, errs, rec);             // several processes: everybody gets every path
+    // gappy columns back on the host for one pair (alignment-helper.cpp:324-375)
+    auto restoreOnHost = [&](int i, alnPath &full) {
+        PairState &s = ps[i];
+        int alnRef = 0, alnQry = 0;
+        for (auto a : paths[i]) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
+        alignment_helper::addGappyColumnsBack(paths[i], full, s.gappy, param, {alnRef, alnQry}, s.consensus);
+        alnRef = alnQry = 0;
+        for (auto a : full) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
+        if (alnRef != s.refLen) std::cout << "R: Post " << nodes[i].first->identifier << "(" << alnRef << "/" << s.refLen << ")\n";
+        if (alnQry != s.qryLen) std::cout << "Q: Post " << nodes[i].second->identifier << "(" << alnQry << "/" << s.qryLen << ")\n";
+        if ((int)full.size() > pathStride) { std::cerr << "ERROR: path longer than both profiles together.\n"; exit(1); }
+    };
+    for (int i : handedBack) {                // (rare: a two-sided run too large for the device) the host's result joins the others in HBM
+        if (errs[i] != 0 || paths[i].empty()) continue;
+        alnPath full;
+        restoreOnHost(i, full);
+        const int rc = twl_level_write_final(g_store, i, full.data(), (int32_t)full.size());
+        if (rc != TWL_OK) die("twl_level_write_final", rc);
+        fromDp[i] = 2; dpLen[i] = (int32_t)full.size();
+        paths[i].clear();
+    }
+    if (devX) {                               // HBM to HBM
+        std::vector<int32_t> bound(n);
+        for (int i = 0; i < n; ++i) bound[i] = ps[i].refLen + ps[i].qryLen;
+        exchangeFinalPaths(ctx, g_store, g_storeDev[0], tp, owner, takesPart, bound, pathStride, fromDp, dpLen, errs, rec);
+    }
+    else exchangePaths(ctx, owner, takesPart, 2 * stride, paths, errs, rec);             // several processes: everybody gets every path
     std::vector<int> fallbackPairs;
     for (int i = 0; i < n; ++i) {
         if (errs[i] == 0) continue;
@@ -435,14 +466,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             continue;
         }
         alnPath full;
-        int alnRef = 0, alnQry = 0;
-        for (auto a : paths[i]) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
-        alignment_helper::addGappyColumnsBack(paths[i], full, s.gappy, param, {alnRef, alnQry}, s.consensus);
-        alnRef = alnQry = 0;
-        for (auto a : full) { if (a != 1) ++alnRef; if (a != 2) ++alnQry; }
-        if (alnRef != s.refLen) std::cout << "R: Post " << nodes[i].first->identifier << "(" << alnRef << "/" << s.refLen << ")\n";
-        if (alnQry != s.qryLen) std::cout << "Q: Post " << nodes[i].second->identifier << "(" << alnQry << "/" << s.qryLen << ")\n";
-        if ((int)full.size() > pathStride) { std::cerr << "ERROR: path longer than both profiles together.\n"; exit(1); }
+        restoreOnHost(i, full);
         std::copy(full.begin(), full.end(), &finalPaths[(size_t)i * pathStride]);
         finalLen[i] = (int32_t)full.size();
     }

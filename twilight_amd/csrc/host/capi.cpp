@@ -78,6 +78,17 @@ int twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange,
     return 0;
 }
 
+int twl_msa_shard_device(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange_dev, void *user_dev, twl_msa_exchange_fn exchange, void *user)
+{
+    if (!exchange_dev) { g_msaErr = "bad argument"; return -2; }
+    const int rc = twl_msa_shard(m, rank, world, exchange ? exchange : exchange_dev, user);      // (validation, thread share)
+    if (rc) return rc;
+    msa::progressive::gpu::Shard sh;
+    sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user; sh.exchangeDev = exchange_dev; sh.userDev = user_dev;
+    msa::progressive::gpu::setShard(m->db, sh);
+    return 0;
+}
+
 int twl_msa_upload(twl_msa *m)
 {
     if (!m) { g_msaErr = "bad argument"; return -2; }

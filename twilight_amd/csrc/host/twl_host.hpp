@@ -258,7 +258,9 @@ struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relau
 // send = this rank's block, recv = [world][bytes_per_rank]; returns 0 on success).  twilight_amd/dist.py provides it over
 // torch.distributed (backend nccl = RCCL over xGMI on GPUs, gloo in the CPU tests).
 using ExchangeFn = int (*)(void *user, const void *send, int64_t bytes_per_rank, void *recv);
-struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *user = nullptr; };
+// exchangeDev: the same all-gather on DEVICE buffers (this process's GPU); with it the device-resident level kernel keeps the paths in
+// HBM end to end (align -> gappy columns back -> pack -> all-gather -> unpack -> write-back)
+struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *user = nullptr; ExchangeFn exchangeDev = nullptr; void *userDev = nullptr; };
 // Per-run state of the level kernels; hangs off SequenceDB::gpuCtx so that several runs can live in one process.
 struct RunCtx;
 RunCtx &ctxOf(SequenceDB *database);

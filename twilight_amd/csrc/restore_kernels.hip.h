@@ -194,4 +194,21 @@ __global__ void __launch_bounds__(256) restore_write_kernel(RestoreArgs a)
     if (threadIdx.x == 0) a.out_len[pair] = (base <= a.out_stride) ? base : -1;
 }
 
+// ---- paths between the level's buffers and one contiguous device block (the exchange between processes) ----
+// grid: n rows, 256 threads: row t = len[t] bytes at base + row_off[t]  <->  blk + blk_off[t]
+__global__ void __launch_bounds__(256) rows_to_block_kernel(const int8_t *base, const int64_t *row_off, const int32_t *len, int8_t *blk, const int64_t *blk_off)
+{
+    const int t = blockIdx.x;
+    const int8_t *src = base + row_off[t];
+    int8_t *dst = blk + blk_off[t];
+    for (int i = threadIdx.x; i < len[t]; i += 256) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) block_to_rows_kernel(int8_t *base, const int64_t *row_off, const int32_t *len, const int8_t *blk, const int64_t *blk_off)
+{
+    const int t = blockIdx.x;
+    int8_t *dst = base + row_off[t];
+    const int8_t *src = blk + blk_off[t];
+    for (int i = threadIdx.x; i < len[t]; i += 256) dst[i] = src[i];
+}
+
 }  // namespace twl

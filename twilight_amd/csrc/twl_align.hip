@@ -984,6 +984,45 @@ void twl_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
+int twl_copy_to_device(int device, void *dst_dev, const void *src, uint64_t bytes)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    if (bytes == 0) return TWL_OK;
+    if (!dst_dev || !src) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    HIP_TRY(hipSetDevice(d->id));
+    HIP_TRY(hipMemcpy(dst_dev, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return TWL_OK;
+}
+
+int twl_copy_from_device(int device, void *dst, const void *src_dev, uint64_t bytes)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    if (bytes == 0) return TWL_OK;
+    if (!dst || !src_dev) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    HIP_TRY(hipSetDevice(d->id));
+    HIP_TRY(hipMemcpy(dst, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
+int twl_copy_rows_from_device(int device, void *dst, uint64_t dst_pitch, const void *src_dev, uint64_t src_pitch, uint64_t width, uint64_t rows)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    if (width == 0 || rows == 0) return TWL_OK;
+    if (!dst || !src_dev || dst_pitch < width || src_pitch < width) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    HIP_TRY(hipSetDevice(d->id));
+    HIP_TRY(hipMemcpy2D(dst, (size_t)dst_pitch, src_dev, (size_t)src_pitch, (size_t)width, (size_t)rows, hipMemcpyDeviceToHost));
+    return TWL_OK;
+}
+
 int twl_set_knob(int key, int value)
 {
     std::lock_guard<std::mutex> lk(g_mu);

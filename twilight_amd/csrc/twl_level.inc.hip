@@ -25,11 +25,12 @@ struct LevelBufs {
     Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
     Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew;
     Buf r_sel, r_oidx, r_run, r_seg, r_aoff, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
+    Buf x_send, x_recv, x_rowoff, x_blkoff, x_len;                                  // exchange of final paths between processes (device blocks)
     bool busy = false;
     void release_all()
     {
         for (Buf *b : {&d_sides, &d_mseq, &d_mw, &d_mplane, &d_tab, &d_raw, &d_colinfo, &d_cols, &d_len, &d_lenmask, &d_num, &d_aln, &d_alnlen, &d_err,
-                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_arena, &r_outlen, &r_tb, &r_rows})
+                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
             b->release();
     }
 };
@@ -534,7 +535,7 @@ int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, cons
 // pairs[t], or -1 when that pair holds a two-sided run too large for the device (the caller restores it on the host, as before).
 int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out)
 {
-    if (!s || !s->prepared || !s->lv || !s->lv->d_aln.p) { g_err = "twl_level_align has not been called"; return TWL_ERR_BAD_ARGUMENT; }
+    if (!s || !s->prepared || !s->lv || (n_sel > 0 && !s->lv->d_aln.p)) { g_err = "twl_level_align has not been called"; return TWL_ERR_BAD_ARGUMENT; }
     int rc = check_params(p);
     if (rc) return rc;
     const int32_t n = s->n_pairs;
@@ -587,6 +588,74 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     return TWL_OK;
 }
 
+// ---- the staged path buffer and contiguous device blocks (exchange of final paths between processes, include/twl_level.h) ----
+int twl_level_exchange_buffers(twl_store *s, int64_t send_bytes, int64_t recv_bytes, void **send_dev, void **recv_dev)
+{
+    if (!s || !s->prepared || !s->lv || send_bytes < 0 || recv_bytes < 0 || !send_dev || !recv_dev) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    int rc;
+    if ((rc = s->lv->x_send.ensure(std::max<size_t>((size_t)send_bytes, 64)))) return rc;
+    if ((rc = s->lv->x_recv.ensure(std::max<size_t>((size_t)recv_bytes, 64)))) return rc;
+    *send_dev = s->lv->x_send.p; *recv_dev = s->lv->x_recv.p;
+    return TWL_OK;
+}
+
+static int level_rows_block(twl_store *s, bool toBlock, int32_t n_sel, const int32_t *pairs, const int32_t *lens, const uint8_t *where, void *blk_dev, const int64_t *blk_off)
+{
+    if (!s || !s->prepared || !s->lv || !s->staged_stride || n_sel < 0 || (n_sel > 0 && (!pairs || !lens || !blk_dev || !blk_off))) { g_err = "bad argument (twl_level_restore first)"; return TWL_ERR_BAD_ARGUMENT; }
+    if (n_sel == 0) return TWL_OK;
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    LevelBufs *lv = s->lv;
+    const size_t sl2 = 2 * (size_t)s->seq_len, ps = (size_t)s->staged_stride;
+    // rows of the DP output (where[t] == 1; only as a source) and rows of the staged path buffer (2), one launch per buffer
+    for (int which = 1; which <= 2; ++which) {
+        std::vector<int64_t> ro, bo;
+        std::vector<int32_t> ln;
+        for (int32_t t = 0; t < n_sel; ++t) {
+            const int w = where ? where[t] : 2;
+            if (w != which || lens[t] <= 0) continue;
+            if (pairs[t] < 0 || pairs[t] >= s->n_pairs || (size_t)lens[t] > (which == 1 ? sl2 : ps) || (which == 1 && !toBlock)) { g_err = "bad row selection"; return TWL_ERR_BAD_ARGUMENT; }
+            ro.push_back((int64_t)pairs[t] * (int64_t)(which == 1 ? sl2 : ps)); bo.push_back(blk_off[t]); ln.push_back(lens[t]);
+        }
+        if (ro.empty()) continue;
+        int rc;
+        if ((rc = upload(lv->x_rowoff, ro, st))) return rc;
+        if ((rc = upload(lv->x_blkoff, bo, st))) return rc;
+        if ((rc = upload(lv->x_len, ln, st))) return rc;
+        int8_t *base = (int8_t *)(which == 1 ? lv->d_aln.p : lv->d_paths.p);
+        if (toBlock) hipLaunchKernelGGL(twl::rows_to_block_kernel, dim3((unsigned)ro.size()), dim3(256), 0, st, (const int8_t *)base, (const int64_t *)lv->x_rowoff.p, (const int32_t *)lv->x_len.p, (int8_t *)blk_dev, (const int64_t *)lv->x_blkoff.p);
+        else hipLaunchKernelGGL(twl::block_to_rows_kernel, dim3((unsigned)ro.size()), dim3(256), 0, st, base, (const int64_t *)lv->x_rowoff.p, (const int32_t *)lv->x_len.p, (const int8_t *)blk_dev, (const int64_t *)lv->x_blkoff.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));      // (the host vectors above go out of scope; the caller hands the block to a collective next)
+    }
+    return TWL_OK;
+}
+
+int twl_level_paths_to_block(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, const uint8_t *where, void *blk_dev, const int64_t *blk_off)
+{
+    return level_rows_block(s, true, n_sel, pairs, lens, where, blk_dev, blk_off);
+}
+
+int twl_level_paths_from_block(twl_store *s, int32_t n_sel, const int32_t *pairs, const int32_t *lens, const void *blk_dev, const int64_t *blk_off)
+{
+    return level_rows_block(s, false, n_sel, pairs, lens, nullptr, const_cast<void *>(blk_dev), blk_off);
+}
+
+int twl_level_write_final(twl_store *s, int32_t pair, const int8_t *path, int32_t len)
+{
+    if (!s || !s->prepared || !s->lv || !s->staged_stride || pair < 0 || pair >= s->n_pairs || len < 0 || len > s->staged_stride || (len > 0 && !path)) { g_err = "bad argument (twl_level_restore first)"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    if (len) HIP_TRY(hipMemcpy((int8_t *)s->lv->d_paths.p + (size_t)pair * (size_t)s->staged_stride, path, (size_t)len, hipMemcpyHostToDevice));
+    return TWL_OK;
+}
+
 int twl_level_read_final(twl_store *s, int32_t pair, int8_t *out, int32_t len)
 {
     if (!s || !s->prepared || !out || pair < 0 || pair >= s->n_pairs || len < 0 || !s->lv || !s->staged_stride || len > s->staged_stride) { g_err = "bad argument (twl_level_restore first)"; return TWL_ERR_BAD_ARGUMENT; }
@@ -615,7 +684,7 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if (from_dp && !staged) for (int32_t i = 0; i < n; ++i) if (from_dp[i] == 2) { g_err = "from_dp == 2 without twl_level_restore"; return TWL_ERR_BAD_ARGUMENT; }
     if (from_dp) {
         for (int32_t i = 0; i < n; ++i) {
-            if (from_dp[i] && (!s->lv || !s->lv->d_aln.p || path_len[i] > 2 * s->seq_len)) { g_err = "from_dp without a DP output of this level"; return TWL_ERR_BAD_ARGUMENT; }
+            if (from_dp[i] == 1 && (!s->lv || !s->lv->d_aln.p || path_len[i] > 2 * s->seq_len)) { g_err = "from_dp without a DP output of this level"; return TWL_ERR_BAD_ARGUMENT; }
             if (!from_dp[i] && path_len[i] > 0 && !paths) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
         }
     }

@@ -49,6 +49,39 @@ def reduce_report(cells: float, seconds: float, device=None):
     return float(t_c.item()), float(t_s.item())
 
 
+class _DevBuf:
+    """A device pointer of the C++ side as an object torch.as_tensor understands (CUDA array interface, zero copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def make_device_exchange(device):
+    """The all-gather of DEVICE blocks a sharded twl_msa run calls once per level (include/twl_msa.h, twl_msa_shard_device):
+    exchange(send_dev_ptr, bytes_per_rank, recv_dev_ptr) -> 0, recv = [world][bytes_per_rank] in the HBM of `device`.  Backend nccl
+    (= RCCL over xGMI): ONE all_gather_into_tensor on the library's own buffers, nothing touches the host.  Backend gloo (tests: two
+    processes sharing one GPU, which RCCL refuses): the blocks bounce through host tensors inside this function."""
+    import torch
+    import torch.distributed as dist
+
+    def exchange(send_ptr, nbytes, recv_ptr):
+        world = dist.get_world_size()
+        with torch.cuda.device(device):
+            send = torch.as_tensor(_DevBuf(send_ptr, nbytes), device=device)
+            recv = torch.as_tensor(_DevBuf(recv_ptr, nbytes * world), device=device)
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(recv, send)
+            else:
+                h = send.cpu()
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, h)
+                recv.copy_(torch.cat(parts))
+            torch.cuda.synchronize(device)          # the library's stream is not torch's: the collective is complete when we return
+        return 0
+
+    return exchange
+
+
 def make_exchange(device=None):
     """The all-gather a sharded twl_msa run calls once per level: exchange(send_ptr, bytes_per_rank, recv_ptr) -> 0.
     send/recv are host buffers of the C++ side (recv = [world][bytes_per_rank]).  With a CUDA/HIP `device` (backend nccl) the

@@ -25,7 +25,7 @@ class MsaTotals(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
-_SYMBOLS = ["twl_msa_open", "twl_msa_shard", "twl_msa_upload", "twl_msa_align", "twl_msa_report", "twl_msa_write", "twl_msa_close",
+_SYMBOLS = ["twl_msa_open", "twl_msa_shard", "twl_msa_shard_device", "twl_msa_upload", "twl_msa_align", "twl_msa_report", "twl_msa_write", "twl_msa_close",
             "twl_msa_last_error"]
 _libs = {}
 
@@ -72,23 +72,30 @@ class Msa:
         if rc != 0:
             raise MsaError(f"{what} failed ({rc}): {self._lib.twl_msa_last_error().decode()}")
 
-    def shard(self, rank: int, world: int, exchange: Optional[Callable[[int, int, int], int]]):
+    def shard(self, rank: int, world: int, exchange: Optional[Callable[[int, int, int], int]], exchange_device: Optional[Callable[[int, int, int], int]] = None):
         """Align this family together with `world` - 1 other processes.  `exchange(send_ptr, bytes_per_rank, recv_ptr) -> 0` is an
-        all-gather of host blocks (twilight_amd.dist.make_exchange)."""
-        if world > 1 or exchange is not None:
+        all-gather of host blocks (twilight_amd.dist.make_exchange); `exchange_device` the same on device pointers
+        (twilight_amd.dist.make_device_exchange): with it the device-resident level kernel keeps the paths in HBM end to end."""
+        def wrap(fn):
             def _cb(user, send, nbytes, recv):
                 # ctypes swallows exceptions raised inside a callback and hands the C side an undefined return value: every failure
                 # must come back as a non-zero code, which the host library turns into a fatal error of the run
                 try:
-                    return int(exchange(send, nbytes, recv))
+                    return int(fn(send, nbytes, recv))
                 except BaseException as ex:  # noqa: BLE001
                     import sys
                     import traceback
                     traceback.print_exc()
                     print(f"twilight_amd: the exchange callback failed: {ex!r}", file=sys.stderr, flush=True)
                     return 1
+            return EXCHANGE_FN(_cb)
 
-            self._cb = EXCHANGE_FN(_cb)
+        if exchange_device is not None:
+            self._cb_dev = wrap(exchange_device)
+            self._cb = wrap(exchange) if exchange is not None else C.cast(None, EXCHANGE_FN)
+            self._check(self._lib.twl_msa_shard_device(self._h, rank, world, self._cb_dev, None, self._cb, None), "twl_msa_shard_device")
+        elif world > 1 or exchange is not None:
+            self._cb = wrap(exchange)
             self._check(self._lib.twl_msa_shard(self._h, rank, world, self._cb, None), "twl_msa_shard")
         return self
 
