@@ -48,7 +48,7 @@ CONFIGS = {
     "rnasim1k_band512": dict(kind="level", pairs=320, length=1600, type="n", P=6, bcell=64, flen=512, xdrop=4000,
                              name="RNASim-shaped 1k seqs x 1.6 kbp: the leaf level (320 sibling pairs) as ONE batch, fLen 512 / xdrop 4000 (BASELINE configs[1])"),
 }
-PMC = os.path.join(ROOT, "profiles", "r02", "bench_pmc_summary.json")
+PMC = os.path.join(ROOT, "profiles", "r03", "bench_pmc_summary.json")
 
 
 def parse():
@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-peak", action="store_true", help="skip the single-level peak leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-final-MSA leg (product CLI as a child process)")
     ap.add_argument("--keep", default="", help="directory for the generated family (kept)")
+    ap.add_argument("--workload", default="calibrated", choices=["calibrated", "survey8d"],
+                    help="family parameters: calibrated on the reference's RNASim sample (default), or SURVEY.md 8d as written (per-branch substitution U(0.03, 0.10), "
+                         "indel 0.005/site, seed 20260501 + config index)")
     return ap.parse_args()
 
 
@@ -90,7 +93,10 @@ def cpu_model():
 
 def write_family(cfg, d):
     sys.setrecursionlimit(1000000)
-    nwk, seqs = synth.make_family(cfg["leaves"], cfg["length"], P=cfg["P"], seed=20260501, sub=cfg["sub"], indel=cfg["indel"])
+    if cfg.get("workload") == "survey8d":
+        nwk, seqs = synth.make_family(cfg["leaves"], cfg["length"], P=cfg["P"], seed=20260501 + cfg["index"], indel=0.005, sub_range=(0.03, 0.10))
+    else:
+        nwk, seqs = synth.make_family(cfg["leaves"], cfg["length"], P=cfg["P"], seed=20260501, sub=cfg["sub"], indel=cfg["indel"])
     tree, fasta = os.path.join(d, "t.nwk"), os.path.join(d, "s.fa")
     with open(tree, "w") as f:
         f.write(nwk + "\n")
@@ -104,7 +110,8 @@ def cpu_baseline(batch, matrix, pk, gpu_paths, gpu_lens, target_seconds=12.0):
     """The oracle ("port" of the reference CPU path; OpenMP over pairs like tbb::parallel_for at alignment-cpu.cpp:46) timed on this
     box's host cores, all usable cores and one: a bounded sample of wide-level pairs of the workload's shape, the very pairs the GPU
     aligned in the peak leg, and the paths are compared while we are at it.  The reference's own code, with its vector<vector<float>>
-    layout and 14 allocations per tile, ran at 1.6e7 cells/s/core: this flat-array port is the stronger baseline."""
+    layout, 14 allocations per tile and AVX2 masked loads, is restated in oracle/talco_faithful.cpp (held to the checker bit for bit by
+    tests/test_oracle_cpu.py) and timed here as well, on a share of the sample: `reference_layout`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
@@ -130,12 +137,24 @@ def cpu_baseline(batch, matrix, pk, gpu_paths, gpu_lens, target_seconds=12.0):
     t0 = time.perf_counter()
     _, _, _, st1 = O.align_batch(p, sub(np.arange(k1) % n), threads=1)
     dt1 = time.perf_counter() - t0
+    # the reference's layout and allocation pattern (SURVEY 8d "faithful" mode), measured on this box: all threads, then one
+    kf = max(len(cal), k // 3)
+    t0 = time.perf_counter()
+    fa, fl, fe, fcells = O.align_batch_faithful(p, sub(np.arange(kf) % n), threads=threads)
+    dtf = time.perf_counter() - t0
+    same = bool(all(fl[i] == ln[i] and np.array_equal(fa[i, : fl[i]], aln[i, : ln[i]]) for i in range(min(kf, k))))
+    t0 = time.perf_counter()
+    _, _, _, fcells1 = O.align_batch_faithful(p, sub(np.arange(k1) % n), threads=1)
+    dtf1 = time.perf_counter() - t0
     return {"value": st.cells / dt, "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "one_thread_value": st1.cells / dt1,
             "sample": f"{k} pairs of ~{batch.seq_len}-column profiles of this workload's shape ({st.cells} band cells) in {dt:.1f} s on {threads} threads "
                       f"(OpenMP over pairs); 1 thread: {k1} pairs in {dt1:.1f} s",
-            "reference_code_cells_per_s_per_core": 1.6e7,
-            "note": "flat-array restatement of the reference CPU path (oracle/talco_oracle.c); faster per core than the reference's own code (BASELINE.md section 2)",
+            "reference_layout": {"value": fcells / dtf, "one_thread_value": fcells1 / dtf1, "unit": "cells/s", "cores": threads,
+                                 "sample": f"{kf} of those pairs in {dtf:.1f} s on {threads} threads; 1 thread: {k1} pairs in {dtf1:.1f} s", "paths_equal_to_port": same,
+                                 "note": "oracle/talco_faithful.cpp: the same algorithm with the reference's data layout and allocation pattern (vector<vector<float>> "
+                                         "profiles, 14 new[] per tile, AVX2 masked loads; TALCO-XDrop.cpp:279-312,378-395), measured on this box"},
+            "note": "flat-array restatement of the reference CPU path (oracle/talco_oracle.c)",
             "gpu_paths_equal_on_sample": parity}
 
 
@@ -212,6 +231,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     cfg = dict(CONFIGS[args.config])
+    cfg["workload"] = args.workload
+    cfg["index"] = {"rnasim1k_band512": 1, "rnasim10k": 2, "rnasim100k": 3, "protein5k": 4}[args.config]      # BASELINE.json configs[] index
     if args.leaves:
         cfg["leaves"] = args.leaves
     if args.length:
@@ -331,10 +352,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": cfg["name"] + (f"; synthetic family: random root evolved down a random binary tree, per-branch substitution {cfg['sub']} x U(0.5,1.5), "
-                                           f"indel rate {cfg['indel']}/site (calibrated on the reference's RNASim sample: band avg 310-420, max ~640 at 10 kbp; milder than "
-                                           f"SURVEY 8d's 0.03-0.10 / 0.005); scoring = CLI defaults (18/-8/-4 or 5xBLOSUM62, gap -50/-5, xdrop 5000, marker 1024, fLen 4096)"
-                                           if family else ""),
+                "workload": cfg["name"] + ((f"; synthetic family: random root evolved down a random binary tree, per-branch substitution {cfg['sub']} x U(0.5,1.5), "
+                                            f"indel rate {cfg['indel']}/site (calibrated on the reference's RNASim sample: band avg 310-420, max ~640 at 10 kbp; milder than "
+                                            f"SURVEY 8d's 0.03-0.10 / 0.005, which --workload survey8d runs)" if args.workload == "calibrated" else
+                                            f"; synthetic family exactly as SURVEY.md 8d: per-branch substitution U(0.03, 0.10), indel 0.005/site, geometric lengths of mean 3, seed 20260501 + {cfg['index']}")
+                                           + "; scoring = CLI defaults (18/-8/-4 or 5xBLOSUM62, gap -50/-5, xdrop 5000, marker 1024, fLen 4096)" if family else ""),
+                "family_parameters": args.workload,
                 "name": args.config,
             },
         }
@@ -363,15 +386,26 @@ def main():
         else:
             out["config"].update(peak)
             kernels, dom = [], None
-        traffic = None
+        traffic = issue = None
         try:
-            traffic = json.load(open(PMC))["hbm_per_pass"]["traffic_bytes"]
+            pmc = json.load(open(PMC))
+            traffic = pmc["hbm_per_pass"]["traffic_bytes"]
+            # what binds this path: instruction issue along the anti-diagonal chain, not HBM; per kernel of the
+            # profiled run: VALU issue slots used (a wave's VALU instruction holds its SIMD for 2 cycles), scalar instructions per cycle
+            # and CU (the scalar unit retires ~1), wave-cycles spent waiting, and the HBM rate the counters saw
+            issue = {"source": "profiles/r03/bench_pmc_summary.json (tools/summarize_pmc.py: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAIT_ANY / SQ_WAVE_CYCLES / "
+                               "FETCH_SIZE / WRITE_SIZE passes and the kernel trace of this command)",
+                     "ceiling": "valu_issue_frac 1.0 = every VALU issue slot of the 1024 SIMDs used; salu_per_cycle_per_cu ~1.0 = scalar unit saturated",
+                     "kernels": [{"kernel": k.replace("void twl::", "").replace("(twl::NArgs)", ""), **{f: round(float(v[f]), 4) for f in
+                                  ("valu_issue_frac", "salu_per_cycle_per_cu", "wait_frac_of_wave_cycles", "active_inst_frac_of_wave_cycles", "hbm_gb_per_s", "seconds_in_run") if f in v}}
+                                 for k, v in sorted(pmc.get("issue_per_kernel", {}).items(), key=lambda kv: -kv[1].get("seconds_in_run", 0.0))]}
         except Exception:
             pass
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_live": False,
-            "traffic_source": "profiles/r02/bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per pass; FETCH_SIZE doubled per MI355X_MICROARCH.md)" if traffic else None,
+            "traffic_source": "profiles/r03/bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per pass; FETCH_SIZE doubled per MI355X_MICROARCH.md)" if traffic else None,
+            "issue": issue,
             "algorithmic_bytes_per_cell": bcell, "cells": int(cells // steps), "kernel_ms": kernel_ms / steps,
             "dominant_kernel": dom, "kernels": kernels,
             "note": "achieved = band cells x algorithmic operand bytes per cell / DP-kernel time over ALL launches of a pass (every level of the family); the operand "

@@ -408,7 +408,8 @@ def test_one_profile_entry_outside_the_fast_division_range(gpu, where):
         else: f[n, 1, 0, 0] = np.float32(1e-12)
     b2 = synth.LevelBatch(P=batch.P, seq_len=batch.seq_len, freq=f, gap_open=batch.gap_open, gap_extend=batch.gap_extend, len=batch.len, num=batch.num)
     _compare(gpu, b2)
-    assert gpu.get_stats(0).n_relaunched == len(pairs)
+    # (an entry that large can also widen the band past the 1024-row window first: such a pair is re-run twice, window then division)
+    assert gpu.get_stats(0).n_relaunched in (len(pairs), 2 * len(pairs))
 
 
 def _replicated(batch, n):

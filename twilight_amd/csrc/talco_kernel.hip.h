@@ -30,6 +30,7 @@ constexpr int kIB = -2;   // I_BOUNDARY, TALCO-XDrop.cpp:33
 constexpr int kDB = -3;   // D_BOUNDARY, TALCO-XDrop.cpp:34
 constexpr int kMaxMarker = 1024;
 constexpr int kErrOverflow = -1;   // internal: band outgrew this kernel's row window -> relaunch wide
+constexpr int kErrGuard = -2;      // internal: an operand outside the hoisted-reciprocal division's range -> relaunch on the IEEE-division kernel
 
 struct KArgs {
     const float *cols;        // packed columns [pair][2][seq_len][P+2]: f0..f(P-1), gapOpen, gapExtend (32 B for P=6, 96 B for P=22)

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         // The row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits -- TILE-local values, so sequences of any length pass
         // (a tile that has not converged after 65 534 diagonals goes to the round-1 kernel, below); the mailbox words of the speculative
         // start carry absolute positions in 16 bits each (the host does not pick that kernel for longer sequences).
-        if (!last_tile && ((SPEC && (R > 65535 || Q > 65535)) || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = kErrOverflow; last_tile = true; }
+        if (!last_tile && ((SPEC && (R > 65535 || Q > 65535)) || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = (denom >= 1.0f && denom <= 1.0995116e12f) ? kErrOverflow : kErrGuard; last_tile = true; }
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
         bool guardBad = false;
         // SPEC: this workgroup runs the tiles of its parity; `confirmed` = the start of the tile in flight is the true one
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 if (guardBad) s_misc[4] = 1;
                 __syncthreads();
                 guardBad = __builtin_amdgcn_readfirstlane(s_misc[4]) != 0;
-                if (guardBad) { err = kErrOverflow; break; }
+                if (guardBad) { err = kErrGuard; break; }
             }
 
             // a tile that ends before the marker leaves its last (partial) group of 8 diagonals unflushed

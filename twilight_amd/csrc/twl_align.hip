@@ -417,7 +417,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
-    bool ranMt = false;
+    bool ranMt = false, leanMid = false;
     const bool force_wide = dev_env("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = dev_env("TWL_FAST_CFG");      // pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
@@ -540,6 +540,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_run <= d->num_cu && maxLen <= 65535 && !dev_env("TWL_NO_SPEC");
         statMode = mm5 ? 5 : mm;
         statSpec = spec ? 1 : 0;
+        leanMid = lean && mm == 2;
         long long sumLen = 0;
         for (int32_t t = 0; t < n_run; ++t) sumLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
         // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the
@@ -602,15 +603,23 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (stage == 1) TRACE("dp kernel done");
+        // first the pairs with an operand outside the fast division's range (lean kernels only): the IEEE-division kernel of the same window
         std::vector<int32_t> redo;
-        for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
+        for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrGuard) redo.push_back(n);
+        const bool guardRound = !redo.empty();
+        if (guardRound) --stage;      // (the window stages follow once these are done)
+        else for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
         if (redo.empty()) break;
         if (force_wide) { g_err = "band wider than the wide window"; return TWL_ERR_UNSUPPORTED; }
         const bool mid = (stage == 1) && (!prot || protSmall);
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
         int grid2 = 0, w2 = 0;
-        if (mid && prot) rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        if (guardRound) rc = prot ? launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2)
+                                  : launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
+        else if (mid && prot) rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        // nucleotide, default matrix structure: the lean kernel on a 2048-row window (8 waves x 4 blocks, reference ring still in LDS)
+        else if (mid && leanMid) rc = launch_lean<6, 8, 4, 2, 2>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         else if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
         else rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         if (rc) return rc;
@@ -621,13 +630,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         ms_redo += ms;
         d->stats.n_launches += 1;
         d->stats.n_relaunched += (int32_t)redo.size();
-        if (!mid) { stage = 2; }
+        if (!mid && !guardRound) { stage = 2; }
     }
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int32_t n = 0; n < n_pairs; ++n)
-        if (h_err[n] == twl::kErrOverflow) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
+        if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
     std::vector<unsigned long long> cells((size_t)n_pairs);
     HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
