@@ -20,7 +20,8 @@ def _family(tmp, f):
     from twilight_amd import synth
 
     sys.setrecursionlimit(1000000)
-    nwk, seqs = synth.make_family(f["leaves"], f["length"], P=f["P"], seed=f["seed"], sub=f["sub"], indel=f["indel"])
+    nwk, seqs = synth.make_family(f["leaves"], f["length"], P=f["P"], seed=f["seed"], indel=f["indel"],
+                                  **({"sub_range": tuple(f["sub_range"])} if f.get("sub_range") else {"sub": f["sub"]}))
     t, fa = os.path.join(tmp, "t.nwk"), os.path.join(tmp, "s.fa")
     open(t, "w").write(nwk + "\n")
     with open(fa, "w") as fh:
@@ -45,7 +46,7 @@ def _run(tree, fasta, out, typ, env=None):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("name", ["rnasim10k", "protein5k"])
+@pytest.mark.parametrize("name", ["rnasim10k", "protein5k", "rnasim10k_survey8d"])
 def test_full_size_configuration_reproduces_the_cpu_checker(built, tmp_path, name):
     if name not in EXP:
         pytest.skip("fixture not generated")
