@@ -13,8 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from variants import VARIANTS, write_family  # noqa: E402
 
-out = {}
+OUT = os.path.join(HERE, "e2e_variants.json")
+only = set(sys.argv[1:])      # names on the command line: regenerate only those, keep the other entries
+out = json.load(open(OUT)) if (only and os.path.exists(OUT)) else {}
 for name, fam, ins, flags, env in VARIANTS:
+    if only and name not in only:
+        continue
     with tempfile.TemporaryDirectory() as d:
         t, f, typ = write_family(d, fam, ins)
         e = dict(os.environ)
@@ -27,4 +31,4 @@ for name, fam, ins, flags, env in VARIANTS:
         out[name] = {"md5": hashlib.md5(open(os.path.join(d, "r.aln"), "rb").read()).hexdigest(), "aln_len": int(kv["aln_len"]), "band_cells": int(kv["band_cells"]),
                      "pairs_per_level": [int(x) for x in kv["pairs_per_level"].split("/")], "deferred_profiles": int(kv["deferred_profiles"]), "retries": int(kv["retries"])}
         print(name, out[name]["md5"], out[name]["deferred_profiles"], out[name]["retries"], flush=True)
-json.dump(out, open(os.path.join(HERE, "e2e_variants.json"), "w"), indent=1)
+json.dump(out, open(OUT, "w"), indent=1)

@@ -25,7 +25,7 @@ def _md5(p):
     return hashlib.md5(open(p, "rb").read()).hexdigest()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("name", [v[0] for v in VARIANTS])
 def test_cpu_checker_equals_independent_replay_and_fixture(built, tmp_path, name):
     _, fam, ins, flags, env = [v for v in VARIANTS if v[0] == name][0]

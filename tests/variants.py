@@ -23,6 +23,10 @@ VARIANTS = [
     ("nuc_deferrals_cache_compress", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, ["--length-deviation", "0.05", "-r", "0.8"],
      {"TWL_TEST_CAL_PROFILE_TH": "2", "TWL_TEST_UPDATE_SEQ_TH": "3"}),
     ("prot_cache_and_compress", dict(leaves=30, length=200, P=22, seed=9, sub=0.1, indel=0.02), None, [], LOW_TH),
+    # families large enough to reach the cached-profile (>= 1000 sequences, msa.hpp:179) and compressed-group (> 1000 members, :180) branches
+    # with the reference's own thresholds: the host mirror at those branches is checked by the independent replay, not only by itself
+    ("nuc_2400_leaves_default_thresholds", dict(leaves=2400, length=600, P=6, seed=31, sub=0.03, indel=0.004), None, [], {}),
+    ("prot_2200_leaves_default_thresholds", dict(leaves=2200, length=220, P=22, seed=33, sub=0.03, indel=0.004), None, [], {}),
     ("nuc_xdrop_failure_retried_in_deferred_pass", dict(leaves=8, length=1200, P=6, seed=3, sub=0.03, indel=0.003), (2, 600, 4500), [], {}),
 ]
 
