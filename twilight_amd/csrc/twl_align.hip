@@ -82,7 +82,9 @@ struct Device {
     bool dump_on = false;
     std::vector<int32_t> dbg_host;
     std::vector<int32_t> mt_jobs_host;
+    std::vector<int16_t> last_err;                                               // error codes of the last run_device call, as read back by it
     int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
+    int mt_launch = 0;                                                           // launches of the tile-parallel level in flight (work counter index)
     char kname[160] = {0};                                                       // the kernel of the first DP launch of the call in flight
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
@@ -240,7 +242,8 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
     int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
     a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
-    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    // (every launch of a tile-parallel level has its own work counter: launch_mt zeroed the 16 of them in one go)
+    a.queue = (int32_t *)d->queue.p + (d->mt_launch++ & 15);
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (grid_out) *grid_out = grid;
@@ -293,6 +296,8 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     HIP_TRY(hipMemsetAsync(d->mt_rec.p, 0, np * slots * twl::kMtRec * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(d->mt_spath.p, 0xFE, np * (size_t)sp_pitch * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(d->mt_stat.p, 0, 4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(d->queue.p, 0, 16 * sizeof(int32_t), st));
+    d->mt_launch = 0;
     twl::NArgs a{};
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
     a.cells = base.cells; a.queue = base.queue; a.items = d_items;
@@ -597,10 +602,18 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 
     // Pairs whose band outgrew a window are re-run, bit-identically, by the next stage: 1024-row fast window ->
     // 2048-row window (16 waves x 2 blocks, LDS ring) -> 4608-row window (covers flen = 4096; columns from L2/HBM).
+    // (error codes, band cells and the tile-parallel counters come back in ONE synchronisation when nothing has to be re-run -- the common case)
     std::vector<int16_t> h_err((size_t)n_pairs);
+    std::vector<unsigned long long> cells((size_t)n_pairs);
+    unsigned long long mtStat[4] = {0, 0, 0, 0};
+    bool reran = false;
     float ms_redo = 0.f;
     for (int stage = 1; stage <= 2; ++stage) {
         HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+        if (!reran) {
+            HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            if (ranMt) HIP_TRY(hipMemcpyAsync(mtStat, d->mt_stat.p, sizeof mtStat, hipMemcpyDeviceToHost, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
         if (stage == 1) TRACE("dp kernel done");
         // first the pairs with an operand outside the fast division's range (lean kernels only): the IEEE-division kernel of the same window
@@ -623,6 +636,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         else if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
         else rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         if (rc) return rc;
+        reran = true;
         HIP_TRY(hipEventRecord(d->ev[4], st));
         HIP_TRY(hipStreamSynchronize(st));
         float ms = 0.f;
@@ -633,21 +647,17 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (!mid && !guardRound) { stage = 2; }
     }
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
-    HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (reran) {
+        HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     for (int32_t n = 0; n < n_pairs; ++n)
         if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
-    std::vector<unsigned long long> cells((size_t)n_pairs);
-    HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
     uint64_t total = 0;
     for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
-    if (ranMt) {
-        unsigned long long ms[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(ms, d->mt_stat.p, sizeof ms, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        d->stats.mt_tiles_predicted = (int32_t)ms[0]; d->stats.mt_tiles_inline = (int32_t)ms[1]; d->stats.mt_scouts_failed = (int32_t)ms[2];
-    }
+    if (ranMt) { d->stats.mt_tiles_predicted = (int32_t)mtStat[0]; d->stats.mt_tiles_inline = (int32_t)mtStat[1]; d->stats.mt_scouts_failed = (int32_t)mtStat[2]; }
+    d->last_err = h_err;      // (twl_level_align hands them to its caller without another copy)
     if (want_dbg) {
         d->dbg_host.resize((size_t)n_pairs * 16);
         HIP_TRY(hipMemcpy(d->dbg_host.data(), d->dbg.p, d->dbg_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1041,7 +1051,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_MIN_MARKER: g_mt_min_marker = std::max(2, value); return TWL_OK;
     case TWL_KNOB_MT_LEAD: g_mt_lead = std::max(16, value); return TWL_OK;
     case TWL_KNOB_MT_MARGIN: g_mt_marg = std::max(2, value); return TWL_OK;
-    case TWL_KNOB_MT_ROUNDS: g_mt_rounds = std::max(1, std::min(8, value)); return TWL_OK;
+    case TWL_KNOB_MT_ROUNDS: g_mt_rounds = std::max(1, std::min(7, value)); return TWL_OK;
     case TWL_KNOB_MT_THR_JOBS: g_mt_thr_jobs = std::max(0, value); return TWL_OK;
     case TWL_KNOB_FAIL_ROW_ALLOCS: g_fail_next_row_allocs = std::max(0, value); return TWL_OK;
     case TWL_KNOB_PROT_MODE: if (value < 0 || value > 6) { g_err = "protein mode 0..6"; return TWL_ERR_BAD_ARGUMENT; } g_prot_mode = value; return TWL_OK;

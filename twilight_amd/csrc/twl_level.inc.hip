@@ -80,6 +80,8 @@ struct twl_store {
     std::vector<twl_side> sides;
     std::vector<int32_t> members;
     std::vector<int32_t> h_len, h_num;
+    std::vector<float> h_mw;                 // host copies that asynchronous uploads read from (kept with the store instead of synchronising)
+    std::vector<int32_t> h_sel, h_pathlen;
     LevelBufs *lv = nullptr;     // the level's device buffers, held from prepare to commit (from the device's pool, see LevelBufs)
     int32_t staged_stride = 0;   // > 0: twl_level_restore put this level's DP paths (and the restored ones) into lv->d_paths at this row pitch
     Buf d_gather, d_off, d_plane, d_rowlen;
@@ -372,7 +374,8 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     HIP_TRY(hipEventRecord(d->ev[0], st));
     if ((rc = upload(s->lv->d_sides, dsides, st))) return rc;
     if ((rc = upload(s->lv->d_mseq, s->members, st))) return rc;
-    { std::vector<float> w(member_weight, member_weight + nm); if ((rc = upload(s->lv->d_mw, w, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    s->h_mw.assign(member_weight, member_weight + nm);
+    if ((rc = upload(s->lv->d_mw, s->h_mw, st))) return rc;
     if ((rc = upload(s->lv->d_mplane, mplane, st))) return rc;
     if ((rc = upload(s->lv->d_tab, tab, st))) return rc;
     if ((rc = upload(s->lv->d_num, s->h_num, st))) return rc;
@@ -471,7 +474,8 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
                     (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(aln_len_out, s->lv->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(err_out, s->lv->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    if ((int32_t)d->last_err.size() == n) std::copy(d->last_err.begin(), d->last_err.end(), err_out);      // (run_device read them back already)
+    else HIP_TRY(hipMemcpyAsync(err_out, s->lv->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     // paths: bulk when most pairs ran, else one copy per pair that has a path
     int32_t ran = 0;
@@ -554,7 +558,8 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     s->staged_stride = out_stride;
     if (n_sel == 0) return TWL_OK;
     const size_t ns = (size_t)n_sel;
-    { std::vector<int32_t> v(pairs, pairs + n_sel); if ((rc = upload(lv->r_sel, v, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    s->h_sel.assign(pairs, pairs + n_sel);
+    if ((rc = upload(lv->r_sel, s->h_sel, st))) return rc;
     if ((rc = lv->r_oidx.ensure(2 * ns * (sl + 1) * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_run.ensure(ns * 4 * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_seg.ensure(ns * bstride * sizeof(int32_t)))) return rc;
@@ -754,7 +759,8 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
             if (!from_dp[i] && path_len[i] > 0)
                 HIP_TRY(hipMemcpyAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
     }
-    { std::vector<int32_t> pl(path_len, path_len + n); if ((rc = upload(s->lv->d_pathlen, pl, st))) return rc; HIP_TRY(hipStreamSynchronize(st)); }
+    s->h_pathlen.assign(path_len, path_len + n);
+    if ((rc = upload(s->lv->d_pathlen, s->h_pathlen, st))) return rc;
     if ((rc = s->lv->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
     if ((rc = upload(s->lv->d_work, work, st))) return rc;
     if ((rc = upload(s->lv->d_merge, merge, st))) return rc;
