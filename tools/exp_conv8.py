@@ -1,0 +1,32 @@
+"""Timing experiment: how much of a level's time is the per-diagonal convergence test of phase C?  Builds a copy of the library in which the
+test runs on every 8th diagonal only (results are WRONG there: timing only) and times a wide level and a lone pair on both.
+    python tools/exp_conv8.py        (GPU box; does not touch the product library)"""
+import os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from twilight_amd import synth, api
+
+so = os.path.join(tempfile.mkdtemp(), "libtwl_exp.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                       "-DTWL_EXP_CONV8", "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
+which = sys.argv[1] if len(sys.argv) > 1 else "exp"
+if which == "exp":
+    api.LIB_PATH = so
+api.init([0])
+dev = torch.device("cuda:0")
+p = api.make_params(synth.nucleotide_matrix())
+for n, mt in ((2048, 1024), (1, 1024), (1, 0), (100, 1024)):
+    api.set_knob(api.KNOB_MT_MAX_PAIRS, mt)
+    b = synth.make_level_batch(min(n, 32), 10000, members=((1, 8), (1, 8)), seed=5)
+    idx = np.arange(n) % b.n_pairs
+    t = lambda a: torch.from_numpy(a[idx]).to(dev)
+    freq, gop, gex, ln, nm = t(b.freq), t(b.gap_open), t(b.gap_extend), t(b.len), t(b.num)
+    aln = torch.zeros((n, 2 * b.seq_len), dtype=torch.int8, device=dev); alen = torch.zeros(n, dtype=torch.int32, device=dev); err = torch.zeros(n, dtype=torch.int16, device=dev)
+    for r in range(3):
+        torch.cuda.synchronize()
+        api.align_batch_device(p, n, b.seq_len, freq.data_ptr(), gop.data_ptr(), gex.data_ptr(), ln.data_ptr(), nm.data_ptr(), aln.data_ptr(), alen.data_ptr(), err.data_ptr())
+        torch.cuda.synchronize()
+        st = api.get_stats(0)
+    print(f"{which}: pairs {n} mt_max {mt}: kernel {st.kernel_ms:.2f} ms, cells {st.band_cells:.4g}, {st.kernel.decode()[:60]}", flush=True)

@@ -13,13 +13,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 so = os.path.join(tempfile.mkdtemp(), "libtwl_stamps.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DTWL_KERNEL_STAMPS", "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
+                       "-DTWL_KERNEL_STAMPS", "-DTWL_DEV", "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
 api.LIB_PATH = so
 os.environ["TWL_DEBUG"] = "1"
 b = synth.make_level_batch(min(n, 32), length, members=((1, 8), (1, 8)), seed=5)
 idx = np.arange(n) % b.n_pairs
 big = synth.LevelBatch(P=b.P, seq_len=b.seq_len, freq=b.freq[idx], gap_open=b.gap_open[idx], gap_extend=b.gap_extend[idx], len=b.len[idx], num=b.num[idx])
 api.init([0])
+api.set_knob(api.KNOB_MT_MAX_PAIRS, 0)      # the plain tile loop, not the tile-parallel path
 api.align_batch(api.make_params(synth.nucleotide_matrix()), big)
 lib = api.load_library()
 lib.twl_debug_read.restype = C.c_int

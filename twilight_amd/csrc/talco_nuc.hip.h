@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         int4 exch[NV];               // mailbox: lane 63 of a block -> lane 0 of the next block {S, I, CS, CI}
         unsigned red[4];             // {running max S (float bits), low-end tag, high-end tag, -}
         int conv[4];                 // {vmin, vmax, flags, -}
+        int edge[2 * NV];            // phase C: CS of the first / last unpruned row of every block (the cheap pre-test of the convergence test)
         int4 trash[64];              // per-lane trash slots: single-lane LDS side effects without touching EXEC
     };
     __shared__ ParBuf s_par[2];
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     __shared__ int8_t s_rev[2 * kMaxMarker + 16];
     __shared__ unsigned long long s_team[4];      // SPEC: {broadcast word, decision of the last poll, best cell of diagonal marker-1, of diagonal marker}
     constexpr unsigned O_CD = (unsigned)offsetof(ParBuf, cd), O_EXCH = (unsigned)offsetof(ParBuf, exch), O_RED = (unsigned)offsetof(ParBuf, red),
-                       O_CONV = (unsigned)offsetof(ParBuf, conv), O_TRASH = (unsigned)offsetof(ParBuf, trash);
+                       O_CONV = (unsigned)offsetof(ParBuf, conv), O_TRASH = (unsigned)offsetof(ParBuf, trash), O_EDGE = (unsigned)offsetof(ParBuf, edge);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -818,6 +819,11 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         lds_max_u32_off<O_RED + 8>((rank == nValid1) ? vcur : vTrashRed, kk16 + (unsigned)i);
                         if constexpr (CONV) lds_st<nuc_i4>(vcur + mbRel[r], nuc_i4{__float_as_int(Sv), __float_as_int(Iv), CS1[r], CI1[r]});
                         else lds_st<nuc_i2>(vcur + mbRel[r], nuc_i2{__float_as_int(Sv), __float_as_int(Iv)});
+                        if constexpr (PH == 2) {       // CS of this block's first / last unpruned row, for the pre-test of the convergence test (below)
+                            const unsigned trashE = vcur + O_TRASH + (unsigned)lane * 16u + 8u;
+                            lds_st<int>((rank == 0) ? vcur + O_EDGE + 8u * (unsigned)(r * W + w) : trashE, CS1[r]);
+                            lds_st<int>((rank == nValid1) ? vcur + O_EDGE + 8u * (unsigned)(r * W + w) + 4u : trashE + 4u, CS1[r]);
+                        }
                         if constexpr (TB) {                                                        // :548-557
                             const uint32_t nib = (isM ? 0u : (gapIsI ? 1u : 2u)) | (Iptr ? 4u : 0u) | (Dptr ? 8u : 0u);
                             tbacc[r] |= nib << (4 * (k & 7));
@@ -878,6 +884,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));
                                 lds_st<nuc_i4>(vprev + O_CONV, nuc_i4{c0, c1, c2, c2});
                             }
+                            // Pre-test (a necessary condition, so the result is unchanged): the surviving band [newL, newU] can only be uniform
+                            // when its two end cells hold the same convergence pointer.  The ends' pointers were left in LDS by their blocks
+                            // before the barrier; two broadcast reads decide.  Until shortly before the tile converges the ends disagree, and
+                            // the test proper -- ballots, three reductions, a second workgroup barrier -- is skipped: conv_S = -1, as it would find.
+                            const int cLo = lds_ld<int>(vcur + O_EDGE + 8u * (((unsigned)newL >> 6) & (unsigned)(NV - 1)));
+                            const int cHi = lds_ld<int>(vcur + O_EDGE + 8u * (((unsigned)newU >> 6) & (unsigned)(NV - 1)) + 4u);
+                            const bool maybe = __builtin_amdgcn_ballot_w64(newL <= newU && cLo == cHi) != 0ull;
+                            if (maybe) {
                             const unsigned cw = (unsigned)(newU - newL);
 #pragma unroll
                             for (int r = 0; r < RPL; ++r) {
@@ -902,6 +916,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             const int vmax = __builtin_amdgcn_readfirstlane(cv.y);
                             const int fl = __builtin_amdgcn_readfirstlane(cv.z);
                             if (vmin == vmax && !(fl & 1)) { conv_S = vmin; all3 = !(fl & 2); }   // (an empty band posts nothing: vmin > vmax)
+                            }
                         }
                         if (all3 && prev_conv_s == conv_S && conv_S != -1) { converged = true; conv_value = prev_conv_s; convf = msp; }
                         prev_conv_s = conv_S;
