@@ -148,7 +148,7 @@ int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq
      TWL_KNOB_MT_LEAD        anti-diagonals a scout starts ahead of its tile boundary (default 320)
      TWL_KNOB_MT_MARGIN      anti-diagonals a scout runs past its tile boundary (default 40)
      TWL_KNOB_MT_ROUNDS      rounds of predict / run / verify before the remaining tiles are computed in line (default 2, at most 7)
-     TWL_KNOB_MT_THR_JOBS    levels with more tiles than this run scouts and tiles on the throughput geometry (default 512)
+     TWL_KNOB_MT_THR_JOBS    levels with more tiles than this run scouts and tiles on the throughput geometry (default 256 = the CUs)
      TWL_KNOB_FAIL_ROW_ALLOCS  the next n device allocations for the row planes of a store (include/twl_level.h) fail: tests of the
                              fallback to the minimal pitch
      TWL_KNOB_PROT_MODE      force a protein kernel variant: 0 auto (default), 1 dense, 2 sparse, 3 precomputed scores, 4 the round-1 kernel,

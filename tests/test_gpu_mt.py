@@ -23,7 +23,7 @@ def knobs(gpu):
     gpu.set_knob(api.KNOB_MT_LEAD, 320)
     gpu.set_knob(api.KNOB_MT_MARGIN, 40)
     gpu.set_knob(api.KNOB_MT_ROUNDS, 2)
-    gpu.set_knob(api.KNOB_MT_THR_JOBS, 512)
+    gpu.set_knob(api.KNOB_MT_THR_JOBS, 256)
 
 
 def _compare(twl, batch, **pk):
@@ -150,7 +150,7 @@ def _compare_p(twl, batch, **pk):
     return st, ost
 
 
-@pytest.mark.parametrize("thr_jobs", [512, 0])
+@pytest.mark.parametrize("thr_jobs", [256, 0])
 def test_protein_tile_parallel(knobs, thr_jobs):
     """5 pairs x ~2500 aa (5-6 tiles each), on either geometry of the scout / tile launches."""
     knobs.set_knob(api.KNOB_MT_THR_JOBS, thr_jobs)
