@@ -116,3 +116,70 @@ def test_deferred_pass_retries_with_flen_above_4096(built, tmp_path):
     assert "Realign profiles that have been deferred" in g.stderr
     assert "Retry pair" in g.stdout                      # the retry really ran with the grown parameters
     assert _md5(out) == _md5(ref)
+
+
+@pytest.mark.timeout(600)
+def test_sharded_run_of_world_size_one_sends_device_blocks_through_rccl(built, tmp_path):
+    """The device exchange (twl_msa_shard_device + twilight_amd.dist.make_device_exchange): ONE all_gather_into_tensor per level on the
+    library's own HBM buffers (wrapped through the CUDA array interface), backend nccl = RCCL.  A 1-rank world drives the code an 8-GPU run drives."""
+    import torch
+    import torch.distributed as dist
+
+    from twilight_amd import dist as tdist
+    from twilight_amd import msa
+
+    tmp = str(tmp_path)
+    tree, fasta = _family(tmp, 60, 800, 6, seed=8, sub=0.05, indel=0.005)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        calls = []
+        ex = tdist.make_device_exchange(torch.device("cuda:0"))
+
+        def counted(send, nbytes, recv):
+            calls.append(nbytes)
+            return ex(send, nbytes, recv)
+
+        out = os.path.join(tmp, "sharded.aln")
+        m = msa.Msa(["-t", tree, "-i", fasta, "-o", out])
+        m.shard(0, 1, tdist.make_exchange(torch.device("cuda:0")), exchange_device=counted)
+        m.upload().align().write()
+        tot, levels = m.report()
+        m.close()
+        assert len(calls) == tot.n_levels and all(c > 32 and c % 256 == 0 for c in calls)      # one collective per level
+    finally:
+        dist.destroy_process_group()
+    ref = os.path.join(tmp, "ref.aln")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "e2e_oracle"), "-t", tree, "-i", fasta, "-o", ref], capture_output=True, text=True)
+    assert r.returncode == 0 and _md5(out) == _md5(ref)
+
+
+@pytest.mark.timeout(600)
+def test_two_sided_run_too_large_for_the_device_is_restored_on_the_host(built, tmp_path):
+    """Two sequences in the two subtrees of the root carry a 150-column insertion at the same place: at the top level both profiles lose
+    a 150-column run at the same step, a 151 x 151 alignment that exceeds the per-thread scratch of the device's addGappyColumnsBack
+    (4096 cells) -- the device hands the pair back and the host mirror restores it; the MSA is the CPU checker's."""
+    import numpy as np
+
+    from twilight_amd import synth
+
+    tmp = str(tmp_path)
+    nwk, seqs = synth.make_family(80, 500, P=6, seed=2, sub=0.04, indel=0.0)      # (seed 2: the root splits 52 / 28; no indels: the two runs meet at one step)
+    rng = np.random.default_rng(7)
+    for k in (0, 79):
+        name, s = seqs[k]
+        seqs[k] = (name, s[:250] + "".join("ACGT"[c] for c in rng.integers(0, 4, size=150)) + s[250:])
+    t, f = os.path.join(tmp, "t.nwk"), os.path.join(tmp, "s.fa")
+    open(t, "w").write(nwk + "\n")
+    with open(f, "w") as fh:
+        for nm, sq in seqs:
+            fh.write(f">{nm}\n{sq}\n")
+    ref, out = os.path.join(tmp, "ref.aln"), os.path.join(tmp, "gpu.aln")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "e2e_oracle"), "-t", t, "-i", f, "-o", ref], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = subprocess.run([os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), "-t", t, "-i", f, "-o", out, "-v", "--check"], capture_output=True, text=True)
+    assert g.returncode == 0, (g.stdout + g.stderr)[-3000:]
+    handed = sum(int(l.split("restored on the host ")[1].split(";")[0]) for l in g.stderr.splitlines() if "restored on the host" in l)
+    assert handed >= 1, "no pair was handed back: the family did not put two long runs at one step"
+    assert _md5(out) == _md5(ref)

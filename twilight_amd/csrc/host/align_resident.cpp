@@ -496,7 +496,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (option->printDetail)
         std::cerr << "  phases (ms): prepare " << ctx.totals.prepare_ms - before.prepare_ms << " (device " << devPrep << ") call " << ctx.totals.call_ms - before.call_ms
                   << " (kernel " << rec.kernel_ms << ", exchange " << rec.exchange_ms << ") finish " << ctx.totals.finish_ms - before.finish_ms << " (device " << devCommit
-                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << ctx.totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << "; gappy columns back " << tGappy << " ms\n";
+                  << ") whole " << nowMs() - tPrep << "; relaunched pairs " << ctx.totals.relaunched - before.relaunched << "; pairs with removed columns " << needInfo.size() << "; restored on the host " << handedBack.size() << "; gappy columns back " << tGappy << " ms\n";
 }
 
 }  // namespace gpu
