@@ -265,12 +265,20 @@ def main():
     from twilight_amd import dist as tdist
     from twilight_amd import msa
 
+    # development: TWL_BENCH_ONE_GPU=1 runs every rank on cuda:0 with gloo between the processes (RCCL refuses two ranks on one device):
+    # the N > 1 code path of this script on a one-GPU box; never a measurement
+    one_gpu = bool(os.environ.get("TWL_BENCH_ONE_GPU"))
+    if one_gpu:
+        local_rank = 0
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     if world > 1 or os.environ.get("TWL_BENCH_FORCE_SHARD"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()          # rank 0 has written the family
     twl.init([local_rank])
     num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -285,7 +293,7 @@ def main():
     if family:
         # ---- K + W fresh handles, opened and made resident in HBM before the clock starts ----
         force_shard = bool(os.environ.get("TWL_BENCH_FORCE_SHARD"))      # development: a 1-rank world still goes through the RCCL all-gather
-        exchange = tdist.make_exchange(dev) if (world > 1 or force_shard) else None                # host blocks: the deferred pass
+        exchange = tdist.make_exchange(None if one_gpu else dev) if (world > 1 or force_shard) else None                # host blocks: the deferred pass
         exchange_dev = tdist.make_device_exchange(dev) if (world > 1 or force_shard) else None      # device blocks: every level of the main pass
         handles = []
         t0 = time.perf_counter()
@@ -332,7 +340,7 @@ def main():
         exch_ms = 0.0
         levels, tot, md5, open_s = [], None, None, 0.0
 
-    dt_max = tdist.reduce_report(0.0, dt, device=dev)[1] if world > 1 else dt      # MAX of seconds over ranks (cells are whole-job already)
+    dt_max = tdist.reduce_report(0.0, dt, device=(None if one_gpu else dev))[1] if world > 1 else dt      # MAX of seconds over ranks (cells are whole-job already)
 
     if rank == 0:
         steps = max(1, args.steps)
