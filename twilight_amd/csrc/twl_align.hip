@@ -348,6 +348,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     HIP_TRY(hipSetDevice(d->id));
     d->stats = twl_stats{};
     d->kname[0] = 0;
+    d->last_err.clear();
     d->pair_cells.assign((size_t)n_pairs, 0);
     if (n_pairs == 0) return TWL_OK;
 
