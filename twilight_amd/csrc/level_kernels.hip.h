@@ -43,6 +43,8 @@ struct LevelArgs {
     uint8_t *colinfo;                 // [2*n_pairs][stride]  consensus letter index | 0x80 when the column is gappy
     float *cols;                      // [2*n_pairs][stride][P+2] packed DP columns
     int32_t *len_out;                 // [2*n_pairs] lengths after removal
+    int32_t *chunk_cnt;               // [2*n_pairs][n_chunks] columns kept in every 1024-column chunk (profile_kernel -> compact_kernel)
+    int32_t n_chunks;
     int32_t stride;
     float gappy_thr;                  // option->gappyVertical
     int32_t remove;                   // 0 when gappy_thr == 1 (removeGappyColumns returns early, :77)
@@ -56,13 +58,15 @@ template <int P>
 __global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
 {
     __shared__ uint8_t s_lut[256];
+    __shared__ int s_kept[4];
     s_lut[threadIdx.x] = a.lut[threadIdx.x];
     __syncthreads();
     const int side = blockIdx.x;
     const SideDesc sd = a.sides[side];
     const int t0 = 4 * (blockIdx.y * 256 + threadIdx.x);
-    if (t0 >= sd.len) return;
-    const int nc = min(4, sd.len - t0);
+    const int nc = max(0, min(4, sd.len - t0));      // (threads behind the side's end carry nothing, but stay for the count below)
+    int kept = 0;
+    if (nc > 0) {
     float acc[4][P];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -78,17 +82,34 @@ __global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
                 for (int v = 0; v < P; ++v) acc[k][v] = c[k * P + v] / sd.weight * fnum;
             }
     } else {                                                             // :23-34  member by member
-        for (int m = 0; m < sd.n_members; ++m) {
-            const int mi = sd.member_off + m;
-            const char *row = (a.member_plane[mi] ? a.rows1 : a.rows0) + (size_t)a.member_seq[mi] * a.cap;
-            const uint32_t four = *reinterpret_cast<const uint32_t *>(row + t0);
-            const float w = a.member_w[mi];
+        // U members per round: their row words are requested together (independent loads in flight), then added in member order
+        constexpr int U = (P == 6) ? 4 : 2;
+        auto add = [&](uint32_t four, float w) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int li = s_lut[(four >> (8 * k)) & 0xFFu];
 #pragma unroll
                 for (int v = 0; v < P; ++v) acc[k][v] += (li == v) ? w : 0.0f;    // x + 0 is exact (accumulators are never -0)
             }
+        };
+        int m = 0;
+        for (; m + U <= sd.n_members; m += U) {
+            uint32_t four[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int mi = sd.member_off + m + u;
+                const char *row = (a.member_plane[mi] ? a.rows1 : a.rows0) + (size_t)a.member_seq[mi] * a.cap;
+                four[u] = *reinterpret_cast<const uint32_t *>(row + t0);
+                w[u] = a.member_w[mi];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) add(four[u], w[u]);
+        }
+        for (; m < sd.n_members; ++m) {
+            const int mi = sd.member_off + m;
+            const char *row = (a.member_plane[mi] ? a.rows1 : a.rows0) + (size_t)a.member_seq[mi] * a.cap;
+            add(*reinterpret_cast<const uint32_t *>(row + t0), a.member_w[mi]);
         }
         if (sd.store_slot >= 0) {                                        // :35-40  cache = profile / num * weight
             float *c = a.cache[sd.store_slot] + (size_t)t0 * P;
@@ -113,6 +134,17 @@ __global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
             if (acc[k][v] > bestCount) { bestCount = acc[k][v]; best = v; }
         const bool gappy = (acc[k][P - 1] / fnum > a.gappy_thr);         // :84,105
         a.colinfo[(size_t)side * a.stride + t0 + k] = (uint8_t)(best | (gappy ? 0x80 : 0));
+        kept += (a.remove && gappy) ? 0 : 1;
+    }
+    }
+    // columns this 1024-column chunk keeps: compact_kernel places every chunk without walking the side serially
+    {
+        int x = kept;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) x += __shfl_xor(x, d, 64);
+        if ((threadIdx.x & 63) == 0) s_kept[threadIdx.x >> 6] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) a.chunk_cnt[(size_t)side * a.n_chunks + blockIdx.y] = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
     }
 }
 
@@ -152,44 +184,62 @@ __device__ __forceinline__ int block_scan_int_256(int v, int *total, int *s_wave
     return base + x - v;
 }
 
-// grid: 2 * n_pairs workgroups of 256 threads; a workgroup walks its side in 256-column chunks with a running output index.
+// grid: (2 * n_pairs, n_chunks), 256 threads: one 1024-column chunk of one side, four columns per thread; the chunk's first output
+// index is the sum of the kept-column counts of the chunks before it (profile_kernel left them).
 template <int P>
 __global__ void __launch_bounds__(256) compact_kernel(LevelArgs a)
 {
     constexpr int CW = P + 2;
     __shared__ int s_wave[4];
+    __shared__ int s_base;
     const int side = blockIdx.x;
     const SideDesc sd = a.sides[side];
+    const int c0 = 1024 * blockIdx.y;
+    const int lastChunk = (sd.len > 0) ? (sd.len - 1) / 1024 : 0;
+    if ((int)blockIdx.y > lastChunk) return;
     const float fnum = (float)sd.num;
     const double dnum = (double)sd.num;
-    int base = 0;
-    for (int c0 = 0; c0 < sd.len; c0 += 256) {
-        const int t = c0 + threadIdx.x;
-        const bool in = t < sd.len;
-        const bool keep = in && !(a.remove && (a.colinfo[(size_t)side * a.stride + t] & 0x80));
-        int total;
-        const int dst = base + block_scan_256(keep, &total, s_wave);
-        if (keep) {
-            const float *src = a.raw + ((size_t)side * a.stride + t) * P;
-            float v[CW];
+    // output index of this chunk's first kept column
+    int part = 0;
+    for (int c = threadIdx.x; c < (int)blockIdx.y; c += 256) part += a.chunk_cnt[(size_t)side * a.n_chunks + c];
+    int tot;
+    (void)block_scan_int_256(part, &tot, s_wave);
+    if (threadIdx.x == 0) s_base = tot;
+    __syncthreads();
+    const int base = s_base;
+    const int t0 = c0 + 4 * threadIdx.x;
+    bool keep[4];
+    int cnt = 0;
 #pragma unroll
-            for (int k = 0; k < P; ++k) v[k] = src[k];
-            const float g = v[P - 1];
-            if (g > 0) {                                                 // calculatePSGP :186-190 (double arithmetic, narrowed once)
-                const double frac = ((double)(fnum - g) * 1.0) / dnum;
-                v[P] = fminf(a.min_gap_open, (float)((double)(a.gap_open * a.scale) * frac));
-                v[P + 1] = fminf(a.min_gap_extend, (float)((double)a.gap_extend * frac));
-            } else {
-                v[P] = a.gap_open;
-                v[P + 1] = a.gap_extend;
-            }
-            float4 *out = reinterpret_cast<float4 *>(a.cols + ((size_t)side * a.stride + dst) * CW);
-#pragma unroll
-            for (int k = 0; k < CW / 4; ++k) out[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-        }
-        base += total;
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + k;
+        keep[k] = t < sd.len && !(a.remove && (a.colinfo[(size_t)side * a.stride + t] & 0x80));
+        cnt += keep[k] ? 1 : 0;
     }
-    if (threadIdx.x == 0) a.len_out[side] = base;
+    int total;
+    int dst = base + block_scan_int_256(cnt, &total, s_wave);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!keep[k]) continue;
+        const float *src = a.raw + ((size_t)side * a.stride + t0 + k) * P;
+        float v[CW];
+#pragma unroll
+        for (int j = 0; j < P; ++j) v[j] = src[j];
+        const float g = v[P - 1];
+        if (g > 0) {                                                 // calculatePSGP :186-190 (double arithmetic, narrowed once)
+            const double frac = ((double)(fnum - g) * 1.0) / dnum;
+            v[P] = fminf(a.min_gap_open, (float)((double)(a.gap_open * a.scale) * frac));
+            v[P + 1] = fminf(a.min_gap_extend, (float)((double)a.gap_extend * frac));
+        } else {
+            v[P] = a.gap_open;
+            v[P + 1] = a.gap_extend;
+        }
+        float4 *out = reinterpret_cast<float4 *>(a.cols + ((size_t)side * a.stride + dst) * CW);
+#pragma unroll
+        for (int j = 0; j < CW / 4; ++j) out[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        ++dst;
+    }
+    if ((int)blockIdx.y == lastChunk && threadIdx.x == 0) a.len_out[side] = base + total;
 }
 
 // ---- write-back ----

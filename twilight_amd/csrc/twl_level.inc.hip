@@ -23,14 +23,14 @@ struct CacheEntry {
 // time (device replicas of a test) get a set each.
 struct LevelBufs {
     Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
-    Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew;
+    Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew, d_ccnt;
     Buf r_sel, r_oidx, r_run, r_seg, r_aoff, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
     Buf x_send, x_recv, x_rowoff, x_blkoff, x_len;                                  // exchange of final paths between processes (device blocks)
     bool busy = false;
     void release_all()
     {
         for (Buf *b : {&d_sides, &d_mseq, &d_mw, &d_mplane, &d_tab, &d_raw, &d_colinfo, &d_cols, &d_len, &d_lenmask, &d_num, &d_aln, &d_alnlen, &d_err,
-                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
+                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &d_ccnt, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
             b->release();
     }
 };
@@ -407,12 +407,15 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     int32_t maxLen = 1;
     for (size_t i = 0; i < ns; ++i) maxLen = std::max(maxLen, sides[i].len);
     const dim3 gridP((unsigned)ns, (unsigned)((maxLen + 1023) / 1024));
+    if ((rc = s->lv->d_ccnt.ensure(ns * (size_t)gridP.y * sizeof(int32_t)))) return rc;
+    a.chunk_cnt = (int32_t *)s->lv->d_ccnt.p;
+    a.n_chunks = (int32_t)gridP.y;
     if (s->P == 6) {
         hipLaunchKernelGGL(twl::profile_kernel<6>, gridP, dim3(256), 0, st, a);
-        hipLaunchKernelGGL(twl::compact_kernel<6>, dim3((unsigned)ns), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(twl::compact_kernel<6>, gridP, dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(twl::profile_kernel<22>, gridP, dim3(256), 0, st, a);
-        hipLaunchKernelGGL(twl::compact_kernel<22>, dim3((unsigned)ns), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(twl::compact_kernel<22>, gridP, dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(d->ev[1], st));
