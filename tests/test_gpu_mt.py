@@ -172,3 +172,52 @@ def test_protein_tile_parallel_small_marker_and_blosum80(knobs):
     batch = synth.make_level_batch(4, 1500, P=22, members=((1, 4), (1, 4)), seed=93, sub=0.25)
     st, ost = _compare_p(knobs, batch, marker=200)
     assert st.speculative == 3
+
+
+# ---- randomized campaign on the tile-parallel path (tools/fuzz_mt.py runs it over arbitrary seed ranges) ----
+def random_mt_case(seed):
+    rng = np.random.default_rng(seed)
+    prot = rng.random() < 0.2
+    P = 22 if prot else 6
+    n = int(rng.integers(1, 10))
+    length = int(rng.choice([2200, 3500, 5000, 8000] if not prot else [1800, 2600]))
+    members = ((1, int(rng.integers(1, 8))), (1, int(rng.integers(1, 8)))) if rng.random() < 0.8 else (1, 1)
+    batch = synth.make_level_batch(n, length, P=P, members=members, seed=int(rng.integers(1 << 30)),
+                                   sub=float(rng.choice([0.02, 0.06, 0.15, 0.3] if not prot else [0.1, 0.25])), indel=float(rng.choice([0.0, 0.005, 0.02])),
+                                   gap_col_rate=float(rng.choice([0.0, 0.03, 0.2])), length_jitter=float(rng.choice([0.02, 0.3])))
+    if rng.random() < 0.25:         # some pairs very unequal in length: straight-line starts far from the path, trailing runs
+        k = int(rng.integers(0, n))
+        batch.len[k, int(rng.integers(0, 2))] = max(1, int(batch.len[k].min() * rng.uniform(0.1, 0.7)))
+    marker = int(rng.choice([200, 512, 1024]))
+    pk = dict(marker=marker, xdrop=int(rng.choice([600, 2000, 5000])), flen=int(rng.choice([200, 700, 4096])))
+    if rng.random() < 0.25:
+        pk["gap_char"] = 0.0
+    knobs = {api.KNOB_MT_MIN_MARKER: 64, api.KNOB_MT_PERTURB: int(rng.choice([0, 0, 1, 2, 5])), api.KNOB_MT_ROUNDS: int(rng.choice([1, 2, 3])),
+             api.KNOB_MT_LEAD: int(rng.choice([16, 128, 320])), api.KNOB_MT_MARGIN: int(rng.choice([2, 16, 40])), api.KNOB_MT_THR_JOBS: int(rng.choice([0, 256]))}
+    return batch, (PM if prot else M), pk, knobs
+
+
+def check_mt_case(twl, seed):
+    batch, matrix, pk, knobs = random_mt_case(seed)
+    for k, v in knobs.items():
+        twl.set_knob(k, v)
+    p = twl.make_params(matrix, **pk)
+    aln, n, err = twl.align_batch(p, batch)
+    st = twl.get_stats(0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(matrix, **pk), batch, threads=8)
+    tag = f"seed {seed} P={batch.P} len={batch.len.tolist()} params={pk} knobs={knobs} speculative={st.speculative}"
+    assert np.array_equal(err, oerr), f"{tag}: errorType gpu {err.tolist()} oracle {oerr.tolist()}"
+    assert np.array_equal(n, on), f"{tag}: path length gpu {n.tolist()} oracle {on.tolist()}"
+    for i in range(batch.n_pairs):
+        assert np.array_equal(aln[i, : n[i]], oa[i, : on[i]]), f"{tag}: path of pair {i} differs"
+    if np.all(oerr == 0):
+        assert st.band_cells == ost.cells, f"{tag}: band cells gpu {st.band_cells} oracle {ost.cells}"
+    return st.speculative == 3, int(np.count_nonzero(oerr))
+
+
+def test_random_campaign_on_the_tile_parallel_path(knobs):
+    took = 0
+    for seed in range(7000, 7040):
+        mt, _ = check_mt_case(knobs, seed)
+        took += mt
+    assert took >= 20, took      # most cases are long enough to take the tile-parallel path
