@@ -1,6 +1,7 @@
-"""Timing experiment: how much of a level's time is the per-diagonal convergence test of phase C?  Builds a copy of the library in which the
-test runs on every 8th diagonal only (results are WRONG there: timing only) and times a wide level and a lone pair on both.
-    python tools/exp_conv8.py        (GPU box; does not touch the product library)"""
+"""Timing experiments on copies of the library built with an experiment flag (-DTWL_EXP_SALU / -DTWL_EXP_VALU: 24 extra scalar / vector
+instructions per wave and diagonal): what does a wide level and a lone pair cost then?  (The convergence-test experiment this script was
+written for led to the pre-test of DESIGN.md section 3.1.)
+    python tools/exp_conv8.py [base | TWL_EXP_SALU | TWL_EXP_VALU]        (GPU box; does not touch the product library)"""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,10 +10,10 @@ import torch
 from twilight_amd import synth, api
 
 so = os.path.join(tempfile.mkdtemp(), "libtwl_exp.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DTWL_EXP_CONV8", "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
-which = sys.argv[1] if len(sys.argv) > 1 else "exp"
-if which == "exp":
+which = sys.argv[1] if len(sys.argv) > 1 else "base"      # base | TWL_EXP_SALU | TWL_EXP_VALU (a -D flag of an experiment build)
+if which != "base":
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                           "-D" + which, "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
     api.LIB_PATH = so
 api.init([0])
 dev = torch.device("cuda:0")

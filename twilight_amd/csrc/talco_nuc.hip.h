@@ -621,6 +621,17 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 constexpr int PH = decltype(PHtag)::value;
                 constexpr bool TB = (PH != 2), CONV = (PH != 0);
                 TWL_STAMP(t_head);
+#if defined(TWL_EXP_SALU)      // timing experiment: 24 extra scalar instructions per wave and diagonal
+                { int xs = k; 
+#pragma unroll
+                  for (int t = 0; t < 24; ++t) asm volatile("s_add_u32 %0, %0, 1" : "+s"(xs));
+                  asm volatile("" :: "s"(xs)); }
+#elif defined(TWL_EXP_VALU)    // timing experiment: 24 extra vector instructions per wave and diagonal
+                { int xv = lane;
+#pragma unroll
+                  for (int t = 0; t < 24; ++t) asm volatile("v_add_u32 %0, %0, 1" : "+v"(xv));
+                  asm volatile("" :: "v"(xv)); }
+#endif
                 const unsigned kk16 = (unsigned)(k + 1) << 16;                // tag of this diagonal's row reductions (k + 1 <= 65535)
                 const int width1 = Uk - Lk;
                 const unsigned vwidth1 = (unsigned)(vU - vL);
