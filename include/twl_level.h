@@ -138,7 +138,8 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
 /* Diagnostics: the packed DP columns [len][P+2] (P frequencies, gapOpen, gapExtend) of one side of the prepared level. */
 int twl_level_read_columns(twl_store *s, int32_t pair, int32_t side, float *out, int32_t max_cols);
 
-/* HIP-event time (ms) of the last prepare / commit kernels, for the per-level report. */
+/* HIP-event time (ms) of the last prepare / commit kernels, for the per-level report.  A commit returns while its kernels run (the
+   next call on the store is queued behind them); this call waits for them. */
 int twl_level_timing(twl_store *s, double *prepare_ms, double *commit_ms);
 
 #ifdef __cplusplus

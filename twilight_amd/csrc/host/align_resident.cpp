@@ -472,7 +472,8 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     }
     const double tGappy = nowMs() - tFin;
     onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit_from_dp(g_stores[d], finalPaths, finalLen.data(), pathStride, inPlace ? fromDp.data() : nullptr); });
-    for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538)
+#pragma omp parallel for schedule(static) if (n >= 512)
+    for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538); the pairs of a level share no node
         if (finalLen[i] == 0) continue;
         Node *a = nodes[i].first, *b = nodes[i].second;
         if (a->cacheId >= 0 && b->cacheId >= 0) b->cacheId = -1;       // merged into a's cache by the commit
@@ -484,7 +485,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     }
     ctx.totals.finish_ms += nowMs() - tFin;
     double devPrep = 0, devCommit = 0;
-    twl_level_timing(g_store, &devPrep, &devCommit);
+    if (option->printDetail) twl_level_timing(g_store, &devPrep, &devCommit);      // (waits for the write-back kernels, which the next level would otherwise overlap with)
     ctx.totals.dev_prepare_ms += devPrep;
     ctx.totals.dev_commit_ms += devCommit;
     for (int i = 0; i < n; ++i)

@@ -38,6 +38,7 @@ struct Node {
     float weight = 0;
     bool placed = false;
     int grpID = -1;
+    int schedIdx = -1;         // scratch of progressive::getProgressivePairs (position in its post-order walk)
 
     std::vector<int> seqsIncluded;
     Profile msaFreq;

@@ -184,6 +184,27 @@ __device__ __forceinline__ int block_scan_int_256(int v, int *total, int *s_wave
     return base + x - v;
 }
 
+// exclusive prefix sum of one int per thread over a workgroup of NW waves; *total = the sum
+template <int NW>
+__device__ __forceinline__ int block_scan_int(int v, int *total, int *s_wave /*[NW]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();                               // s_wave may still be read from the previous round
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    int base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int c = s_wave[w]; if (w < wave) base += c; sum += c; }
+    *total = sum;
+    return base + x - v;
+}
+
 // grid: (2 * n_pairs, n_chunks), 256 threads: one 1024-column chunk of one side, four columns per thread; the chunk's first output
 // index is the sum of the kept-column counts of the chunks before it (profile_kernel left them).
 template <int P>
@@ -260,24 +281,45 @@ struct CommitArgs {
     const float *merge_w;         // [n_merge][2]  refWeight, qryWeight
 };
 
-// grid: n_pairs workgroups of 256 threads.
+// grid: n_pairs workgroups of 256 threads: chunk_base[pair][ch] = reference / query columns the path consumes before its 256-element chunk ch.
+// Thread t counts chunk g * 256 + t (sixteen 16-byte loads; rows of the path buffer start at multiples of path_stride, hence the byte
+// path for rows that are not 16-byte aligned), one workgroup scan per 65536 path elements.
 __global__ void __launch_bounds__(256) path_scan_kernel(CommitArgs a)
 {
     __shared__ int s_wave[4];
     const int pair = blockIdx.x;
     const int n = a.path_len[pair];
     const int8_t *path = a.paths + (size_t)pair * a.path_stride;
+    const bool aligned = (((size_t)pair * (size_t)a.path_stride) & 15u) == 0 && ((size_t)a.paths & 15u) == 0;
+    const int nch = (n + 255) >> 8;
     int baseR = 0, baseQ = 0;
-    for (int c0 = 0, ch = 0; c0 < n; c0 += 256, ++ch) {
-        const int c = c0 + threadIdx.x;
-        const int code = (c < n) ? path[c] : 3;
-        if (threadIdx.x == 0) {
-            a.chunk_base[((size_t)pair * a.n_chunks + ch) * 2] = baseR;
-            a.chunk_base[((size_t)pair * a.n_chunks + ch) * 2 + 1] = baseQ;
+    for (int g0 = 0; g0 < nch; g0 += 256) {
+        const int ch = g0 + threadIdx.x;
+        const int c0 = ch << 8;
+        int cR = 0, cQ = 0;
+        if (ch < nch) {
+            if (aligned && c0 + 256 <= n) {
+                const uint4 *w4 = reinterpret_cast<const uint4 *>(path + c0);
+                int oddR = 0, oddQ = 0;              // codes 0 / 1 / 2: the reference is consumed unless bit 0 is set, the query unless bit 1 is
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint4 w = w4[k];
+                    oddR += __popc(w.x & 0x01010101u) + __popc(w.y & 0x01010101u) + __popc(w.z & 0x01010101u) + __popc(w.w & 0x01010101u);
+                    oddQ += __popc(w.x & 0x02020202u) + __popc(w.y & 0x02020202u) + __popc(w.z & 0x02020202u) + __popc(w.w & 0x02020202u);
+                }
+                cR = 256 - oddR; cQ = 256 - oddQ;
+            } else {
+                const int e = min(n, c0 + 256);
+                for (int c = c0; c < e; ++c) { const int code = path[c]; cR += (code == 0 || code == 2); cQ += (code == 0 || code == 1); }
+            }
         }
         int totR, totQ;
-        (void)block_scan_256(code == 0 || code == 2, &totR, s_wave);
-        (void)block_scan_256(code == 0 || code == 1, &totQ, s_wave);
+        const int exR = baseR + block_scan_int_256(cR, &totR, s_wave);
+        const int exQ = baseQ + block_scan_int_256(cQ, &totQ, s_wave);
+        if (ch < nch) {
+            a.chunk_base[((size_t)pair * a.n_chunks + ch) * 2] = exR;
+            a.chunk_base[((size_t)pair * a.n_chunks + ch) * 2 + 1] = exQ;
+        }
         baseR += totR;
         baseQ += totQ;
     }
@@ -307,24 +349,43 @@ __global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
         cnt += keep[k] ? 1 : 0;
     }
     int tot;
-    int src = a.chunk_base[((size_t)pair * a.n_chunks + 4 * blockIdx.y) * 2 + isQ] + block_scan_int_256(cnt, &tot, s_wave);
+    const int src = a.chunk_base[((size_t)pair * a.n_chunks + 4 * blockIdx.y) * 2 + isQ] + block_scan_int_256(cnt, &tot, s_wave);
     if (c >= n) return;
+    // the kept columns of this thread are cnt CONSECUTIVE bytes of the old row, from src: one or two aligned 32-bit loads per member
+    // (the second only when the bytes straddle a word: it then lies inside the row), spread over the word that is stored;
+    // four members per round so that their loads are in flight together
     const SideDesc sd = a.sides[side];
-    for (int m = w[1]; m < w[1] + w[2]; ++m) {
-        const int mi = sd.member_off + m;
-        const size_t off = (size_t)a.member_seq[mi] * a.cap;
-        const bool pl = a.member_plane[mi];
-        const char *from = (pl ? a.rows1 : a.rows0) + off;
-        char *to = (pl ? a.rows0 : a.rows1) + off;
-        uint32_t word = 0;
-        int sidx = src;
+    const int sh = (src & 3) * 8;
+    const bool two = (src & 3) + cnt > 4;
+    const size_t lo = (size_t)(src & ~3);
+    constexpr int U = 4;
+    const int mEnd = w[1] + w[2];
+    for (int m = w[1]; m < mEnd; m += U) {
+        uint32_t v0[U], v1[U];
+        char *to[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ch = keep[k] ? (uint32_t)(uint8_t)from[sidx] : (uint32_t)'-';
-            sidx += keep[k] ? 1 : 0;
-            word |= ch << (8 * k);
+        for (int u = 0; u < U; ++u) {
+            const int mi = sd.member_off + min(m + u, mEnd - 1);
+            const size_t off = (size_t)a.member_seq[mi] * a.cap;
+            const bool pl = a.member_plane[mi];
+            const char *from = (pl ? a.rows1 : a.rows0) + off;
+            to[u] = (pl ? a.rows0 : a.rows1) + off;
+            v0[u] = cnt ? *reinterpret_cast<const uint32_t *>(from + lo) : 0u;
+            v1[u] = two ? *reinterpret_cast<const uint32_t *>(from + lo + 4) : 0u;
         }
-        *reinterpret_cast<uint32_t *>(to + c) = word;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (m + u >= mEnd) break;
+            uint64_t v = (((uint64_t)v1[u] << 32) | v0[u]) >> sh;
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t ch = keep[k] ? (uint32_t)(v & 0xFFu) : (uint32_t)'-';
+                if (keep[k]) v >>= 8;
+                word |= ch << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(to[u] + c) = word;
+        }
     }
 }
 

@@ -37,6 +37,8 @@ struct RestoreArgs {
     int32_t *run;             // [n_sel][4][bstride] per boundary: run length ref, run length query, run start ref, run start query
     int32_t *seg;             // [n_sel][bstride] segment length per boundary
     int32_t *aoff;            // [n_sel][bstride] arena offset of a two-sided boundary
+    int32_t *both_list;       // [n_sel][bstride] the two-sided boundaries of a pair, ascending
+    int32_t *n_both;          // [n_sel] how many
     int8_t *arena;            // [n_sel][out_stride] the aligned two-sided segments, reversed
     int32_t bstride;
     int8_t *out;              // [n_pairs][out_stride] final paths
@@ -49,66 +51,98 @@ struct RestoreArgs {
     float gap_open, gap_extend;
 };
 
-// grid: 2 * n_sel workgroups of 256 threads: original index of every kept column of one side (+ the side's original length as a sentinel)
-__global__ void __launch_bounds__(256) restore_index_kernel(RestoreArgs a)
+// The three scan kernels below run one workgroup of kRsThreads threads per pair (or side), kRsItems consecutive items per thread and
+// one workgroup scan per kRsThreads * kRsItems items: at the top of a tree a level is ONE pair with a path of 10^5 elements, and the
+// time of these kernels is the number of scan rounds.
+constexpr int kRsThreads = 1024, kRsItems = 8, kRsWaves = kRsThreads / 64;
+
+// grid: 2 * n_sel workgroups: original index of every kept column of one side (+ the side's original length as a sentinel)
+__global__ void __launch_bounds__(kRsThreads) restore_index_kernel(RestoreArgs a)
 {
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[kRsWaves];
     const int side = 2 * a.sel[blockIdx.x >> 1] + (blockIdx.x & 1);
     const int len = a.sides[side].len;
+    const uint8_t *ci = a.colinfo + (size_t)side * a.stride;
     int32_t *oi = a.orig_idx + (size_t)blockIdx.x * (size_t)(a.stride + 1);
     int base = 0;
-    for (int c0 = 0; c0 < len; c0 += 256) {
-        const int t = c0 + threadIdx.x;
-        const bool keep = t < len && !(a.colinfo[(size_t)side * a.stride + t] & 0x80);
+    for (int c0 = 0; c0 < len; c0 += kRsThreads * kRsItems) {
+        const int t0 = c0 + (int)threadIdx.x * kRsItems;
+        bool keep[kRsItems];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) { keep[k] = t0 + k < len && !(ci[t0 + k] & 0x80); cnt += keep[k] ? 1 : 0; }
         int total;
-        const int dst = base + block_scan_256(keep, &total, s_wave);
-        if (keep) oi[dst] = t;
+        int dst = base + block_scan_int<kRsWaves>(cnt, &total, s_wave);
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) if (keep[k]) oi[dst++] = t0 + k;
         base += total;
     }
     if (threadIdx.x == 0) oi[base] = len;      // (base == len_red[side])
 }
 
-// grid: n_sel workgroups: the runs at every boundary of the DP path, and where the two-sided ones go in the arena
-__global__ void __launch_bounds__(256) restore_runs_kernel(RestoreArgs a)
+// grid: n_sel workgroups: the runs at every boundary of the DP path, where the two-sided ones go in the arena, and the list of them
+__global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
 {
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[kRsWaves];
+    __shared__ int s_big;
     const int pair = a.sel[blockIdx.x];
     const int n = a.aln_len[pair];
     const int8_t *path = a.aln + (size_t)pair * a.aln_stride;
     const int32_t *oiR = a.orig_idx + (size_t)(2 * blockIdx.x) * (size_t)(a.stride + 1), *oiQ = oiR + (a.stride + 1);
     int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride, *stR = runQ + a.bstride, *stQ = stR + a.bstride;
     int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride, *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
-    int baseR = 0, baseQ = 0, baseA = 0;
+    int32_t *both_list = a.both_list + (size_t)blockIdx.x * a.bstride;
+    if (threadIdx.x == 0) s_big = 0;
+    int baseR = 0, baseQ = 0, baseA = 0, baseB = 0;
     bool tooBig = false;
-    for (int c0 = 0; c0 <= n; c0 += 256) {
-        const int b = c0 + threadIdx.x;                 // boundary b: between elements b - 1 and b
-        const int prev = (b >= 1 && b <= n) ? path[b - 1] : 3;
-        const bool fR = (prev == 0 || prev == 2), fQ = (prev == 0 || prev == 1);
-        int totR, totQ, totA;
-        const int cR = baseR + block_scan_256(fR, &totR, s_wave) + (fR ? 1 : 0);      // reference columns consumed before boundary b
-        const int cQ = baseQ + block_scan_256(fQ, &totQ, s_wave) + (fQ ? 1 : 0);
-        int rR = 0, rQ = 0, sR = 0, sQ = 0;
-        if (b <= n) {
-            if (b == 0 || fR) { sR = cR ? oiR[cR - 1] + 1 : 0; rR = oiR[cR] - sR; }
-            if (b == 0 || fQ) { sQ = cQ ? oiQ[cQ - 1] + 1 : 0; rQ = oiQ[cQ] - sQ; }
+    for (int c0 = 0; c0 <= n; c0 += kRsThreads * kRsItems) {
+        const int b0 = c0 + (int)threadIdx.x * kRsItems;       // boundary b: between elements b - 1 and b
+        bool fR[kRsItems], fQ[kRsItems];
+        int nR = 0, nQ = 0;
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) {
+            const int b = b0 + k;
+            const int prev = (b >= 1 && b <= n) ? path[b - 1] : 3;
+            fR[k] = (prev == 0 || prev == 2); fQ[k] = (prev == 0 || prev == 1);
+            nR += fR[k] ? 1 : 0; nQ += fQ[k] ? 1 : 0;
         }
-        const bool both = rR > 0 && rQ > 0;
-        if (both && ((long long)(rR + 1) * (rQ + 1) > kNwCells || rQ + 1 > kNwRow)) tooBig = true;
-        const int off = baseA + block_scan_int_256(both ? rR + rQ : 0, &totA, s_wave);
-        if (b <= n) {
-            runR[b] = rR; runQ[b] = rQ; stR[b] = sR; stQ[b] = sQ;
-            seg[b] = both ? -1 : rR + rQ;
+        int totR, totQ, totA, totB;
+        int cR = baseR + block_scan_int<kRsWaves>(nR, &totR, s_wave);      // reference columns consumed before boundary b0 (element b0 - 1 not counted yet)
+        int cQ = baseQ + block_scan_int<kRsWaves>(nQ, &totQ, s_wave);
+        int rR[kRsItems], rQ[kRsItems], sR[kRsItems], sQ[kRsItems];
+        int sumA = 0, nB = 0;
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) {
+            const int b = b0 + k;
+            cR += fR[k] ? 1 : 0; cQ += fQ[k] ? 1 : 0;                     // ... consumed before boundary b
+            rR[k] = rQ[k] = sR[k] = sQ[k] = 0;
+            if (b <= n) {
+                if (b == 0 || fR[k]) { sR[k] = cR ? oiR[cR - 1] + 1 : 0; rR[k] = oiR[cR] - sR[k]; }
+                if (b == 0 || fQ[k]) { sQ[k] = cQ ? oiQ[cQ - 1] + 1 : 0; rQ[k] = oiQ[cQ] - sQ[k]; }
+            }
+            const bool both = rR[k] > 0 && rQ[k] > 0;
+            if (both && ((long long)(rR[k] + 1) * (rQ[k] + 1) > kNwCells || rQ[k] + 1 > kNwRow)) tooBig = true;
+            sumA += both ? rR[k] + rQ[k] : 0;
+            nB += both ? 1 : 0;
+        }
+        int off = baseA + block_scan_int<kRsWaves>(sumA, &totA, s_wave);
+        int lst = baseB + block_scan_int<kRsWaves>(nB, &totB, s_wave);
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) {
+            const int b = b0 + k;
+            if (b > n) continue;
+            const bool both = rR[k] > 0 && rQ[k] > 0;
+            runR[b] = rR[k]; runQ[b] = rQ[k]; stR[b] = sR[k]; stQ[b] = sQ[k];
+            seg[b] = both ? -1 : rR[k] + rQ[k];
             aoff[b] = off;
+            if (both) { both_list[lst++] = b; off += rR[k] + rQ[k]; }
         }
-        baseR += totR; baseQ += totQ; baseA += totA;
+        baseR += totR; baseQ += totQ; baseA += totA; baseB += totB;
     }
-    // (every thread votes: a.out_len is written by one)
     __syncthreads();
-    if (threadIdx.x == 0) s_wave[0] = 0;
+    if (tooBig) s_big = 1;
     __syncthreads();
-    if (tooBig) s_wave[0] = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) a.out_len[pair] = s_wave[0] ? -1 : 0;
+    if (threadIdx.x == 0) { a.out_len[pair] = s_big ? -1 : 0; a.n_both[blockIdx.x] = baseB; }
 }
 
 // grid: (n_sel, nb) workgroups: every two-sided boundary aligned by one thread (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322);
@@ -117,7 +151,6 @@ __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
 {
     const int pair = a.sel[blockIdx.x];
     if (a.out_len[pair] < 0) return;
-    const int n = a.aln_len[pair];
     const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride, *stR = runQ + a.bstride, *stQ = stR + a.bstride;
     int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride;
     const int32_t *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
@@ -128,8 +161,10 @@ __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
     float *rw = a.rows + thr * (6 * kNwRow);
     const float go = a.gap_open, ge = a.gap_extend;
     const int ms = a.ms;
-    for (int b = blockIdx.y * 256 + threadIdx.x; b <= n; b += 256 * gridDim.y) {
-        if (seg[b] >= 0) continue;
+    const int32_t *both_list = a.both_list + (size_t)blockIdx.x * a.bstride;
+    const int nBoth = a.n_both[blockIdx.x];
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < nBoth; t += 256 * gridDim.y) {
+        const int b = both_list[t];
         const int m = runR[b], nn = runQ[b];
         const uint8_t *s1 = cR + stR[b], *s2 = cQ + stQ[b];
         const int W = nn + 1;
@@ -165,9 +200,9 @@ __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
 }
 
 // grid: n_sel workgroups: the final path = for every boundary its segment, then the path element behind it
-__global__ void __launch_bounds__(256) restore_write_kernel(RestoreArgs a)
+__global__ void __launch_bounds__(kRsThreads) restore_write_kernel(RestoreArgs a)
 {
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[kRsWaves];
     const int pair = a.sel[blockIdx.x];
     if (a.out_len[pair] < 0) return;
     const int n = a.aln_len[pair];
@@ -177,17 +212,31 @@ __global__ void __launch_bounds__(256) restore_write_kernel(RestoreArgs a)
     const int8_t *arena = a.arena + (size_t)blockIdx.x * a.out_stride;
     int8_t *out = a.out + (size_t)pair * a.out_stride;
     int base = 0;
-    for (int c0 = 0; c0 <= n; c0 += 256) {
-        const int b = c0 + threadIdx.x;
-        const int sl = (b <= n) ? seg[b] : 0;
+    for (int c0 = 0; c0 <= n; c0 += kRsThreads * kRsItems) {
+        const int b0 = c0 + (int)threadIdx.x * kRsItems;
+        int sl[kRsItems];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) {
+            const int b = b0 + k;
+            sl[k] = (b <= n) ? seg[b] : 0;
+            sum += (b <= n) ? sl[k] + (b < n ? 1 : 0) : 0;
+        }
         int total;
-        const int pos = base + block_scan_int_256((b <= n) ? sl + (b < n ? 1 : 0) : 0, &total, s_wave);
-        if (b <= n && pos + sl + (b < n ? 1 : 0) <= a.out_stride) {
-            if (sl > 0) {
-                if (runR[b] > 0 && runQ[b] > 0) { const int8_t *src = arena + aoff[b]; for (int t = 0; t < sl; ++t) out[pos + t] = src[sl - 1 - t]; }
-                else { const int8_t code = runR[b] > 0 ? 2 : 1; for (int t = 0; t < sl; ++t) out[pos + t] = code; }
+        int pos = base + block_scan_int<kRsWaves>(sum, &total, s_wave);
+#pragma unroll
+        for (int k = 0; k < kRsItems; ++k) {
+            const int b = b0 + k;
+            if (b > n) continue;
+            const int w = sl[k] + (b < n ? 1 : 0);
+            if (pos + w <= a.out_stride) {
+                if (sl[k] > 0) {
+                    if (runR[b] > 0 && runQ[b] > 0) { const int8_t *src = arena + aoff[b]; for (int t = 0; t < sl[k]; ++t) out[pos + t] = src[sl[k] - 1 - t]; }
+                    else { const int8_t code = runR[b] > 0 ? 2 : 1; for (int t = 0; t < sl[k]; ++t) out[pos + t] = code; }
+                }
+                if (b < n) out[pos + sl[k]] = path[b];
             }
-            if (b < n) out[pos + sl] = path[b];
+            pos += w;
         }
         base += total;
     }

@@ -72,7 +72,7 @@ struct Buf {
 struct Device {
     int id = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};                                                       // [6], [7]: the write-back of a level (twl_level_commit, read later by twl_level_timing)
     int num_cu = 0;
     Buf cols, tb, cells, queue, items, errs, dbg;
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)

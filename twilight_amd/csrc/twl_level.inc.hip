@@ -24,13 +24,13 @@ struct CacheEntry {
 struct LevelBufs {
     Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
     Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew, d_ccnt;
-    Buf r_sel, r_oidx, r_run, r_seg, r_aoff, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
+    Buf r_sel, r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
     Buf x_send, x_recv, x_rowoff, x_blkoff, x_len;                                  // exchange of final paths between processes (device blocks)
     bool busy = false;
     void release_all()
     {
         for (Buf *b : {&d_sides, &d_mseq, &d_mw, &d_mplane, &d_tab, &d_raw, &d_colinfo, &d_cols, &d_len, &d_lenmask, &d_num, &d_aln, &d_alnlen, &d_err,
-                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &d_ccnt, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
+                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &d_ccnt, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_blist, &r_nboth, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
             b->release();
     }
 };
@@ -54,6 +54,42 @@ LevelBufs *acquire_level(Device *d)
     return b;
 }
 void release_level(LevelBufs *&lv) { if (lv) { lv->busy = false; lv = nullptr; } }
+
+// Cached node profiles come and go with every level near the top of a tree (a merged profile replaces its two parts): their buffers are
+// recycled through the device instead of hipMalloc / hipFree (which waits for the device) in the middle of a level.  Everything that
+// touches them runs on the device's one stream, so a buffer may be handed out again while the kernel that last read it is still queued.
+std::vector<Buf> &cache_pool(Device *d)
+{
+    static std::mutex mu;
+    static std::unordered_map<Device *, std::vector<Buf>> pools;
+    std::lock_guard<std::mutex> lk(mu);
+    return pools[d];
+}
+// (callers hold d->mu)
+int cache_buf_get(Device *d, Buf &b, size_t bytes)
+{
+    auto &pool = cache_pool(d);
+    size_t best = pool.size();
+    for (size_t k = 0; k < pool.size(); ++k)
+        if (pool[k].cap >= bytes && (best == pool.size() || pool[k].cap < pool[best].cap)) best = k;
+    if (best != pool.size()) { b = pool[best]; pool[best] = pool.back(); pool.pop_back(); return TWL_OK; }
+    b = Buf{};
+    return b.ensure(bytes + bytes / 4);      // (the next profile up the tree is a little longer)
+}
+void cache_buf_put(Device *d, Buf &b)
+{
+    if (!b.p) return;
+    auto &pool = cache_pool(d);
+    if (pool.size() >= 64) {                 // keep the larger ones
+        size_t small = 0;
+        for (size_t k = 1; k < pool.size(); ++k) if (pool[k].cap < pool[small].cap) small = k;
+        if (pool[small].cap < b.cap) std::swap(pool[small], b);
+        b.release();
+        return;
+    }
+    pool.push_back(b);
+    b = Buf{};
+}
 }  // namespace
 
 static void twl_level_pool_release(Device *d)
@@ -61,6 +97,8 @@ static void twl_level_pool_release(Device *d)
     auto &pool = level_pool(d);
     for (LevelBufs *b : pool) { b->release_all(); delete b; }
     pool.clear();
+    for (Buf &b : cache_pool(d)) b.release();
+    cache_pool(d).clear();
 }
 
 struct twl_store {
@@ -81,7 +119,11 @@ struct twl_store {
     std::vector<int32_t> members;
     std::vector<int32_t> h_len, h_num;
     std::vector<float> h_mw;                 // host copies that asynchronous uploads read from (kept with the store instead of synchronising)
-    std::vector<int32_t> h_sel, h_pathlen;
+    std::vector<int32_t> h_sel, h_pathlen, h_work, h_merge;
+    std::vector<float> h_mergew;
+    std::vector<float *> h_tab;
+    std::vector<uint8_t> h_mplane;
+    bool commit_pending = false;             // the last commit's kernels may still run (its events are d->ev[6], d->ev[7])
     LevelBufs *lv = nullptr;     // the level's device buffers, held from prepare to commit (from the device's pool, see LevelBufs)
     int32_t staged_stride = 0;   // > 0: twl_level_restore put this level's DP paths (and the restored ones) into lv->d_paths at this row pitch
     Buf d_gather, d_off, d_plane, d_rowlen;
@@ -165,7 +207,8 @@ int grow_rows(twl_store *s, int64_t need, int64_t want = 0)
 void store_destroy_locked(twl_store *s)
 {
     (void)hipSetDevice(s->d->id);
-    for (auto &kv : s->cache) { kv.second->buf.release(); delete kv.second; }
+    (void)hipStreamSynchronize(s->d->stream);        // (a commit does not wait for its kernels)
+    for (auto &kv : s->cache) { cache_buf_put(s->d, kv.second->buf); delete kv.second; }
     release_level(s->lv);
     for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
         b->release();
@@ -288,6 +331,7 @@ int twl_store_read_cache(twl_store *s, int32_t id, float *out, int32_t *len_out)
     if (!out) return TWL_OK;
     std::lock_guard<std::mutex> lk(s->d->mu);
     HIP_TRY(hipSetDevice(s->d->id));
+    HIP_TRY(hipStreamSynchronize(s->d->stream));     // (a commit does not wait for its kernels)
     HIP_TRY(hipMemcpy(out, it->second->buf.p, (size_t)it->second->len * s->P * sizeof(float), hipMemcpyDeviceToHost));
     return TWL_OK;
 }
@@ -300,7 +344,7 @@ int twl_store_drop_cache(twl_store *s, int32_t id)
     std::lock_guard<std::mutex> lk(s->d->mu);
     (void)hipSetDevice(s->d->id);
     (void)hipStreamSynchronize(s->d->stream);
-    it->second->buf.release();
+    cache_buf_put(s->d, it->second->buf);
     delete it->second;
     s->cache.erase(it);
     return TWL_OK;
@@ -363,7 +407,7 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
             if (s->cache.count(sd.store_id)) { g_err = "store_id already in use"; return TWL_ERR_BAD_ARGUMENT; }
             auto *ce = new CacheEntry();
             ce->len = sd.len;
-            if ((rc = ce->buf.ensure(std::max<size_t>((size_t)sd.len * P * sizeof(float), 16)))) { delete ce; return rc; }
+            if ((rc = cache_buf_get(d, ce->buf, std::max<size_t>((size_t)sd.len * P * sizeof(float), 16)))) { delete ce; return rc; }
             s->cache[sd.store_id] = ce;
             ds.store_slot = slot(sd.store_id);
         }
@@ -567,6 +611,8 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     if ((rc = lv->r_run.ensure(ns * 4 * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_seg.ensure(ns * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_blist.ensure(ns * bstride * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_nboth.ensure(ns * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return rc;
     if ((rc = lv->r_outlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
     const unsigned nb = (unsigned)std::max(1, std::min(32, 1024 / n_sel));      // workgroups per pair of the small alignments (<= ~1.8 GB of scratch)
@@ -578,16 +624,17 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     a.sides = (const twl::SideDesc *)lv->d_sides.p; a.len_red = (const int32_t *)lv->d_len.p;
     a.sel = (const int32_t *)lv->r_sel.p; a.n_sel = n_sel;
     a.orig_idx = (int32_t *)lv->r_oidx.p; a.run = (int32_t *)lv->r_run.p; a.seg = (int32_t *)lv->r_seg.p; a.aoff = (int32_t *)lv->r_aoff.p;
+    a.both_list = (int32_t *)lv->r_blist.p; a.n_both = (int32_t *)lv->r_nboth.p;
     a.arena = (int8_t *)lv->r_arena.p; a.bstride = (int32_t)bstride;
     a.out = (int8_t *)lv->d_paths.p; a.out_stride = out_stride; a.out_len = (int32_t *)lv->r_outlen.p;
     a.tbs = (int8_t *)lv->r_tb.p; a.rows = (float *)lv->r_rows.p;
     a.ms = p->P - 1;
     for (int t = 0; t < a.ms * a.ms; ++t) a.M[t] = p->matrix[t];
     a.gap_open = p->gap_open; a.gap_extend = p->gap_extend;
-    hipLaunchKernelGGL(twl::restore_index_kernel, dim3(2 * (unsigned)n_sel), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(twl::restore_runs_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_index_kernel, dim3(2 * (unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_runs_kernel, dim3((unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
     hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel, nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> all((size_t)n);
     HIP_TRY(hipMemcpyAsync(all.data(), lv->r_outlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -713,9 +760,11 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     const int32_t nChunks = (maxPath + 255) / 256;
 
     constexpr int MG = 16;                      // members per workgroup of the row rewrite
-    std::vector<int32_t> work, merge;
-    std::vector<float> mergew;
-    std::vector<float *> tab;
+    // (the tables the kernels read are kept with the store: the commit does not wait for its uploads and kernels)
+    std::vector<int32_t> &work = s->h_work, &merge = s->h_merge;
+    std::vector<float> &mergew = s->h_mergew;
+    std::vector<float *> &tab = s->h_tab;
+    work.clear(); merge.clear(); mergew.clear(); tab.clear();
     struct Pending { int32_t refId, qryId; CacheEntry *dst; };
     std::vector<Pending> pend;
     for (int32_t i = 0; i < n; ++i) {
@@ -729,7 +778,7 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
         if (rid >= 0 && qid >= 0) {             // updateFrequency: both nodes carry a cached profile
             auto *ce = new CacheEntry();
             ce->len = path_len[i];
-            if ((rc = ce->buf.ensure((size_t)path_len[i] * P * sizeof(float)))) { delete ce; return rc; }
+            if ((rc = cache_buf_get(d, ce->buf, (size_t)path_len[i] * P * sizeof(float)))) { delete ce; return rc; }
             merge.push_back(i);
             merge.push_back((int32_t)tab.size()); tab.push_back((float *)s->cache[rid]->buf.p);
             merge.push_back((int32_t)tab.size()); tab.push_back((float *)s->cache[qid]->buf.p);
@@ -740,10 +789,12 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     }
     // current planes of the members (prepare's table may be stale if a sequence took part in an earlier commit of this level: it cannot,
     // a sequence belongs to one node of one pair per level)
-    std::vector<uint8_t> mplane(s->members.size(), 0);
+    std::vector<uint8_t> &mplane = s->h_mplane;
+    mplane.resize(s->members.size());
     for (size_t k = 0; k < s->members.size(); ++k) mplane[k] = s->plane[s->members[k]];
 
-    HIP_TRY(hipEventRecord(d->ev[0], st));
+    bool hostRows = !from_dp;                  // rows of the caller's `paths` are uploaded: wait for them below
+    HIP_TRY(hipEventRecord(d->ev[6], st));
     if ((rc = s->lv->d_paths.ensure((size_t)n * (size_t)path_stride))) return rc;
     if (!from_dp) HIP_TRY(hipMemcpyAsync(s->lv->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
     else {
@@ -759,7 +810,7 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
             i = j;
         }
         for (int32_t i = 0; i < n; ++i)
-            if (!from_dp[i] && path_len[i] > 0)
+            if (!from_dp[i] && path_len[i] > 0 && (hostRows = true))
                 HIP_TRY(hipMemcpyAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
     }
     s->h_pathlen.assign(path_len, path_len + n);
@@ -794,11 +845,11 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
         else hipLaunchKernelGGL(twl::merge_cache_kernel<22>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(d->ev[1], st));
-    HIP_TRY(hipStreamSynchronize(st));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
-    s->commit_ms = ms;
+    HIP_TRY(hipEventRecord(d->ev[7], st));
+    s->commit_pending = true;
+    // No wait for the kernels: whatever touches the rows, the caches or the level's buffers next is queued behind them on the device's
+    // stream, and the host's share of the next level overlaps with the row rewrite.  (Only the caller's own `paths` must be consumed.)
+    if (hostRows) HIP_TRY(hipStreamSynchronize(st));
 
     // bookkeeping: every member of a committed pair now lives in its other plane with the path's length
     for (int32_t i = 0; i < n; ++i) {
@@ -814,8 +865,8 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     }
     for (const Pending &pe : pend) {            // merged profile replaces the reference node's cache, the query node's is dropped
         CacheEntry *oldR = s->cache[pe.refId], *oldQ = s->cache[pe.qryId];
-        oldR->buf.release(); delete oldR;
-        oldQ->buf.release(); delete oldQ;
+        cache_buf_put(d, oldR->buf); delete oldR;      // (merge_cache_kernel may still read them: the pool hands them out on the same stream)
+        cache_buf_put(d, oldQ->buf); delete oldQ;
         s->cache.erase(pe.qryId);
         s->cache[pe.refId] = pe.dst;
     }
@@ -837,6 +888,15 @@ int twl_level_read_columns(twl_store *s, int32_t pair, int32_t side, float *out,
 int twl_level_timing(twl_store *s, double *prepare_ms, double *commit_ms)
 {
     if (!s) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (s->commit_pending) {
+        std::lock_guard<std::mutex> lk(s->d->mu);
+        HIP_TRY(hipSetDevice(s->d->id));
+        HIP_TRY(hipEventSynchronize(s->d->ev[7]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->d->ev[6], s->d->ev[7]));
+        s->commit_ms = ms;
+        s->commit_pending = false;
+    }
     if (prepare_ms) *prepare_ms = s->prepare_ms;
     if (commit_ms) *commit_ms = s->commit_ms;
     return TWL_OK;
