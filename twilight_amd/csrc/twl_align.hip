@@ -25,6 +25,36 @@
 #include <unordered_map>
 #include <vector>
 
+namespace twl {
+// Several byte fills in one launch (a level's DP call zeroes its outputs, work counters and tile tables: seven hipMemsetAsync before).
+struct FillJob { void *p; unsigned long long bytes; unsigned int val; };
+struct FillArgs { FillJob j[8]; int n; };
+__global__ void __launch_bounds__(256) fill_kernel(FillArgs a)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+    for (int r = 0; r < a.n; ++r) {
+        const size_t nw = a.j[r].bytes >> 4;
+        uint4 *w = reinterpret_cast<uint4 *>(a.j[r].p);
+        const unsigned v = a.j[r].val;
+        for (size_t i = t; i < nw; i += nt) w[i] = make_uint4(v, v, v, v);
+        const size_t tail = a.j[r].bytes & 15;
+        if (t < tail) reinterpret_cast<unsigned char *>(a.j[r].p)[(nw << 4) + t] = (unsigned char)v;
+    }
+}
+// The per-pair results of a DP call (and the tile-parallel counters) into one host-visible block: [4 counters][n cells][n lengths][n codes]
+__global__ void __launch_bounds__(256) collect_kernel(int n, const int16_t *err, const int32_t *aln_len, const unsigned long long *cells,
+                                                      const unsigned long long *mt_stat, unsigned long long *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long *oc = out + 4;
+    int32_t *ol = reinterpret_cast<int32_t *>(oc + n);
+    int16_t *oe = reinterpret_cast<int16_t *>(ol + n);
+    if (i < 4) out[i] = mt_stat ? mt_stat[i] : 0ull;
+    if (i < n) { oc[i] = cells[i]; ol[i] = aln_len[i]; oe[i] = err[i]; }
+    __threadfence_system();
+}
+}  // namespace twl
+
 namespace {
 
 thread_local std::string g_err;
@@ -89,6 +119,10 @@ struct Device {
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
     twl_stats stats{};
     std::vector<uint64_t> pair_cells;
+    twl::FillArgs fills{};                                                        // byte fills queued for ONE launch in front of the next kernel (queue_fill / flush_fills)
+    char *res_h = nullptr;                                                       // pinned host block the results of a call come back in (collect_kernel writes it)
+    size_t res_cap = 0;
+    std::vector<int32_t> last_alnlen;                                            // path lengths of the last run_device call, as read back by it
     std::mutex mu;
 };
 
@@ -101,6 +135,28 @@ int find_dev(int device, Device **out)
     g_err = "device not selected in twl_init";
     return TWL_ERR_BAD_ARGUMENT;
 }
+
+// Byte fills queued in front of the next kernel of the device's stream: one launch for all of them (16-byte aligned pointers).
+int flush_fills(Device *d, hipStream_t st)
+{
+    if (d->fills.n == 0) return TWL_OK;
+    unsigned long long most = 0;
+    for (int r = 0; r < d->fills.n; ++r) most = std::max(most, d->fills.j[r].bytes);
+    const unsigned blocks = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((most / 16 + 255) / 256, (unsigned long long)d->num_cu * 8));
+    hipLaunchKernelGGL(twl::fill_kernel, dim3(blocks), dim3(256), 0, st, d->fills);
+    d->fills.n = 0;
+    HIP_TRY(hipGetLastError());
+    return TWL_OK;
+}
+int queue_fill(Device *d, hipStream_t st, void *p, size_t bytes, unsigned char v)
+{
+    if (!bytes) return TWL_OK;
+    if (((size_t)p & 15) != 0) { HIP_TRY(hipMemsetAsync(p, v, bytes, st)); return TWL_OK; }
+    if (d->fills.n == 8) { const int rc = flush_fills(d, st); if (rc) return rc; }
+    d->fills.j[d->fills.n++] = twl::FillJob{p, (unsigned long long)bytes, 0x01010101u * v};
+    return TWL_OK;
+}
+#define FILL_TRY(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 int check_params(const twl_params *p)
 {
@@ -143,7 +199,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.tb_words = (int32_t)tbw;
     a.items = d_items;
     a.n_items = n_items;
-    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    FILL_TRY(queue_fill(d, st, d->queue.p, sizeof(int32_t), 0));
     int32_t *hb = nullptr;
 #ifdef TWL_KERNEL_DEBUG
     if (dbg_on()) {
@@ -154,6 +210,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 #endif
     TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
     if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_kernel<%d, %d, %d, %s, %s, %s, %d, %d>", P, W, RPL, PRE ? "true" : "false", REFLDS ? "true" : "false", QREG ? "true" : "false", MINW, MM);
+    FILL_TRY(flush_fills(d, st));
     hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
@@ -202,16 +259,17 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
     for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
     a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
-    HIP_TRY(hipMemsetAsync(d->queue.p, 0, sizeof(int32_t), st));
+    FILL_TRY(queue_fill(d, st, d->queue.p, sizeof(int32_t), 0));
     if (SPEC) {
         if ((rc = d->team.ensure((size_t)n_items * twl::kTeamWords * sizeof(unsigned long long)))) return rc;
-        HIP_TRY(hipMemsetAsync(d->team.p, 0, (size_t)n_items * twl::kTeamWords * sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(a.cells, 0, (size_t)base.n_pairs_total * sizeof(unsigned long long), st));
+        FILL_TRY(queue_fill(d, st, d->team.p, (size_t)n_items * twl::kTeamWords * sizeof(unsigned long long), 0));
+        FILL_TRY(queue_fill(d, st, a.cells, (size_t)base.n_pairs_total * sizeof(unsigned long long), 0));
         a.team = (unsigned long long *)d->team.p;
     }
     TRACE("launch lean P=%d W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", P, W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
     if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, %d, %s, %s, 0>", P, W, RPL, MM, MINW, SPEC ? "true" : "false", DUMP ? "true" : "false");
     a.simdump = DUMP ? (float *)d->simdump.p : nullptr;
+    FILL_TRY(flush_fills(d, st));
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (SPEC && (dbg_on() || dev_env("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
@@ -244,6 +302,7 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
     a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
     // (every launch of a tile-parallel level has its own work counter: launch_mt zeroed the 16 of them in one go)
     a.queue = (int32_t *)d->queue.p + (d->mt_launch++ & 15);
+    FILL_TRY(flush_fills(d, st));
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (grid_out) *grid_out = grid;
@@ -293,10 +352,10 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     if ((rc = d->mt_stat.ensure(4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t)))) return rc;      // counters, then the per-pair frontier
     if ((rc = d->mt_jobs.ensure(jobs.size() * sizeof(int32_t)))) return rc;
     HIP_TRY(hipMemcpyAsync(d->mt_jobs.p, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d->mt_rec.p, 0, np * slots * twl::kMtRec * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(d->mt_spath.p, 0xFE, np * (size_t)sp_pitch * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(d->mt_stat.p, 0, 4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(d->queue.p, 0, 16 * sizeof(int32_t), st));
+    FILL_TRY(queue_fill(d, st, d->mt_rec.p, np * slots * twl::kMtRec * sizeof(int32_t), 0));
+    FILL_TRY(queue_fill(d, st, d->mt_spath.p, np * (size_t)sp_pitch * sizeof(int32_t), 0xFE));
+    FILL_TRY(queue_fill(d, st, d->mt_stat.p, 4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t), 0));
+    FILL_TRY(queue_fill(d, st, d->queue.p, 16 * sizeof(int32_t), 0));
     d->mt_launch = 0;
     twl::NArgs a{};
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
@@ -323,6 +382,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     }
     const int rounds = std::max(1, g_mt_rounds);
     for (int r = 0; r < rounds; ++r) {
+        FILL_TRY(flush_fills(d, st));
         hipLaunchKernelGGL(twl::mt_chain_kernel, dim3((n_run + 63) / 64), dim3(64), 0, st, (const int32_t *)d->mt_spath.p, sp_pitch, base.len, d_items, n_run,
                            (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
         HIP_TRY(hipGetLastError());
@@ -348,7 +408,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     HIP_TRY(hipSetDevice(d->id));
     d->stats = twl_stats{};
     d->kname[0] = 0;
+    d->fills.n = 0;
     d->last_err.clear();
+    d->last_alnlen.clear();
     d->pair_cells.assign((size_t)n_pairs, 0);
     if (n_pairs == 0) return TWL_OK;
 
@@ -416,9 +478,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     { const int ms = p->P - 1; for (int l = 0; l < ms; ++l) for (int m = 0; m < ms; ++m) a.M[ms * l + m] = p->matrix[ms * l + m]; }
 
     // the pairs that do not run: path length 0, errorType 0, no cells
-    HIP_TRY(hipMemsetAsync(d_alnlen, 0, (size_t)n_pairs * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(d_err, 0, (size_t)n_pairs * sizeof(int16_t), st));
-    HIP_TRY(hipMemsetAsync(d->cells.p, 0, (size_t)n_pairs * sizeof(unsigned long long), st));
+    FILL_TRY(queue_fill(d, st, d_alnlen, (size_t)n_pairs * sizeof(int32_t), 0));
+    FILL_TRY(queue_fill(d, st, d_err, (size_t)n_pairs * sizeof(int16_t), 0));
+    FILL_TRY(queue_fill(d, st, d->cells.p, (size_t)n_pairs * sizeof(unsigned long long), 0));
 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
@@ -489,6 +551,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
                 sa.n_items = n_run; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p;
                 sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
+                FILL_TRY(flush_fills(d, st));
                 hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_run]), dim3(256), 0, st, sa);
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
@@ -593,6 +656,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
     if (rc) return rc;
+    FILL_TRY(flush_fills(d, st));      // (nothing ran: the outputs are still to be zeroed)
     HIP_TRY(hipEventRecord(d->ev[2], st));
     d->stats.n_launches = 1;
     d->stats.grid = grid;
@@ -607,15 +671,31 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     std::vector<int16_t> h_err((size_t)n_pairs);
     std::vector<unsigned long long> cells((size_t)n_pairs);
     unsigned long long mtStat[4] = {0, 0, 0, 0};
+    // (one small kernel writes them into a pinned host block: three device-to-host copies into pageable memory before)
+    const size_t resBytes = 4 * sizeof(unsigned long long) + (size_t)n_pairs * (sizeof(unsigned long long) + sizeof(int32_t) + sizeof(int16_t));
+    if (resBytes > d->res_cap) {
+        if (d->res_h) (void)hipHostFree(d->res_h);
+        d->res_h = nullptr; d->res_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&d->res_h, resBytes + resBytes / 2, hipHostMallocDefault));
+        d->res_cap = resBytes + resBytes / 2;
+    }
+    auto collect = [&](bool withCells) -> int {
+        hipLaunchKernelGGL(twl::collect_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, (int)n_pairs, (const int16_t *)d_err, (const int32_t *)d_alnlen,
+                           (const unsigned long long *)d->cells.p, ranMt ? (const unsigned long long *)d->mt_stat.p : nullptr, (unsigned long long *)d->res_h);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        const unsigned long long *r = (const unsigned long long *)d->res_h;
+        const int32_t *rl = (const int32_t *)(r + 4 + n_pairs);
+        const int16_t *re = (const int16_t *)(rl + n_pairs);
+        std::copy(re, re + n_pairs, h_err.begin());
+        d->last_alnlen.assign(rl, rl + n_pairs);
+        if (withCells) { std::copy(r + 4, r + 4 + n_pairs, cells.begin()); if (ranMt) for (int t = 0; t < 4; ++t) mtStat[t] = r[t]; }
+        return TWL_OK;
+    };
     bool reran = false;
     float ms_redo = 0.f;
     for (int stage = 1; stage <= 2; ++stage) {
-        HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-        if (!reran) {
-            HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            if (ranMt) HIP_TRY(hipMemcpyAsync(mtStat, d->mt_stat.p, sizeof mtStat, hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = collect(!reran))) return rc;
         if (stage == 1) TRACE("dp kernel done");
         // first the pairs with an operand outside the fast division's range (lean kernels only): the IEEE-division kernel of the same window
         std::vector<int32_t> redo;
@@ -649,9 +729,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     if (reran) {
-        HIP_TRY(hipMemcpyAsync(h_err.data(), d_err, h_err.size() * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(cells.data(), d->cells.p, cells.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
+        if ((rc = collect(true))) return rc;
+        for (int t = 0; t < 4; ++t) mtStat[t] = keep[t];      // (the counters of the first launch: a re-run does not touch them)
     }
     for (int32_t n = 0; n < n_pairs; ++n)
         if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
@@ -754,6 +834,7 @@ void twl_shutdown(void)
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
         if (d->stream) (void)hipStreamDestroy(d->stream);
+        if (d->res_h) (void)hipHostFree(d->res_h);
         delete d;
     }
     g_devs.clear();

@@ -16,22 +16,83 @@ struct CacheEntry {
 
 }  // namespace
 
+// The small tables a call hands to its kernels (side descriptors, member lists, work lists ...) travel as ONE copy: they are laid out
+// back to back in a pinned host block and land in a device block of the same layout.  One arena per kind of call (prepare / align /
+// restore / commit): a call rewrites its host block only after an earlier synchronisation of the same store has seen the previous
+// copy out of it complete, and the device block is rewritten in stream order behind the kernels that read the old content.
+struct Ref { void *p = nullptr; };      // a table inside an arena
+struct PinBuf {                         // pinned host memory a device-to-host copy lands in (no staging through pageable memory)
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return TWL_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        HIP_TRY(hipHostMalloc(&p, bytes + bytes / 2 + 256, hipHostMallocDefault));
+        cap = bytes + bytes / 2 + 256;
+        return TWL_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+struct Arena {
+    char *h = nullptr;
+    size_t hcap = 0, used = 0;
+    Buf d;
+    int begin(size_t bytes, size_t tables)      // room for `bytes` of payload in `tables` tables
+    {
+        const size_t want = bytes + 256 * (tables + 1);
+        if (want > hcap) {
+            if (h) (void)hipHostFree(h);
+            h = nullptr; hcap = 0;
+            const size_t cap = want + want / 2;
+            HIP_TRY(hipHostMalloc((void **)&h, cap, hipHostMallocDefault));
+            hcap = cap;
+        }
+        used = 0;
+        return d.ensure(hcap);
+    }
+    template <class T>
+    void put(Ref &r, const T *src, size_t n)
+    {
+        used = (used + 255) & ~(size_t)255;
+        if (n) memcpy(h + used, src, n * sizeof(T));
+        r.p = (char *)d.p + used;
+        used += std::max<size_t>(n * sizeof(T), 16);
+    }
+    template <class T> void put(Ref &r, const std::vector<T> &v) { put(r, v.data(), v.size()); }
+    int flush(hipStream_t st)
+    {
+        if (used) HIP_TRY(hipMemcpyAsync(d.p, h, used, hipMemcpyHostToDevice, st));
+        return TWL_OK;
+    }
+    void release() { if (h) (void)hipHostFree(h); h = nullptr; hcap = 0; d.release(); }
+};
+
 // The device buffers of one prepared level (raw and packed columns are GBs at the leaf level).  They belong to the DEVICE, not to the
 // store: a store takes a set at twl_level_prepare and gives it back at twl_level_commit, so the runs of a process that align one after
 // the other work in the same, already mapped memory (device memory a process has not touched before costs tens of ms per GB:
 // tools/micro/alloc_cost.hip), and a run holds only its rows while it waits.  Stores that are between prepare and commit at the same
 // time (device replicas of a test) get a set each.
 struct LevelBufs {
-    Buf d_sides, d_mseq, d_mw, d_mplane, d_tab, d_raw, d_colinfo, d_cols, d_len, d_lenmask, d_num, d_aln, d_alnlen, d_err;
-    Buf d_paths, d_pathlen, d_chunk, d_work, d_merge, d_mergew, d_ccnt;
-    Buf r_sel, r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
+    Arena up_prepare, up_align, up_restore, up_commit;
+    PinBuf back;                                             // lengths coming back from prepare / restore
+    Ref d_sides, d_mseq, d_mw, d_mplane, d_tab, d_num;       // up_prepare (d_mplane, d_tab: up_commit after the commit's upload)
+    Ref d_lenmask;                                           // up_align
+    Ref r_sel;                                               // up_restore
+    Ref d_pathlen, d_work, d_merge, d_mergew;                // up_commit
+    Buf d_raw, d_colinfo, d_cols, d_len, d_aln, d_alnlen, d_err;
+    Buf d_paths, d_chunk, d_ccnt;
+    Buf r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
     Buf x_send, x_recv, x_rowoff, x_blkoff, x_len;                                  // exchange of final paths between processes (device blocks)
     bool busy = false;
     void release_all()
     {
-        for (Buf *b : {&d_sides, &d_mseq, &d_mw, &d_mplane, &d_tab, &d_raw, &d_colinfo, &d_cols, &d_len, &d_lenmask, &d_num, &d_aln, &d_alnlen, &d_err,
-                       &d_paths, &d_pathlen, &d_chunk, &d_work, &d_merge, &d_mergew, &d_ccnt, &r_sel, &r_oidx, &r_run, &r_seg, &r_aoff, &r_blist, &r_nboth, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
+        for (Buf *b : {&d_raw, &d_colinfo, &d_cols, &d_len, &d_aln, &d_alnlen, &d_err,
+                       &d_paths, &d_chunk, &d_ccnt, &r_oidx, &r_run, &r_seg, &r_aoff, &r_blist, &r_nboth, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
             b->release();
+        for (Arena *a : {&up_prepare, &up_align, &up_restore, &up_commit}) a->release();
+        back.release();
     }
 };
 
@@ -118,8 +179,7 @@ struct twl_store {
     std::vector<twl_side> sides;
     std::vector<int32_t> members;
     std::vector<int32_t> h_len, h_num;
-    std::vector<float> h_mw;                 // host copies that asynchronous uploads read from (kept with the store instead of synchronising)
-    std::vector<int32_t> h_sel, h_pathlen, h_work, h_merge;
+    std::vector<int32_t> h_work, h_merge;    // scratch of the commit (kept for its capacity)
     std::vector<float> h_mergew;
     std::vector<float *> h_tab;
     std::vector<uint8_t> h_mplane;
@@ -416,13 +476,17 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     for (size_t i = 0; i < ns; ++i) s->h_num[i] = sides[i].num;
 
     HIP_TRY(hipEventRecord(d->ev[0], st));
-    if ((rc = upload(s->lv->d_sides, dsides, st))) return rc;
-    if ((rc = upload(s->lv->d_mseq, s->members, st))) return rc;
-    s->h_mw.assign(member_weight, member_weight + nm);
-    if ((rc = upload(s->lv->d_mw, s->h_mw, st))) return rc;
-    if ((rc = upload(s->lv->d_mplane, mplane, st))) return rc;
-    if ((rc = upload(s->lv->d_tab, tab, st))) return rc;
-    if ((rc = upload(s->lv->d_num, s->h_num, st))) return rc;
+    {
+        Arena &A = s->lv->up_prepare;
+        if ((rc = A.begin(ns * (sizeof(twl::SideDesc) + sizeof(int32_t)) + nm * (sizeof(int32_t) + sizeof(float) + 1) + tab.size() * sizeof(float *), 6))) return rc;
+        A.put(s->lv->d_sides, dsides);
+        A.put(s->lv->d_mseq, s->members);
+        A.put(s->lv->d_mw, member_weight, nm);
+        A.put(s->lv->d_mplane, mplane);
+        A.put(s->lv->d_tab, tab);
+        A.put(s->lv->d_num, s->h_num);
+        if ((rc = A.flush(st))) return rc;
+    }
     if ((rc = s->lv->d_raw.ensure(ns * sl * P * sizeof(float)))) return rc;
     if ((rc = s->lv->d_colinfo.ensure(ns * sl))) return rc;
     if ((rc = s->lv->d_cols.ensure(ns * sl * (P + 2) * sizeof(float)))) return rc;
@@ -464,9 +528,11 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(d->ev[1], st));
     s->h_len.resize(ns);
-    HIP_TRY(hipMemcpyAsync(s->h_len.data(), s->lv->d_len.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if ((rc = s->lv->back.ensure(ns * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->lv->back.p, s->lv->d_len.p, ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (colinfo_out) HIP_TRY(hipMemcpyAsync(colinfo_out, s->lv->d_colinfo.p, ns * sl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    memcpy(s->h_len.data(), s->lv->back.p, ns * sizeof(int32_t));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1]));
     s->prepare_ms = ms;
@@ -508,7 +574,12 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     std::vector<int32_t> lm(s->h_len);
     if (run_mask)
         for (int32_t i = 0; i < n; ++i) if (!run_mask[i]) lm[2 * i] = lm[2 * i + 1] = 0;
-    if ((rc = upload(s->lv->d_lenmask, lm, st))) return rc;
+    {
+        Arena &A = s->lv->up_align;
+        if ((rc = A.begin(lm.size() * sizeof(int32_t), 1))) return rc;
+        A.put(s->lv->d_lenmask, lm);
+        if ((rc = A.flush(st))) return rc;
+    }
     if ((rc = s->lv->d_aln.ensure((size_t)n * 2 * sl))) return rc;
     if ((rc = s->lv->d_alnlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
     if ((rc = s->lv->d_err.ensure((size_t)n * sizeof(int16_t)))) return rc;
@@ -520,14 +591,19 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->lv->d_lenmask.p, (const int32_t *)s->lv->d_num.p, (int8_t *)s->lv->d_aln.p,
                     (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(aln_len_out, s->lv->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if ((int32_t)d->last_err.size() == n) std::copy(d->last_err.begin(), d->last_err.end(), err_out);      // (run_device read them back already)
-    else HIP_TRY(hipMemcpyAsync(err_out, s->lv->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((int32_t)d->last_err.size() == n && (int32_t)d->last_alnlen.size() == n) {      // (run_device read them back already, in its one synchronisation)
+        std::copy(d->last_err.begin(), d->last_err.end(), err_out);
+        std::copy(d->last_alnlen.begin(), d->last_alnlen.end(), aln_len_out);
+        if (!aln_out) { d->stats.total_ms = d->stats.kernel_ms; return TWL_OK; }       // the paths stay in HBM (twl_level_read_path / twl_level_commit_from_dp)
+    } else {
+        HIP_TRY(hipMemcpyAsync(aln_len_out, s->lv->d_alnlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(err_out, s->lv->d_err.p, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     // paths: bulk when most pairs ran, else one copy per pair that has a path
     int32_t ran = 0;
     for (int32_t i = 0; i < n; ++i) ran += aln_len_out[i] > 0;
-    if (!aln_out) {}                            // the paths stay in HBM (twl_level_read_path / twl_level_commit_from_dp)
+    if (!aln_out) {}
     else if (ran * 2 >= n) HIP_TRY(hipMemcpyAsync(aln_out, s->lv->d_aln.p, (size_t)n * 2 * sl, hipMemcpyDeviceToHost, st));
     else
         for (int32_t i = 0; i < n; ++i)
@@ -605,8 +681,12 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     s->staged_stride = out_stride;
     if (n_sel == 0) return TWL_OK;
     const size_t ns = (size_t)n_sel;
-    s->h_sel.assign(pairs, pairs + n_sel);
-    if ((rc = upload(lv->r_sel, s->h_sel, st))) return rc;
+    {
+        Arena &A = lv->up_restore;
+        if ((rc = A.begin(ns * sizeof(int32_t), 1))) return rc;
+        A.put(lv->r_sel, pairs, ns);
+        if ((rc = A.flush(st))) return rc;
+    }
     if ((rc = lv->r_oidx.ensure(2 * ns * (sl + 1) * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_run.ensure(ns * 4 * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_seg.ensure(ns * bstride * sizeof(int32_t)))) return rc;
@@ -636,9 +716,10 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel, nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> all((size_t)n);
-    HIP_TRY(hipMemcpyAsync(all.data(), lv->r_outlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if ((rc = lv->back.ensure((size_t)n * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipMemcpyAsync(lv->back.p, lv->r_outlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const int32_t *all = (const int32_t *)lv->back.p;
     for (int32_t t = 0; t < n_sel; ++t) final_len_out[t] = all[pairs[t]];
     return TWL_OK;
 }
@@ -760,7 +841,6 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     const int32_t nChunks = (maxPath + 255) / 256;
 
     constexpr int MG = 16;                      // members per workgroup of the row rewrite
-    // (the tables the kernels read are kept with the store: the commit does not wait for its uploads and kernels)
     std::vector<int32_t> &work = s->h_work, &merge = s->h_merge;
     std::vector<float> &mergew = s->h_mergew;
     std::vector<float *> &tab = s->h_tab;
@@ -813,14 +893,18 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
             if (!from_dp[i] && path_len[i] > 0 && (hostRows = true))
                 HIP_TRY(hipMemcpyAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
     }
-    s->h_pathlen.assign(path_len, path_len + n);
-    if ((rc = upload(s->lv->d_pathlen, s->h_pathlen, st))) return rc;
     if ((rc = s->lv->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
-    if ((rc = upload(s->lv->d_work, work, st))) return rc;
-    if ((rc = upload(s->lv->d_merge, merge, st))) return rc;
-    if ((rc = upload(s->lv->d_mergew, mergew, st))) return rc;
-    if ((rc = upload(s->lv->d_tab, tab, st))) return rc;
-    if ((rc = upload(s->lv->d_mplane, mplane, st))) return rc;
+    {
+        Arena &A = s->lv->up_commit;
+        if ((rc = A.begin(((size_t)n + work.size() + merge.size()) * sizeof(int32_t) + mergew.size() * sizeof(float) + tab.size() * sizeof(float *) + mplane.size(), 6))) return rc;
+        A.put(s->lv->d_pathlen, path_len, (size_t)n);
+        A.put(s->lv->d_work, work);
+        A.put(s->lv->d_merge, merge);
+        A.put(s->lv->d_mergew, mergew);
+        A.put(s->lv->d_tab, tab);
+        A.put(s->lv->d_mplane, mplane);
+        if ((rc = A.flush(st))) return rc;
+    }
 
     twl::CommitArgs a{};
     a.paths = (const int8_t *)s->lv->d_paths.p;
