@@ -143,7 +143,7 @@ int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq
      TWL_KNOB_MT_PERTURB     n > 0: spoil every n-th predicted tile start of the tile-parallel path, so that its stitch launch has tiles to
                              compute in line (tests of that path); 0 = off (default)
      TWL_KNOB_MT_MAX_PAIRS   levels with at most this many pairs may take the tile-parallel path (default 1024; 0 = never): all levels of up to CUs/2 pairs, larger
-                             ones when their pairs fill the last round of the throughput kernel badly
+                             ones (up to 2 * CUs, one round of the throughput kernel) when they would fill that round badly
      TWL_KNOB_MT_MIN_MARKER  ... and only with marker >= this (default 512)
      TWL_KNOB_MT_LEAD        anti-diagonals a scout starts ahead of its tile boundary (default 320)
      TWL_KNOB_MT_MARGIN      anti-diagonals a scout runs past its tile boundary (default 40)
@@ -155,10 +155,13 @@ int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq
                              5 lean sparse, 6 lean precomputed -- every variant computes the same sums (tests hold each to the oracle)
      TWL_KNOB_ASSUME_ONEHOT_QUERY  1: the caller promises that every query row of twl_align_batch has at most one non-zero letter
                              (single sequences), which selects the four-product column score; the device-resident level path
-                             (twl_level.h) knows this by itself */
+                             (twl_level.h) knows this by itself
+     TWL_KNOB_MT_TAIL_PCT    levels of more than 2 * CUs pairs: a last round of the throughput kernel that would be filled to at most this
+                             share (percent, default 70) runs on the tile-parallel path instead, behind the full rounds, when its pairs have 8 or more
+                             tiles each (0 = never) */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11 };
 int twl_set_knob(int key, int value);
 
 #ifdef __cplusplus

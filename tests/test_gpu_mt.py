@@ -221,3 +221,31 @@ def test_random_campaign_on_the_tile_parallel_path(knobs):
         mt, _ = check_mt_case(knobs, seed)
         took += mt
     assert took >= 20, took      # most cases are long enough to take the tile-parallel path
+
+
+def test_badly_filled_last_round_goes_through_tiles(knobs):
+    """More pairs than persistent workgroups (2 per CU) with a small remainder: the full rounds run on the throughput kernel, the remainder
+    (the shortest pairs) on the tile-parallel path behind it -- one call, two kinds of launches, same results.  12 distinct pairs replicated."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n = 2 * cus + 27
+    pool = synth.make_level_batch(12, 4400, members=((1, 6), (1, 6)), seed=77)      # 8+ tiles of 1024 anti-diagonals each
+    idx = np.arange(n) % pool.n_pairs
+    batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    p = knobs.make_params(M)
+    aln, ln, err = knobs.align_batch(p, batch)
+    st = knobs.get_stats(0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M), pool, threads=8)
+    assert st.mt_tiles_predicted + st.mt_tiles_inline > 0, "the remainder did not take the tile-parallel path"
+    assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx])
+    for i in range(n):
+        assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"
+    knobs.set_knob(api.KNOB_MT_TAIL_PCT, 0)      # never: the same call on the throughput kernel alone
+    try:
+        aln2, ln2, err2 = knobs.align_batch(p, batch)
+        st2 = knobs.get_stats(0)
+    finally:
+        knobs.set_knob(api.KNOB_MT_TAIL_PCT, 70)
+    assert st2.mt_tiles_predicted + st2.mt_tiles_inline == 0
+    assert np.array_equal(aln, aln2) and np.array_equal(ln, ln2) and np.array_equal(err, err2)
+    assert st.band_cells == st2.band_cells

@@ -1,7 +1,8 @@
 """Timing experiments on copies of the library built with an experiment flag (-DTWL_EXP_SALU / -DTWL_EXP_VALU: 24 extra scalar / vector
 instructions per wave and diagonal): what does a wide level and a lone pair cost then?  (The convergence-test experiment this script was
 written for led to the pre-test of DESIGN.md section 3.1.)
-    python tools/exp_conv8.py [base | TWL_EXP_SALU | TWL_EXP_VALU]        (GPU box; does not touch the product library)"""
+    python tools/exp_step_cost.py [base | TWL_EXP_SALU | TWL_EXP_VALU | <label> <compiler flags...>]        (GPU box; does not touch the product library;
+    prints a checksum of the paths so that a flag experiment can be compared with the base build)"""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,10 +11,14 @@ import torch
 from twilight_amd import synth, api
 
 so = os.path.join(tempfile.mkdtemp(), "libtwl_exp.so")
-which = sys.argv[1] if len(sys.argv) > 1 else "base"      # base | TWL_EXP_SALU | TWL_EXP_VALU (a -D flag of an experiment build)
-if which != "base":
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                           "-D" + which, "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
+which = sys.argv[1] if len(sys.argv) > 1 else "base"      # base | TWL_EXP_SALU | TWL_EXP_VALU (a -D flag of an experiment build) | any label followed by compiler flags
+if which.endswith(".so"):          # a library built elsewhere (cross-compiled variants travel with the repository snapshot)
+    api.LIB_PATH = os.path.abspath(which)
+    which = os.path.basename(which)
+elif which != "base":
+    extra = sys.argv[2:] if len(sys.argv) > 2 else ["-D" + which]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"] + extra +
+                          ["-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
     api.LIB_PATH = so
 api.init([0])
 dev = torch.device("cuda:0")
@@ -30,4 +35,6 @@ for n, mt in ((2048, 1024), (1, 1024), (1, 0), (100, 1024)):
         api.align_batch_device(p, n, b.seq_len, freq.data_ptr(), gop.data_ptr(), gex.data_ptr(), ln.data_ptr(), nm.data_ptr(), aln.data_ptr(), alen.data_ptr(), err.data_ptr())
         torch.cuda.synchronize()
         st = api.get_stats(0)
-    print(f"{which}: pairs {n} mt_max {mt}: kernel {st.kernel_ms:.2f} ms, cells {st.band_cells:.4g}, {st.kernel.decode()[:60]}", flush=True)
+    import hashlib
+    h = hashlib.md5(aln.cpu().numpy().tobytes() + alen.cpu().numpy().tobytes() + err.cpu().numpy().tobytes()).hexdigest()[:12]
+    print(f"{which}: pairs {n} mt_max {mt}: kernel {st.kernel_ms:.2f} ms, cells {st.band_cells:.4g}, paths {h}, {st.kernel.decode()[:60]}", flush=True)

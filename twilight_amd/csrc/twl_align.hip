@@ -315,6 +315,7 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
+int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 
@@ -613,11 +614,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         long long sumLen = 0;
         for (int32_t t = 0; t < n_run; ++t) sumLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
         // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the
-        // pairs fill the last round of the throughput kernel badly (2 * CUs persistent workgroups: 646 pairs = 1.26 rounds cost 2) --
-        // tiles spread evenly, at the price of the scouts (~1.2x the work)
+        // pairs fill the ONE round of the throughput kernel badly (2 * CUs persistent workgroups) -- tiles spread evenly, at the price of
+        // the scouts (~1.2x the work).  Levels of several rounds: see the remainder rule at the throughput launch below.
         const double roundsThr = (double)n_run / (2.0 * d->num_cu);
         const bool mtOk = lean && mm == 2 && !mm5 && !d->dump_on && n_run <= g_mt_max_pairs && p->marker >= g_mt_min_marker &&
-                          sumLen >= 3ll * p->marker * n_run && (2 * n_run <= d->num_cu || std::ceil(roundsThr) >= 1.2 * roundsThr);
+                          sumLen >= 3ll * p->marker * n_run && (2 * n_run <= d->num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
             if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_run, &grid, &window);
@@ -645,10 +646,25 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_run, &grid, &window);
         } else if (lean) {
-            if (mm5) rc = launch_lean<6, 8, 2, 5, 4>(d, st, a, items, n_run, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, n_run, &grid, &window);
-            else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, n_run, &grid, &window);
-            else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, n_run, &grid, &window);
+            // Many pairs: 2 * CUs persistent workgroups take them in rounds.  A last round that is badly filled costs a whole round: when
+            // the remainder is small enough its pairs (the shortest ones, the order is longest first) go through the tile-parallel path
+            // instead, where they spread over all CUs (1301 pairs of 10 kbp = 2.54 rounds: 3 rounds 84 ms, 2 rounds + 277 pairs in tiles 76 ms).
+            const int R = 2 * d->num_cu;
+            int tail = n_run % R;
+            long long tailLen = 0;
+            for (int32_t t = n_run - tail; t < n_run; ++t) tailLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
+            if (!(n_run > R && tail > 0 && tail * 100 <= g_mt_tail_pct * R && mm == 2 && p->marker >= g_mt_min_marker && tailLen >= 8ll * p->marker * tail)) tail = 0;      // (pairs of 8+ tiles: with fewer the scouts and extra launches cost more than the idle workgroups)
+            const int bulk = n_run - tail;
+            if (mm5) rc = launch_lean<6, 8, 2, 5, 4>(d, st, a, items, bulk, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, bulk, &grid, &window);
+            else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, bulk, &grid, &window);
+            else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, bulk, &grid, &window);
+            if (!rc && tail > 0) {
+                const std::vector<int32_t> tailOrder(order.begin() + bulk, order.begin() + n_run);
+                int g2 = 0, w2 = 0;
+                rc = launch_mt<6, 2, 2>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
+                ranMt = true;
+            }
         }
         else if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_run, 0, &grid, &window);
         else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_run, 0, &grid, &window);
@@ -810,6 +826,7 @@ int twl_init(const int *device_ids, int n_devices)
     if (const char *v = getenv("TWL_MT_PERTURB")) g_mt_perturb = atoi(v);
     if (const char *v = getenv("TWL_MT_ROUNDS")) g_mt_rounds = atoi(v);
     if (const char *v = getenv("TWL_MT_THR_JOBS")) g_mt_thr_jobs = atoi(v);
+    if (const char *v = getenv("TWL_MT_TAIL_PCT")) g_mt_tail_pct = atoi(v);
 #endif
     return TWL_OK;
 }
@@ -1138,6 +1155,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_FAIL_ROW_ALLOCS: g_fail_next_row_allocs = std::max(0, value); return TWL_OK;
     case TWL_KNOB_PROT_MODE: if (value < 0 || value > 6) { g_err = "protein mode 0..6"; return TWL_ERR_BAD_ARGUMENT; } g_prot_mode = value; return TWL_OK;
     case TWL_KNOB_ASSUME_ONEHOT_QUERY: g_assume_onehot_query = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_MT_TAIL_PCT: g_mt_tail_pct = std::max(0, std::min(100, value)); return TWL_OK;
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }
