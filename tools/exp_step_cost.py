@@ -17,15 +17,17 @@ if which.endswith(".so"):          # a library built elsewhere (cross-compiled v
     which = os.path.basename(which)
 elif which != "base":
     extra = sys.argv[2:] if len(sys.argv) > 2 else ["-D" + which]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"] + extra +
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17"] + extra +
                           ["-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
     api.LIB_PATH = so
 api.init([0])
 dev = torch.device("cuda:0")
 p = api.make_params(synth.nucleotide_matrix())
-for n, mt in ((2048, 1024), (1, 1024), (1, 0), (100, 1024)):
+cases = [(2048, 1024, 6), (1, 1024, 6), (1, 0, 6), (100, 1024, 6), (2048, 1024, 22), (64, 1024, 22)]      # pairs, MT_MAX_PAIRS, P (22: 2 kaa protein pairs)
+for n, mt, P in cases:
     api.set_knob(api.KNOB_MT_MAX_PAIRS, mt)
-    b = synth.make_level_batch(min(n, 32), 10000, members=((1, 8), (1, 8)), seed=5)
+    if P == 22: p = api.make_params(synth.protein_matrix())
+    b = synth.make_level_batch(min(n, 32), 10000, members=((1, 8), (1, 8)), seed=5) if P == 6 else synth.make_level_batch(min(n, 32), 2000, members=((1, 8), (1, 8)), seed=5, P=22, sub=0.15)
     idx = np.arange(n) % b.n_pairs
     t = lambda a: torch.from_numpy(a[idx]).to(dev)
     freq, gop, gex, ln, nm = t(b.freq), t(b.gap_open), t(b.gap_extend), t(b.len), t(b.num)
@@ -37,4 +39,4 @@ for n, mt in ((2048, 1024), (1, 1024), (1, 0), (100, 1024)):
         st = api.get_stats(0)
     import hashlib
     h = hashlib.md5(aln.cpu().numpy().tobytes() + alen.cpu().numpy().tobytes() + err.cpu().numpy().tobytes()).hexdigest()[:12]
-    print(f"{which}: pairs {n} mt_max {mt}: kernel {st.kernel_ms:.2f} ms, cells {st.band_cells:.4g}, paths {h}, {st.kernel.decode()[:60]}", flush=True)
+    print(f"{which}: P {P} pairs {n} mt_max {mt}: kernel {st.kernel_ms:.2f} ms, cells {st.band_cells:.4g}, paths {h}, {st.kernel.decode()[:60]}", flush=True)

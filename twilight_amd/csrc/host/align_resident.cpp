@@ -452,13 +452,18 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     int8_t *finalPaths = reinterpret_cast<int8_t *>(g_finalStage.get((size_t)n * pathStride));
     std::vector<int32_t> finalLen(n, 0);
     std::vector<char> deferred(n, 0);
-#pragma omp parallel for schedule(dynamic, 1)
+    std::vector<int> onHost;                 // pairs whose final path the host still has to make (none in the in-place mode: their paths are in HBM)
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
         deferred[i] = ((s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144
         if (deferred[i]) { paths[i].clear(); fromDp[i] = 0; }
         if (fromDp[i]) { finalLen[i] = dpLen[i]; continue; }      // no column was removed: the DP path is the final path, and it is in HBM
-        if (paths[i].empty()) continue;
+        if (!paths[i].empty()) onHost.push_back(i);
+    }
+#pragma omp parallel for schedule(dynamic, 1) if (onHost.size() > 1)
+    for (int t = 0; t < (int)onHost.size(); ++t) {
+        const int i = onHost[t];
+        PairState &s = ps[i];
         if (s.gappy.first.empty() && s.gappy.second.empty()) {      // nothing was removed: the DP path is the final path (addGappyColumnsBack would copy it)
             if ((int)paths[i].size() > pathStride) { std::cerr << "ERROR: path longer than both profiles together.\n"; exit(1); }
             std::copy(paths[i].begin(), paths[i].end(), &finalPaths[(size_t)i * pathStride]);

@@ -54,7 +54,8 @@ struct RestoreArgs {
 // The three scan kernels below run one workgroup of kRsThreads threads per pair (or side), kRsItems consecutive items per thread and
 // one workgroup scan per kRsThreads * kRsItems items: at the top of a tree a level is ONE pair with a path of 10^5 elements, and the
 // time of these kernels is the number of scan rounds.
-constexpr int kRsThreads = 1024, kRsItems = 8, kRsWaves = kRsThreads / 64;
+constexpr int kRsThreads = 1024, kRsItems = 16, kRsWaves = kRsThreads / 64;
+constexpr int kRsItemsRuns = 8;     // restore_runs_kernel keeps four values per item: 16 items would not fit the 128 registers of a 1024-thread workgroup
 
 // grid: 2 * n_sel workgroups: original index of every kept column of one side (+ the side's original length as a sentinel)
 __global__ void __launch_bounds__(kRsThreads) restore_index_kernel(RestoreArgs a)
@@ -95,12 +96,12 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
     if (threadIdx.x == 0) s_big = 0;
     int baseR = 0, baseQ = 0, baseA = 0, baseB = 0;
     bool tooBig = false;
-    for (int c0 = 0; c0 <= n; c0 += kRsThreads * kRsItems) {
-        const int b0 = c0 + (int)threadIdx.x * kRsItems;       // boundary b: between elements b - 1 and b
-        bool fR[kRsItems], fQ[kRsItems];
+    for (int c0 = 0; c0 <= n; c0 += kRsThreads * kRsItemsRuns) {
+        const int b0 = c0 + (int)threadIdx.x * kRsItemsRuns;       // boundary b: between elements b - 1 and b
+        bool fR[kRsItemsRuns], fQ[kRsItemsRuns];
         int nR = 0, nQ = 0;
 #pragma unroll
-        for (int k = 0; k < kRsItems; ++k) {
+        for (int k = 0; k < kRsItemsRuns; ++k) {
             const int b = b0 + k;
             const int prev = (b >= 1 && b <= n) ? path[b - 1] : 3;
             fR[k] = (prev == 0 || prev == 2); fQ[k] = (prev == 0 || prev == 1);
@@ -109,10 +110,10 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
         int totR, totQ, totA, totB;
         int cR = baseR + block_scan_int<kRsWaves>(nR, &totR, s_wave);      // reference columns consumed before boundary b0 (element b0 - 1 not counted yet)
         int cQ = baseQ + block_scan_int<kRsWaves>(nQ, &totQ, s_wave);
-        int rR[kRsItems], rQ[kRsItems], sR[kRsItems], sQ[kRsItems];
+        int rR[kRsItemsRuns], rQ[kRsItemsRuns], sR[kRsItemsRuns], sQ[kRsItemsRuns];
         int sumA = 0, nB = 0;
 #pragma unroll
-        for (int k = 0; k < kRsItems; ++k) {
+        for (int k = 0; k < kRsItemsRuns; ++k) {
             const int b = b0 + k;
             cR += fR[k] ? 1 : 0; cQ += fQ[k] ? 1 : 0;                     // ... consumed before boundary b
             rR[k] = rQ[k] = sR[k] = sQ[k] = 0;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
         int off = baseA + block_scan_int<kRsWaves>(sumA, &totA, s_wave);
         int lst = baseB + block_scan_int<kRsWaves>(nB, &totB, s_wave);
 #pragma unroll
-        for (int k = 0; k < kRsItems; ++k) {
+        for (int k = 0; k < kRsItemsRuns; ++k) {
             const int b = b0 + k;
             if (b > n) continue;
             const bool both = rR[k] > 0 && rQ[k] > 0;
@@ -145,10 +146,49 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
     if (threadIdx.x == 0) { a.out_len[pair] = s_big ? -1 : 0; a.n_both[blockIdx.x] = baseB; }
 }
 
-// grid: (n_sel, nb) workgroups: every two-sided boundary aligned by one thread (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322);
-// the boundaries of a pair are dealt to the nb * 256 threads of its workgroups (thousands of small alignments per pair at the top of a tree)
+// One small affine Needleman-Wunsch (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322) by one thread: rolling rows of M / X / Y
+// and the traceback matrix live in the storage the accessors address (per-thread LDS for runs of up to kNwSmall columns, global scratch
+// beyond); the operations and their order are the same either way.  Writes the reversed path to dst, returns its length.
+constexpr int kNwSmall = 7;         // runs of up to this many columns on both sides: rows and traceback in LDS
+template <class Rows, class Tb>
+__device__ __forceinline__ int nw_small(const uint8_t *s1, int m, const uint8_t *s2, int nn, const float *Mx, int ms, float go, float ge, Rows R, Tb T, int8_t *dst)
+{
+    const int W = nn + 1;
+    int Mp = 0, Xp = 1, Yp = 2, Mc = 3, Xc = 4, Yc = 5;
+    R(Mp, 0) = 0.0f; R(Xp, 0) = 0.0f; R(Yp, 0) = 0.0f; T(0) = 0;
+    for (int j = 1; j <= nn; ++j) { R(Mp, j) = 0.0f; R(Yp, j) = 0.0f; R(Xp, j) = -1e9f; T(j) = 1; }
+    for (int i = 1; i <= m; ++i) {
+        const float *row = Mx + (size_t)(s1[i - 1] & 0x7f) * ms;
+        R(Mc, 0) = 0.0f; R(Xc, 0) = 0.0f; R(Yc, 0) = -1e9f; T(i * W) = 2;
+        for (int j = 1; j <= nn; ++j) {
+            const float base = row[s2[j - 1] & 0x7f];
+            const float mv = base + fmaxf(fmaxf(R(Mp, j - 1), R(Xp, j - 1)), R(Yp, j - 1));
+            const float xv = fmaxf(R(Mp, j) + go, R(Xp, j) + ge);
+            const float yv = fmaxf(R(Mc, j - 1) + go, R(Yc, j - 1) + ge);
+            const float best = fmaxf(fmaxf(mv, xv), yv);
+            R(Mc, j) = mv; R(Xc, j) = xv; R(Yc, j) = yv;
+            T(i * W + j) = (best == mv) ? 0 : ((best == yv) ? 1 : 2);
+        }
+        int t;
+        t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Yp; Yp = Yc; Yc = t;
+    }
+    int len = 0;
+    for (int i = m, j = nn; i > 0 || j > 0;) {
+        const int8_t d = T(i * W + j);
+        dst[len++] = d;
+        if (d == 0) { --i; --j; }
+        else if (d == 1) --j;
+        else --i;
+    }
+    return len;
+}
+
+// grid: (n_sel, nb) workgroups: every two-sided boundary aligned by one thread; the boundaries of a pair (restore_runs_kernel listed
+// them) are dealt to the nb * 256 threads of its workgroups (thousands of small alignments per pair at the top of a tree)
 __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
 {
+    __shared__ float s_rows[6 * (kNwSmall + 1) * 256];                      // [row][j][thread]
+    __shared__ int8_t s_tb[(kNwSmall + 1) * (kNwSmall + 1) * 256];          // [cell][thread]
     const int pair = a.sel[blockIdx.x];
     if (a.out_len[pair] < 0) return;
     const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride, *stR = runQ + a.bstride, *stQ = stR + a.bstride;
@@ -159,43 +199,22 @@ __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
     const size_t thr = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
     int8_t *tb = a.tbs + thr * kNwCells;
     float *rw = a.rows + thr * (6 * kNwRow);
-    const float go = a.gap_open, ge = a.gap_extend;
-    const int ms = a.ms;
     const int32_t *both_list = a.both_list + (size_t)blockIdx.x * a.bstride;
     const int nBoth = a.n_both[blockIdx.x];
+    const int tid = threadIdx.x;
     for (int t = blockIdx.y * 256 + threadIdx.x; t < nBoth; t += 256 * gridDim.y) {
         const int b = both_list[t];
         const int m = runR[b], nn = runQ[b];
         const uint8_t *s1 = cR + stR[b], *s2 = cQ + stQ[b];
-        const int W = nn + 1;
-        float *Mp = rw, *Xp = rw + kNwRow, *Yp = rw + 2 * kNwRow, *Mc = rw + 3 * kNwRow, *Xc = rw + 4 * kNwRow, *Yc = rw + 5 * kNwRow;
-        Mp[0] = 0.0f; Xp[0] = 0.0f; Yp[0] = 0.0f; tb[0] = 0;
-        for (int j = 1; j <= nn; ++j) { Mp[j] = 0.0f; Yp[j] = 0.0f; Xp[j] = -1e9f; tb[j] = 1; }
-        for (int i = 1; i <= m; ++i) {
-            const float *row = a.M + (size_t)(s1[i - 1] & 0x7f) * ms;
-            Mc[0] = 0.0f; Xc[0] = 0.0f; Yc[0] = -1e9f; tb[i * W] = 2;
-            for (int j = 1; j <= nn; ++j) {
-                const float base = row[s2[j - 1] & 0x7f];
-                const float mv = base + fmaxf(fmaxf(Mp[j - 1], Xp[j - 1]), Yp[j - 1]);
-                const float xv = fmaxf(Mp[j] + go, Xp[j] + ge);
-                const float yv = fmaxf(Mc[j - 1] + go, Yc[j - 1] + ge);
-                const float best = fmaxf(fmaxf(mv, xv), yv);
-                Mc[j] = mv; Xc[j] = xv; Yc[j] = yv;
-                tb[i * W + j] = (best == mv) ? 0 : ((best == yv) ? 1 : 2);
-            }
-            float *t;
-            t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Yp; Yp = Yc; Yc = t;
-        }
         int8_t *dst = arena + aoff[b];       // reversed: the write kernel turns it round
-        int len = 0;
-        for (int i = m, j = nn; i > 0 || j > 0;) {
-            const int8_t d = tb[i * W + j];
-            dst[len++] = d;
-            if (d == 0) { --i; --j; }
-            else if (d == 1) --j;
-            else --i;
-        }
-        seg[b] = len;
+        if (m <= kNwSmall && nn <= kNwSmall)
+            seg[b] = nw_small(s1, m, s2, nn, a.M, a.ms, a.gap_open, a.gap_extend,
+                              [&](int r, int j) -> float & { return s_rows[(r * (kNwSmall + 1) + j) * 256 + tid]; },
+                              [&](int c) -> int8_t & { return s_tb[c * 256 + tid]; }, dst);
+        else
+            seg[b] = nw_small(s1, m, s2, nn, a.M, a.ms, a.gap_open, a.gap_extend,
+                              [&](int r, int j) -> float & { return rw[r * kNwRow + j]; },
+                              [&](int c) -> int8_t & { return tb[c]; }, dst);
     }
 }
 
