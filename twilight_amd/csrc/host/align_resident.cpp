@@ -219,28 +219,38 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<PairState> ps(n);
     size_t nMembers = 0;
     int stride = 1;
+    // (what is read from the nodes and sequences of a pair -- cache misses, mostly -- in parallel; the running member offsets and the
+    // ids of newly cached profiles, which depend on the order of the pairs, in a serial pass behind it)
+#pragma omp parallel for schedule(static) if (n >= 512)
     for (int i = 0; i < n; ++i) {
         Node *nd[2] = {nodes[i].first, nodes[i].second};
         PairState &s = ps[i];
         s.refLen = nd[0]->getAlnLen(0); s.qryLen = nd[1]->getAlnLen(0);
         s.refNum = nd[0]->getAlnNum(0); s.qryNum = nd[1]->getAlnNum(0);
-        const bool storeFreq = (s.refNum >= alignment_helper::_CAL_PROFILE_TH || s.qryNum >= alignment_helper::_CAL_PROFILE_TH) || (nd[0]->cacheId >= 0 || nd[1]->cacheId >= 0);
         for (int sd = 0; sd < 2; ++sd) {
             twl_side &x = sides[2 * (size_t)i + sd];
             x.n_members = (int32_t)nd[sd]->seqsIncluded.size();
-            x.member_off = (int32_t)nMembers;
             x.len = sd ? s.qryLen : s.refLen;
             x.num = sd ? s.qryNum : s.refNum;
             x.weight = nd[sd]->alnWeight;
             x.cache_id = nd[sd]->cacheId;
             x.store_id = -1;
             x.reserved = 0;
-            if (storeFreq && nd[sd]->cacheId < 0) x.store_id = nd[sd]->cacheId = g_nextCacheId++;
-            nMembers += (size_t)x.n_members;
-            stride = std::max(stride, x.len);
         }
         s.lowQ_r = (option->alnMode == MERGE_MSA) ? false : ((s.refNum > 1) ? false : database->sequences[nd[0]->seqsIncluded[0]]->lowQuality);
         s.lowQ_q = (option->alnMode == MERGE_MSA) ? false : ((s.qryNum > 1) ? false : database->sequences[nd[1]->seqsIncluded[0]]->lowQuality);
+    }
+    for (int i = 0; i < n; ++i) {
+        PairState &s = ps[i];
+        Node *nd[2] = {nodes[i].first, nodes[i].second};
+        const bool storeFreq = (s.refNum >= alignment_helper::_CAL_PROFILE_TH || s.qryNum >= alignment_helper::_CAL_PROFILE_TH) || (sides[2 * (size_t)i].cache_id >= 0 || sides[2 * (size_t)i + 1].cache_id >= 0);
+        for (int sd = 0; sd < 2; ++sd) {
+            twl_side &x = sides[2 * (size_t)i + sd];
+            x.member_off = (int32_t)nMembers;
+            if (storeFreq && x.cache_id < 0) x.store_id = nd[sd]->cacheId = g_nextCacheId++;
+            nMembers += (size_t)x.n_members;
+            stride = std::max(stride, x.len);
+        }
     }
     std::vector<int32_t> members(nMembers);
     std::vector<float> weights(nMembers);
