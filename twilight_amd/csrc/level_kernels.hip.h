@@ -353,12 +353,12 @@ __global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
     if (c >= n) return;
     // the kept columns of this thread are cnt CONSECUTIVE bytes of the old row, from src: one or two aligned 32-bit loads per member
     // (the second only when the bytes straddle a word: it then lies inside the row), spread over the word that is stored;
-    // four members per round so that their loads are in flight together
+    // eight members per round so that their loads are in flight together
     const SideDesc sd = a.sides[side];
     const int sh = (src & 3) * 8;
     const bool two = (src & 3) + cnt > 4;
     const size_t lo = (size_t)(src & ~3);
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int mEnd = w[1] + w[2];
     for (int m = w[1]; m < mEnd; m += U) {
         uint32_t v0[U], v1[U];

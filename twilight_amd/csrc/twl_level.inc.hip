@@ -840,7 +840,7 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if ((rc = grow_rows(s, maxPath))) return rc;
     const int32_t nChunks = (maxPath + 255) / 256;
 
-    constexpr int MG = 16;                      // members per workgroup of the row rewrite
+    constexpr int MG = 64;                      // members per workgroup of the row rewrite (its scan of the path chunk is shared by them)
     std::vector<int32_t> &work = s->h_work, &merge = s->h_merge;
     std::vector<float> &mergew = s->h_mergew;
     std::vector<float *> &tab = s->h_tab;
