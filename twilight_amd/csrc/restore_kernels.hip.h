@@ -39,6 +39,8 @@ struct RestoreArgs {
     int32_t *aoff;            // [n_sel][bstride] arena offset of a two-sided boundary
     int32_t *both_list;       // [n_sel][bstride] the two-sided boundaries of a pair, ascending
     int32_t *n_both;          // [n_sel] how many
+    int32_t *wtot;            // [n_sel][n_wchunks] bytes of the final path per chunk of boundaries (restore_count_kernel -> restore_write_kernel)
+    int32_t n_wchunks;
     int8_t *arena;            // [n_sel][out_stride] the aligned two-sided segments, reversed
     int32_t bstride;
     int8_t *out;              // [n_pairs][out_stride] final paths
@@ -149,25 +151,29 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
 // One small affine Needleman-Wunsch (pairwiseGlobal, helpers.cpp / alignment-helper.cpp:243-322) by one thread: rolling rows of M / X / Y
 // and the traceback matrix live in the storage the accessors address (per-thread LDS for runs of up to kNwSmall columns, global scratch
 // beyond); the operations and their order are the same either way.  Writes the reversed path to dst, returns its length.
-constexpr int kNwSmall = 7;         // runs of up to this many columns on both sides: rows and traceback in LDS
-template <class Rows, class Tb>
-__device__ __forceinline__ int nw_small(const uint8_t *s1, int m, const uint8_t *s2, int nn, const float *Mx, int ms, float go, float ge, Rows R, Tb T, int8_t *dst)
+constexpr int kNwSmall = 31;        // runs of up to this many columns on both sides: rows and traceback in LDS (one wave per workgroup)
+template <class L1, class L2, class Rows, class Tb>
+__device__ __forceinline__ int nw_small(L1 s1, int m, L2 s2, int nn, const float *Mx, int ms, float go, float ge, Rows R, Tb T, int8_t *dst)
 {
     const int W = nn + 1;
     int Mp = 0, Xp = 1, Yp = 2, Mc = 3, Xc = 4, Yc = 5;
     R(Mp, 0) = 0.0f; R(Xp, 0) = 0.0f; R(Yp, 0) = 0.0f; T(0) = 0;
     for (int j = 1; j <= nn; ++j) { R(Mp, j) = 0.0f; R(Yp, j) = 0.0f; R(Xp, j) = -1e9f; T(j) = 1; }
     for (int i = 1; i <= m; ++i) {
-        const float *row = Mx + (size_t)(s1[i - 1] & 0x7f) * ms;
+        const float *row = Mx + (size_t)(s1(i - 1) & 0x7f) * ms;
         R(Mc, 0) = 0.0f; R(Xc, 0) = 0.0f; R(Yc, 0) = -1e9f; T(i * W) = 2;
+        // (the cell's left and upper-left neighbours travel in registers: three reads of the row above per cell)
+        float dM = R(Mp, 0), dX = R(Xp, 0), dY = R(Yp, 0), lM = 0.0f, lY = -1e9f;
         for (int j = 1; j <= nn; ++j) {
-            const float base = row[s2[j - 1] & 0x7f];
-            const float mv = base + fmaxf(fmaxf(R(Mp, j - 1), R(Xp, j - 1)), R(Yp, j - 1));
-            const float xv = fmaxf(R(Mp, j) + go, R(Xp, j) + ge);
-            const float yv = fmaxf(R(Mc, j - 1) + go, R(Yc, j - 1) + ge);
+            const float base = row[s2(j - 1) & 0x7f];
+            const float uM = R(Mp, j), uX = R(Xp, j), uY = R(Yp, j);
+            const float mv = base + fmaxf(fmaxf(dM, dX), dY);
+            const float xv = fmaxf(uM + go, uX + ge);
+            const float yv = fmaxf(lM + go, lY + ge);
             const float best = fmaxf(fmaxf(mv, xv), yv);
             R(Mc, j) = mv; R(Xc, j) = xv; R(Yc, j) = yv;
             T(i * W + j) = (best == mv) ? 0 : ((best == yv) ? 1 : 2);
+            dM = uM; dX = uX; dY = uY; lM = mv; lY = yv;
         }
         int t;
         t = Mp; Mp = Mc; Mc = t; t = Xp; Xp = Xc; Xc = t; t = Yp; Yp = Yc; Yc = t;
@@ -183,12 +189,19 @@ __device__ __forceinline__ int nw_small(const uint8_t *s1, int m, const uint8_t 
     return len;
 }
 
-// grid: (n_sel, nb) workgroups: every two-sided boundary aligned by one thread; the boundaries of a pair (restore_runs_kernel listed
-// them) are dealt to the nb * 256 threads of its workgroups (thousands of small alignments per pair at the top of a tree)
-__global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
+// grid: (n_sel, nb) workgroups of ONE wave: every two-sided boundary aligned by one thread; the boundaries of a pair (restore_runs_kernel
+// listed them) are dealt to the nb * 64 threads of its workgroups (thousands of small alignments per pair at the top of a tree, the largest
+// of them a few hundred cells: what the launch takes is its longest alignment, so the rows and the traceback of all but the rare large
+// ones live in LDS, 1.8 KB per thread)
+constexpr int kNwThreads = 64;
+__global__ void __launch_bounds__(kNwThreads) restore_align_kernel(RestoreArgs a)
 {
-    __shared__ float s_rows[6 * (kNwSmall + 1) * 256];                      // [row][j][thread]
-    __shared__ int8_t s_tb[(kNwSmall + 1) * (kNwSmall + 1) * 256];          // [cell][thread]
+    __shared__ float s_rows[6 * (kNwSmall + 1) * kNwThreads];                      // [row][j][thread]
+    __shared__ int8_t s_tb[(kNwSmall + 1) * (kNwSmall + 1) * kNwThreads];          // [cell][thread]
+    __shared__ uint8_t s_l1[kNwSmall * kNwThreads], s_l2[kNwSmall * kNwThreads];   // the two runs' consensus letters
+    __shared__ float s_M[441];
+    for (int t = threadIdx.x; t < a.ms * a.ms; t += kNwThreads) s_M[t] = a.M[t];
+    __syncthreads();
     const int pair = a.sel[blockIdx.x];
     if (a.out_len[pair] < 0) return;
     const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride, *stR = runQ + a.bstride, *stQ = stR + a.bstride;
@@ -196,70 +209,120 @@ __global__ void __launch_bounds__(256) restore_align_kernel(RestoreArgs a)
     const int32_t *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
     const uint8_t *cR = a.colinfo + (size_t)(2 * pair) * a.stride, *cQ = cR + a.stride;
     int8_t *arena = a.arena + (size_t)blockIdx.x * a.out_stride;
-    const size_t thr = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 256 + threadIdx.x;
+    const size_t thr = ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kNwThreads + threadIdx.x;
     int8_t *tb = a.tbs + thr * kNwCells;
     float *rw = a.rows + thr * (6 * kNwRow);
     const int32_t *both_list = a.both_list + (size_t)blockIdx.x * a.bstride;
     const int nBoth = a.n_both[blockIdx.x];
     const int tid = threadIdx.x;
-    for (int t = blockIdx.y * 256 + threadIdx.x; t < nBoth; t += 256 * gridDim.y) {
+    for (int t = blockIdx.y * kNwThreads + threadIdx.x; t < nBoth; t += kNwThreads * gridDim.y) {
         const int b = both_list[t];
         const int m = runR[b], nn = runQ[b];
         const uint8_t *s1 = cR + stR[b], *s2 = cQ + stQ[b];
         int8_t *dst = arena + aoff[b];       // reversed: the write kernel turns it round
-        if (m <= kNwSmall && nn <= kNwSmall)
-            seg[b] = nw_small(s1, m, s2, nn, a.M, a.ms, a.gap_open, a.gap_extend,
-                              [&](int r, int j) -> float & { return s_rows[(r * (kNwSmall + 1) + j) * 256 + tid]; },
-                              [&](int c) -> int8_t & { return s_tb[c * 256 + tid]; }, dst);
-        else
-            seg[b] = nw_small(s1, m, s2, nn, a.M, a.ms, a.gap_open, a.gap_extend,
+        if (m <= kNwSmall && nn <= kNwSmall) {      // letters, scores, rows and traceback in LDS: no global load inside the cell loop
+            for (int i = 0; i < m; ++i) s_l1[i * kNwThreads + tid] = s1[i];
+            for (int j = 0; j < nn; ++j) s_l2[j * kNwThreads + tid] = s2[j];
+            seg[b] = nw_small([&](int i) -> uint8_t { return s_l1[i * kNwThreads + tid]; }, m, [&](int j) -> uint8_t { return s_l2[j * kNwThreads + tid]; }, nn,
+                              s_M, a.ms, a.gap_open, a.gap_extend,
+                              [&](int r, int j) -> float & { return s_rows[(r * (kNwSmall + 1) + j) * kNwThreads + tid]; },
+                              [&](int c) -> int8_t & { return s_tb[c * kNwThreads + tid]; }, dst);
+        } else
+            seg[b] = nw_small([&](int i) -> uint8_t { return s1[i]; }, m, [&](int j) -> uint8_t { return s2[j]; }, nn, a.M, a.ms, a.gap_open, a.gap_extend,
                               [&](int r, int j) -> float & { return rw[r * kNwRow + j]; },
                               [&](int c) -> int8_t & { return tb[c]; }, dst);
     }
 }
 
-// grid: n_sel workgroups: the final path = for every boundary its segment, then the path element behind it
+// grid: (n_sel, n_wchunks) workgroups: bytes of the final path that the boundaries of one chunk (kRsThreads * kRsItems of them) produce
+__global__ void __launch_bounds__(kRsThreads) restore_count_kernel(RestoreArgs a)
+{
+    __shared__ int s_wave[kRsWaves];
+    const int pair = a.sel[blockIdx.x];
+    if (a.out_len[pair] < 0) return;
+    const int n = a.aln_len[pair];
+    const int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride;
+    const int b0 = ((int)blockIdx.y * kRsThreads + (int)threadIdx.x) * kRsItems;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kRsItems; ++k) {
+        const int b = b0 + k;
+        sum += (b <= n) ? seg[b] + (b < n ? 1 : 0) : 0;
+    }
+    int total;
+    (void)block_scan_int<kRsWaves>(sum, &total, s_wave);
+    if (threadIdx.x == 0) a.wtot[(size_t)blockIdx.x * a.n_wchunks + blockIdx.y] = total;
+}
+
+// grid: (n_sel, n_wchunks) workgroups: the final path = for every boundary its segment, then the path element behind it; a chunk's first
+// output position is the sum of the chunks before it (restore_count_kernel)
 __global__ void __launch_bounds__(kRsThreads) restore_write_kernel(RestoreArgs a)
 {
     __shared__ int s_wave[kRsWaves];
     const int pair = a.sel[blockIdx.x];
     if (a.out_len[pair] < 0) return;
     const int n = a.aln_len[pair];
+    const int c0 = (int)blockIdx.y * kRsThreads * kRsItems;
+    if (c0 > n) return;
     const int8_t *path = a.aln + (size_t)pair * a.aln_stride;
     const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride;
     const int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride, *aoff = a.aoff + (size_t)blockIdx.x * a.bstride;
     const int8_t *arena = a.arena + (size_t)blockIdx.x * a.out_stride;
     int8_t *out = a.out + (size_t)pair * a.out_stride;
     int base = 0;
-    for (int c0 = 0; c0 <= n; c0 += kRsThreads * kRsItems) {
-        const int b0 = c0 + (int)threadIdx.x * kRsItems;
-        int sl[kRsItems];
-        int sum = 0;
+    for (int c = 0; c < (int)blockIdx.y; ++c) base += a.wtot[(size_t)blockIdx.x * a.n_wchunks + c];
+    const int b0 = c0 + (int)threadIdx.x * kRsItems;
+    int sl[kRsItems];
+    // everything the store loop needs is read first: a load behind a store waits for that store to complete (one counter orders them),
+    // which made the sixteen boundaries of a thread cost sixteen round trips
+    int8_t pe[kRsItems];           // the path element behind the boundary
+    int src[kRsItems];             // >= 0: arena offset of a two-sided segment (reversed copy); -1 / -2: a run of code 1 / 2
+    int sum = 0;
 #pragma unroll
-        for (int k = 0; k < kRsItems; ++k) {
-            const int b = b0 + k;
-            sl[k] = (b <= n) ? seg[b] : 0;
-            sum += (b <= n) ? sl[k] + (b < n ? 1 : 0) : 0;
-        }
-        int total;
-        int pos = base + block_scan_int<kRsWaves>(sum, &total, s_wave);
-#pragma unroll
-        for (int k = 0; k < kRsItems; ++k) {
-            const int b = b0 + k;
-            if (b > n) continue;
-            const int w = sl[k] + (b < n ? 1 : 0);
-            if (pos + w <= a.out_stride) {
-                if (sl[k] > 0) {
-                    if (runR[b] > 0 && runQ[b] > 0) { const int8_t *src = arena + aoff[b]; for (int t = 0; t < sl[k]; ++t) out[pos + t] = src[sl[k] - 1 - t]; }
-                    else { const int8_t code = runR[b] > 0 ? 2 : 1; for (int t = 0; t < sl[k]; ++t) out[pos + t] = code; }
-                }
-                if (b < n) out[pos + sl[k]] = path[b];
-            }
-            pos += w;
-        }
-        base += total;
+    for (int k = 0; k < kRsItems; ++k) {
+        const int b = b0 + k;
+        sl[k] = (b <= n) ? seg[b] : 0;
+        pe[k] = (b < n) ? path[b] : (int8_t)0;
+        const int rr = (b <= n) ? runR[b] : 0, rq = (b <= n) ? runQ[b] : 0, ao = (b <= n) ? aoff[b] : 0;
+        src[k] = (rr > 0 && rq > 0) ? ao : (rr > 0 ? -2 : -1);
+        sum += (b <= n) ? sl[k] + (b < n ? 1 : 0) : 0;
     }
-    if (threadIdx.x == 0) a.out_len[pair] = (base <= a.out_stride) ? base : -1;
+    int total;
+    int pos = base + block_scan_int<kRsWaves>(sum, &total, s_wave);
+    // Segments of up to kSegDirect bytes are written by the boundary's own thread; a removed run can be thousands of columns long (one
+    // thread would write it byte by byte while the launch waits): those are queued and filled by the whole workgroup.
+    constexpr int kSegDirect = 32, kQueue = 2048;
+    __shared__ int q_n, q_pos[kQueue], q_len[kQueue], q_src[kQueue];       // q_src >= 0: arena offset (reversed copy); -1 / -2: fill with code 1 / 2
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kRsItems; ++k) {
+        const int b = b0 + k;
+        if (b > n) continue;
+        const int w = sl[k] + (b < n ? 1 : 0);
+        if (pos + w <= a.out_stride) {
+            if (sl[k] > 0) {
+                const bool both = src[k] >= 0;
+                int slot = -1;
+                if (sl[k] > kSegDirect) { slot = atomicAdd(&q_n, 1); if (slot >= kQueue) slot = -1; }
+                if (slot >= 0) { q_pos[slot] = pos; q_len[slot] = sl[k]; q_src[slot] = src[k]; }
+                else if (both) { const int8_t *from = arena + src[k]; for (int t = 0; t < sl[k]; ++t) out[pos + t] = from[sl[k] - 1 - t]; }
+                else { const int8_t code = (src[k] == -2) ? 2 : 1; for (int t = 0; t < sl[k]; ++t) out[pos + t] = code; }
+            }
+            if (b < n) out[pos + sl[k]] = pe[k];
+        }
+        pos += w;
+    }
+    __syncthreads();
+    const int nq = min(q_n, kQueue);
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x >> 6; e < nq; e += kRsWaves) {      // a wave per queued segment
+        const int p0 = q_pos[e], len = q_len[e], from = q_src[e];
+        if (from >= 0) for (int t = lane; t < len; t += 64) out[p0 + t] = arena[from + len - 1 - t];
+        else { const int8_t code = (from == -2) ? 2 : 1; for (int t = lane; t < len; t += 64) out[p0 + t] = code; }
+    }
+    // (the chunk that holds the last boundary knows the length of the whole path)
+    if (threadIdx.x == 0 && n < c0 + kRsThreads * kRsItems) a.out_len[pair] = (base + total <= a.out_stride) ? base + total : -1;
 }
 
 // ---- paths between the level's buffers and one contiguous device block (the exchange between processes) ----

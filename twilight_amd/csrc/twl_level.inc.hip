@@ -83,13 +83,13 @@ struct LevelBufs {
     Ref d_pathlen, d_work, d_merge, d_mergew;                // up_commit
     Buf d_raw, d_colinfo, d_cols, d_len, d_aln, d_alnlen, d_err;
     Buf d_paths, d_chunk, d_ccnt;
-    Buf r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
+    Buf r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_wtot, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
     Buf x_send, x_recv, x_rowoff, x_blkoff, x_len;                                  // exchange of final paths between processes (device blocks)
     bool busy = false;
     void release_all()
     {
         for (Buf *b : {&d_raw, &d_colinfo, &d_cols, &d_len, &d_aln, &d_alnlen, &d_err,
-                       &d_paths, &d_chunk, &d_ccnt, &r_oidx, &r_run, &r_seg, &r_aoff, &r_blist, &r_nboth, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
+                       &d_paths, &d_chunk, &d_ccnt, &r_oidx, &r_run, &r_seg, &r_aoff, &r_blist, &r_nboth, &r_wtot, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
             b->release();
         for (Arena *a : {&up_prepare, &up_align, &up_restore, &up_commit}) a->release();
         back.release();
@@ -693,11 +693,13 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_blist.ensure(ns * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_nboth.ensure(ns * sizeof(int32_t)))) return rc;
+    const unsigned nWch = (unsigned)((bstride + (size_t)twl::kRsThreads * twl::kRsItems - 1) / ((size_t)twl::kRsThreads * twl::kRsItems));      // chunks of boundaries of the longest possible path
+    if ((rc = lv->r_wtot.ensure(ns * nWch * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return rc;
     if ((rc = lv->r_outlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
-    const unsigned nb = (unsigned)std::max(1, std::min(32, 1024 / n_sel));      // workgroups per pair of the small alignments (<= ~1.8 GB of scratch)
-    if ((rc = lv->r_tb.ensure(ns * nb * 256 * (size_t)twl::kNwCells))) return rc;
-    if ((rc = lv->r_rows.ensure(ns * nb * 256 * 6 * (size_t)twl::kNwRow * sizeof(float)))) return rc;
+    const unsigned nb = (unsigned)std::max(1, std::min(128, 4096 / n_sel));     // one-wave workgroups per pair of the small alignments (<= ~1.8 GB of scratch for the rare large ones)
+    if ((rc = lv->r_tb.ensure(ns * nb * twl::kNwThreads * (size_t)twl::kNwCells))) return rc;
+    if ((rc = lv->r_rows.ensure(ns * nb * twl::kNwThreads * 6 * (size_t)twl::kNwRow * sizeof(float)))) return rc;
     twl::RestoreArgs a{};
     a.aln = (const int8_t *)lv->d_aln.p; a.aln_len = (const int32_t *)lv->d_alnlen.p; a.aln_stride = (int32_t)(2 * sl);
     a.colinfo = (const uint8_t *)lv->d_colinfo.p; a.stride = s->seq_len;
@@ -705,6 +707,7 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     a.sel = (const int32_t *)lv->r_sel.p; a.n_sel = n_sel;
     a.orig_idx = (int32_t *)lv->r_oidx.p; a.run = (int32_t *)lv->r_run.p; a.seg = (int32_t *)lv->r_seg.p; a.aoff = (int32_t *)lv->r_aoff.p;
     a.both_list = (int32_t *)lv->r_blist.p; a.n_both = (int32_t *)lv->r_nboth.p;
+    a.wtot = (int32_t *)lv->r_wtot.p; a.n_wchunks = (int32_t)nWch;
     a.arena = (int8_t *)lv->r_arena.p; a.bstride = (int32_t)bstride;
     a.out = (int8_t *)lv->d_paths.p; a.out_stride = out_stride; a.out_len = (int32_t *)lv->r_outlen.p;
     a.tbs = (int8_t *)lv->r_tb.p; a.rows = (float *)lv->r_rows.p;
@@ -713,8 +716,9 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     a.gap_open = p->gap_open; a.gap_extend = p->gap_extend;
     hipLaunchKernelGGL(twl::restore_index_kernel, dim3(2 * (unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
     hipLaunchKernelGGL(twl::restore_runs_kernel, dim3((unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
-    hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel, nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel), dim3(twl::kRsThreads), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_align_kernel, dim3((unsigned)n_sel, nb), dim3(twl::kNwThreads), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_count_kernel, dim3((unsigned)n_sel, nWch), dim3(twl::kRsThreads), 0, st, a);
+    hipLaunchKernelGGL(twl::restore_write_kernel, dim3((unsigned)n_sel, nWch), dim3(twl::kRsThreads), 0, st, a);
     HIP_TRY(hipGetLastError());
     if ((rc = lv->back.ensure((size_t)n * sizeof(int32_t)))) return rc;
     HIP_TRY(hipMemcpyAsync(lv->back.p, lv->r_outlen.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
