@@ -344,8 +344,9 @@ __global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int code = (c + k < n) ? path[c + k] : 3;
-        keep[k] = (code == 0) || (code == own);
+        const int pc = path[min(c + k, n - 1)];          // (unconditional: a load under a lane condition is a branch with its own wait)
+        const int code = (c + k < n) ? pc : 3;
+        keep[k] = (code == 0) | (code == own);
         cnt += keep[k] ? 1 : 0;
     }
     int tot;

@@ -57,6 +57,8 @@ struct RestoreArgs {
 // one workgroup scan per kRsThreads * kRsItems items: at the top of a tree a level is ONE pair with a path of 10^5 elements, and the
 // time of these kernels is the number of scan rounds.
 constexpr int kRsThreads = 1024, kRsItems = 16, kRsWaves = kRsThreads / 64;
+// Item loads are UNCONDITIONAL with clamped indices and the values are masked afterwards: a load under a lane condition compiles to a
+// branch with its own wait, and the sixteen items of a thread then cost sixteen memory round trips instead of one.
 constexpr int kRsItemsRuns = 8;     // restore_runs_kernel keeps four values per item: 16 items would not fit the 128 registers of a 1024-thread workgroup
 
 // grid: 2 * n_sel workgroups: original index of every kept column of one side (+ the side's original length as a sentinel)
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(kRsThreads) restore_index_kernel(RestoreArgs a
         bool keep[kRsItems];
         int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < kRsItems; ++k) { keep[k] = t0 + k < len && !(ci[t0 + k] & 0x80); cnt += keep[k] ? 1 : 0; }
+        for (int k = 0; k < kRsItems; ++k) { const uint8_t f = ci[min(t0 + k, len - 1)]; keep[k] = (t0 + k < len) & !(f & 0x80); cnt += keep[k] ? 1 : 0; }
         int total;
         int dst = base + block_scan_int<kRsWaves>(cnt, &total, s_wave);
 #pragma unroll
@@ -105,8 +107,9 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
 #pragma unroll
         for (int k = 0; k < kRsItemsRuns; ++k) {
             const int b = b0 + k;
-            const int prev = (b >= 1 && b <= n) ? path[b - 1] : 3;
-            fR[k] = (prev == 0 || prev == 2); fQ[k] = (prev == 0 || prev == 1);
+            const int pv = path[max(min(b, n) - 1, 0)];
+            const int prev = (b >= 1 && b <= n) ? pv : 3;
+            fR[k] = (prev == 0) | (prev == 2); fQ[k] = (prev == 0) | (prev == 1);
             nR += fR[k] ? 1 : 0; nQ += fQ[k] ? 1 : 0;
         }
         int totR, totQ, totA, totB;
@@ -118,11 +121,12 @@ __global__ void __launch_bounds__(kRsThreads) restore_runs_kernel(RestoreArgs a)
         for (int k = 0; k < kRsItemsRuns; ++k) {
             const int b = b0 + k;
             cR += fR[k] ? 1 : 0; cQ += fQ[k] ? 1 : 0;                     // ... consumed before boundary b
-            rR[k] = rQ[k] = sR[k] = sQ[k] = 0;
-            if (b <= n) {
-                if (b == 0 || fR[k]) { sR[k] = cR ? oiR[cR - 1] + 1 : 0; rR[k] = oiR[cR] - sR[k]; }
-                if (b == 0 || fQ[k]) { sQ[k] = cQ ? oiQ[cQ - 1] + 1 : 0; rQ[k] = oiQ[cQ] - sQ[k]; }
-            }
+            // (cR <= the side's kept columns, whose sentinel entry orig_idx[kept] exists: the loads are in range for every lane)
+            const int iR = min(cR, a.stride), iQ = min(cQ, a.stride);
+            const int pR = oiR[max(iR - 1, 0)], qR = oiR[iR], pQ = oiQ[max(iQ - 1, 0)], qQ = oiQ[iQ];
+            const bool useR = (b <= n) & ((b == 0) | fR[k]), useQ = (b <= n) & ((b == 0) | fQ[k]);
+            sR[k] = useR ? (cR ? pR + 1 : 0) : 0; rR[k] = useR ? qR - sR[k] : 0;
+            sQ[k] = useQ ? (cQ ? pQ + 1 : 0) : 0; rQ[k] = useQ ? qQ - sQ[k] : 0;
             const bool both = rR[k] > 0 && rQ[k] > 0;
             if (both && ((long long)(rR[k] + 1) * (rQ[k] + 1) > kNwCells || rQ[k] + 1 > kNwRow)) tooBig = true;
             sumA += both ? rR[k] + rQ[k] : 0;
@@ -234,7 +238,11 @@ __global__ void __launch_bounds__(kNwThreads) restore_align_kernel(RestoreArgs a
     }
 }
 
-// grid: (n_sel, n_wchunks) workgroups: bytes of the final path that the boundaries of one chunk (kRsThreads * kRsItems of them) produce
+// The write pass gives every boundary its own thread (kWrItems = 1): consecutive lanes then touch consecutive words of the per-boundary
+// tables (a thread that owns sixteen consecutive boundaries makes every wave-level load touch 64 cache lines), and a path of 10^4
+// boundaries spreads over a dozen CUs instead of one.
+constexpr int kWrItems = 1;
+// grid: (n_sel, n_wchunks) workgroups: bytes of the final path that the boundaries of one chunk (kRsThreads * kWrItems of them) produce
 __global__ void __launch_bounds__(kRsThreads) restore_count_kernel(RestoreArgs a)
 {
     __shared__ int s_wave[kRsWaves];
@@ -242,12 +250,13 @@ __global__ void __launch_bounds__(kRsThreads) restore_count_kernel(RestoreArgs a
     if (a.out_len[pair] < 0) return;
     const int n = a.aln_len[pair];
     const int32_t *seg = a.seg + (size_t)blockIdx.x * a.bstride;
-    const int b0 = ((int)blockIdx.y * kRsThreads + (int)threadIdx.x) * kRsItems;
+    const int b0 = ((int)blockIdx.y * kRsThreads + (int)threadIdx.x) * kWrItems;
     int sum = 0;
 #pragma unroll
-    for (int k = 0; k < kRsItems; ++k) {
+    for (int k = 0; k < kWrItems; ++k) {
         const int b = b0 + k;
-        sum += (b <= n) ? seg[b] + (b < n ? 1 : 0) : 0;
+        const int sg = seg[min(b, n)];
+        sum += (b <= n) ? sg + (b < n ? 1 : 0) : 0;
     }
     int total;
     (void)block_scan_int<kRsWaves>(sum, &total, s_wave);
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(kRsThreads) restore_write_kernel(RestoreArgs a
     const int pair = a.sel[blockIdx.x];
     if (a.out_len[pair] < 0) return;
     const int n = a.aln_len[pair];
-    const int c0 = (int)blockIdx.y * kRsThreads * kRsItems;
+    const int c0 = (int)blockIdx.y * kRsThreads * kWrItems;
     if (c0 > n) return;
     const int8_t *path = a.aln + (size_t)pair * a.aln_stride;
     const int32_t *runR = a.run + (size_t)blockIdx.x * 4 * a.bstride, *runQ = runR + a.bstride;
@@ -271,20 +280,21 @@ __global__ void __launch_bounds__(kRsThreads) restore_write_kernel(RestoreArgs a
     int8_t *out = a.out + (size_t)pair * a.out_stride;
     int base = 0;
     for (int c = 0; c < (int)blockIdx.y; ++c) base += a.wtot[(size_t)blockIdx.x * a.n_wchunks + c];
-    const int b0 = c0 + (int)threadIdx.x * kRsItems;
-    int sl[kRsItems];
+    const int b0 = c0 + (int)threadIdx.x * kWrItems;
+    int sl[kWrItems];
     // everything the store loop needs is read first: a load behind a store waits for that store to complete (one counter orders them),
     // which made the sixteen boundaries of a thread cost sixteen round trips
-    int8_t pe[kRsItems];           // the path element behind the boundary
-    int src[kRsItems];             // >= 0: arena offset of a two-sided segment (reversed copy); -1 / -2: a run of code 1 / 2
+    int8_t pe[kWrItems];           // the path element behind the boundary
+    int src[kWrItems];             // >= 0: arena offset of a two-sided segment (reversed copy); -1 / -2: a run of code 1 / 2
     int sum = 0;
 #pragma unroll
-    for (int k = 0; k < kRsItems; ++k) {
+    for (int k = 0; k < kWrItems; ++k) {
         const int b = b0 + k;
-        sl[k] = (b <= n) ? seg[b] : 0;
-        pe[k] = (b < n) ? path[b] : (int8_t)0;
-        const int rr = (b <= n) ? runR[b] : 0, rq = (b <= n) ? runQ[b] : 0, ao = (b <= n) ? aoff[b] : 0;
-        src[k] = (rr > 0 && rq > 0) ? ao : (rr > 0 ? -2 : -1);
+        const int bb = min(b, n);
+        const int sg = seg[bb], rr = runR[bb], rq = runQ[bb], ao = aoff[bb];
+        pe[k] = path[min(b, max(n - 1, 0))];
+        sl[k] = (b <= n) ? sg : 0;
+        src[k] = ((rr > 0) & (rq > 0)) ? ao : (rr > 0 ? -2 : -1);
         sum += (b <= n) ? sl[k] + (b < n ? 1 : 0) : 0;
     }
     int total;
@@ -296,7 +306,7 @@ __global__ void __launch_bounds__(kRsThreads) restore_write_kernel(RestoreArgs a
     if (threadIdx.x == 0) q_n = 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kRsItems; ++k) {
+    for (int k = 0; k < kWrItems; ++k) {
         const int b = b0 + k;
         if (b > n) continue;
         const int w = sl[k] + (b < n ? 1 : 0);
@@ -322,7 +332,7 @@ __global__ void __launch_bounds__(kRsThreads) restore_write_kernel(RestoreArgs a
         else { const int8_t code = (from == -2) ? 2 : 1; for (int t = lane; t < len; t += 64) out[p0 + t] = code; }
     }
     // (the chunk that holds the last boundary knows the length of the whole path)
-    if (threadIdx.x == 0 && n < c0 + kRsThreads * kRsItems) a.out_len[pair] = (base + total <= a.out_stride) ? base + total : -1;
+    if (threadIdx.x == 0 && n < c0 + kRsThreads * kWrItems) a.out_len[pair] = (base + total <= a.out_stride) ? base + total : -1;
 }
 
 // ---- paths between the level's buffers and one contiguous device block (the exchange between processes) ----

@@ -693,7 +693,7 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_blist.ensure(ns * bstride * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_nboth.ensure(ns * sizeof(int32_t)))) return rc;
-    const unsigned nWch = (unsigned)((bstride + (size_t)twl::kRsThreads * twl::kRsItems - 1) / ((size_t)twl::kRsThreads * twl::kRsItems));      // chunks of boundaries of the longest possible path
+    const unsigned nWch = (unsigned)((bstride + (size_t)twl::kRsThreads * twl::kWrItems - 1) / ((size_t)twl::kRsThreads * twl::kWrItems));      // chunks of boundaries of the longest possible path
     if ((rc = lv->r_wtot.ensure(ns * nWch * sizeof(int32_t)))) return rc;
     if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return rc;
     if ((rc = lv->r_outlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
