@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
             }
     } else {                                                             // :23-34  member by member
         // U members per round: their row words are requested together (independent loads in flight), then added in member order
-        constexpr int U = (P == 6) ? 4 : 2;
+        constexpr int U = (P == 6) ? 16 : 2;      // (a side of 900 rows is 900 dependent round trips otherwise: the adds stay in member order, only the loads overlap)
         auto add = [&](uint32_t four, float w) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -127,6 +127,25 @@ __global__ void __launch_bounds__(256) profile_kernel(LevelArgs a)
         if (k >= nc) continue;
 #pragma unroll
         for (int v = 0; v < P; ++v) dst[k * P + v] = acc[k][v];
+        {   // the packed DP column at its UNCOMPACTED position: where no column of the side is removed before it (every side of the wide
+            // levels at the bottom of a tree) that is where it belongs, and compact_kernel has nothing to move (same arithmetic as there)
+            constexpr int CW = P + 2;
+            float pc[CW];
+#pragma unroll
+            for (int v = 0; v < P; ++v) pc[v] = acc[k][v];
+            const float g = acc[k][P - 1];
+            if (g > 0) {                                                 // calculatePSGP :186-190 (double arithmetic, narrowed once)
+                const double frac = ((double)(fnum - g) * 1.0) / (double)sd.num;
+                pc[P] = fminf(a.min_gap_open, (float)((double)(a.gap_open * a.scale) * frac));
+                pc[P + 1] = fminf(a.min_gap_extend, (float)((double)a.gap_extend * frac));
+            } else {
+                pc[P] = a.gap_open;
+                pc[P + 1] = a.gap_extend;
+            }
+            float4 *out = reinterpret_cast<float4 *>(a.cols + ((size_t)side * a.stride + t0 + k) * CW);
+#pragma unroll
+            for (int j = 0; j < CW / 4; ++j) out[j] = make_float4(pc[4 * j], pc[4 * j + 1], pc[4 * j + 2], pc[4 * j + 3]);
+        }
         int best = P - 2;                                                // getConsensus: first strict maximum, all-zero -> N / X
         float bestCount = 0.0f;
 #pragma unroll
@@ -239,6 +258,9 @@ __global__ void __launch_bounds__(256) compact_kernel(LevelArgs a)
     }
     int total;
     int dst = base + block_scan_int_256(cnt, &total, s_wave);
+    if ((int)blockIdx.y == lastChunk && threadIdx.x == 0) a.len_out[side] = base + total;
+    // nothing removed up to the end of this chunk: profile_kernel has put its columns where they belong already
+    if (base == c0 && total == min(1024, sd.len - c0)) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!keep[k]) continue;
@@ -260,7 +282,6 @@ __global__ void __launch_bounds__(256) compact_kernel(LevelArgs a)
         for (int j = 0; j < CW / 4; ++j) out[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
         ++dst;
     }
-    if ((int)blockIdx.y == lastChunk && threadIdx.x == 0) a.len_out[side] = base + total;
 }
 
 // ---- write-back ----
