@@ -102,6 +102,8 @@ struct Buf {
 struct Device {
     int id = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                                               // row rewrites of small levels (twl_level_commit), beside the next level's work on `stream`
+    hipEvent_t ev2[2] = {};                                                      // ... timed
     hipEvent_t ev[8] = {};                                                       // [6], [7]: the write-back of a level (twl_level_commit, read later by twl_level_timing)
     int num_cu = 0;
     Buf cols, tb, cells, queue, items, errs, dbg;
@@ -801,6 +803,8 @@ int twl_init(const int *device_ids, int n_devices)
         for (auto *d : devs) {
             for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
             if (d->stream) (void)hipStreamDestroy(d->stream);
+            if (d->stream2) (void)hipStreamDestroy(d->stream2);
+            for (auto &e : d->ev2) if (e) (void)hipEventDestroy(e);
             delete d;
         }
         return rc;
@@ -813,7 +817,8 @@ int twl_init(const int *device_ids, int n_devices)
         hipDeviceProp_t prop;
         hipError_t e = hipSetDevice(id);
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, id);
-        if (e == hipSuccess) { d->num_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking); }
+        if (e == hipSuccess) { d->num_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking); if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking); }
+        for (auto &ev : d->ev2) if (e == hipSuccess) e = hipEventCreate(&ev);
         for (auto &ev : d->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
         if (e != hipSuccess) { g_err = std::string("twl_init: ") + hipGetErrorString(e); return fail(TWL_ERR_HIP); }
     }
@@ -845,12 +850,15 @@ void twl_shutdown(void)
     for (auto *d : g_devs) {
         (void)hipSetDevice(d->id);
         (void)hipStreamSynchronize(d->stream);
+        (void)hipStreamSynchronize(d->stream2);
         twl_level_pool_release(d);
         for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
         if (d->stream) (void)hipStreamDestroy(d->stream);
+        if (d->stream2) (void)hipStreamDestroy(d->stream2);
+        for (auto &e : d->ev2) if (e) (void)hipEventDestroy(e);
         if (d->res_h) (void)hipHostFree(d->res_h);
         delete d;
     }

@@ -86,8 +86,13 @@ struct LevelBufs {
     Buf r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_wtot, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
     Buf x_send, x_recv, x_rowoff, x_blkoff, x_len;                                  // exchange of final paths between processes (device blocks)
     bool busy = false;
+    hipEvent_t ev_scan = nullptr, ev_apply = nullptr;        // a small level's row rewrite runs on the device's second stream: path_scan done / rewrite done
+    bool apply_pending = false;                              // ... and may still read this set's tables
     void release_all()
     {
+        if (ev_scan) (void)hipEventDestroy(ev_scan);
+        if (ev_apply) (void)hipEventDestroy(ev_apply);
+        ev_scan = ev_apply = nullptr; apply_pending = false;
         for (Buf *b : {&d_raw, &d_colinfo, &d_cols, &d_len, &d_aln, &d_alnlen, &d_err,
                        &d_paths, &d_chunk, &d_ccnt, &r_oidx, &r_run, &r_seg, &r_aoff, &r_blist, &r_nboth, &r_wtot, &r_arena, &r_outlen, &r_tb, &r_rows, &x_send, &x_recv, &x_rowoff, &x_blkoff, &x_len})
             b->release();
@@ -108,7 +113,20 @@ std::vector<LevelBufs *> &level_pool(Device *d)
 LevelBufs *acquire_level(Device *d)
 {
     auto &pool = level_pool(d);
-    for (LevelBufs *b : pool) if (!b->busy) { b->busy = true; return b; }
+    LevelBufs *waiting = nullptr;        // free, but the row rewrite of its last level may still read its tables
+    for (LevelBufs *b : pool) {
+        if (b->busy) continue;
+        if (b->apply_pending && hipEventQuery(b->ev_apply) != hipSuccess) { (void)hipGetLastError(); if (!waiting) waiting = b; continue; }
+        b->apply_pending = false;
+        b->busy = true;
+        return b;
+    }
+    if (waiting && pool.size() >= 3) {   // (two sets alternate at the top of a tree; never more than three)
+        (void)hipStreamWaitEvent(d->stream, waiting->ev_apply, 0);
+        waiting->apply_pending = false;
+        waiting->busy = true;
+        return waiting;
+    }
     auto *b = new LevelBufs();
     b->busy = true;
     pool.push_back(b);
@@ -184,6 +202,8 @@ struct twl_store {
     std::vector<float *> h_tab;
     std::vector<uint8_t> h_mplane;
     bool commit_pending = false;             // the last commit's kernels may still run (its events are d->ev[6], d->ev[7])
+    bool commit_side = false;                // ... its row rewrite on the second stream (timed by d->ev2)
+    hipEvent_t rows_event = nullptr;         // != nullptr: a row rewrite on the second stream may still run; whoever reads or rewrites rows on the first stream waits for it
     LevelBufs *lv = nullptr;     // the level's device buffers, held from prepare to commit (from the device's pool, see LevelBufs)
     int32_t staged_stride = 0;   // > 0: twl_level_restore put this level's DP paths (and the restored ones) into lv->d_paths at this row pitch
     Buf d_gather, d_off, d_plane, d_rowlen;
@@ -236,6 +256,8 @@ int grow_rows(twl_store *s, int64_t need, int64_t want = 0)
 {
     if (need <= s->cap) return TWL_OK;
     Device *d = s->d;
+    HIP_TRY(hipStreamSynchronize(d->stream2));      // (a row rewrite of the previous level may still run there)
+    s->rows_event = nullptr;
     const int64_t minCap = (need + 255) & ~(int64_t)255;
     int64_t ncap = std::max(need, std::min(std::max(want, need + need / 2), rows_budget_cap(s)));
     ncap = (ncap + 255) & ~(int64_t)255;
@@ -268,6 +290,7 @@ void store_destroy_locked(twl_store *s)
 {
     (void)hipSetDevice(s->d->id);
     (void)hipStreamSynchronize(s->d->stream);        // (a commit does not wait for its kernels)
+    (void)hipStreamSynchronize(s->d->stream2);
     for (auto &kv : s->cache) { cache_buf_put(s->d, kv.second->buf); delete kv.second; }
     release_level(s->lv);
     for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
@@ -352,6 +375,7 @@ int twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out)
     for (int32_t i = 0; i < s->n_seqs; ++i) { off[i] = total; total += s->len[i]; maxLen = std::max(maxLen, s->len[i]); }
     int rc;
     if ((rc = s->d_gather.ensure((size_t)std::max<int64_t>(total, 16)))) return rc;
+    if (s->rows_event) { HIP_TRY(hipStreamWaitEvent(d->stream, s->rows_event, 0)); s->rows_event = nullptr; }
     if ((rc = upload(s->d_off, off, d->stream))) return rc;
     if ((rc = upload(s->d_plane, s->plane, d->stream))) return rc;
     if ((rc = upload(s->d_rowlen, s->len, d->stream))) return rc;
@@ -475,6 +499,11 @@ int twl_level_prepare(twl_store *s, const twl_params *p, float gappy_threshold, 
     s->h_num.resize(ns);
     for (size_t i = 0; i < ns; ++i) s->h_num[i] = sides[i].num;
 
+    if (s->rows_event) {       // a row rewrite on the second stream: sides that are built from rows (not from a cached profile) read what it writes
+        bool readsRows = false;
+        for (size_t i = 0; i < ns && !readsRows; ++i) readsRows = sides[i].cache_id < 0 && sides[i].n_members > 0;
+        if (readsRows) { HIP_TRY(hipStreamWaitEvent(st, s->rows_event, 0)); s->rows_event = nullptr; }
+    }
     HIP_TRY(hipEventRecord(d->ev[0], st));
     {
         Arena &A = s->lv->up_prepare;
@@ -927,7 +956,28 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     a.merge_w = (const float *)s->lv->d_mergew.p;
     hipLaunchKernelGGL(twl::path_scan_kernel, dim3((unsigned)n), dim3(256), 0, st, a);
     const unsigned nWork = (unsigned)(work.size() / 3), nMerge = (unsigned)(merge.size() / 4);
-    if (nWork) hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)((nChunks + 3) / 4)), dim3(256), 0, st, a);
+    // The row rewrite of a SMALL level (the top of a tree: a pair or a few, each with thousands of rows, 0.1-3 ms of HBM traffic) goes to
+    // the device's second stream: the next levels there align a few pairs on a few CUs from cached profiles and need no row, so the rewrite
+    // runs beside them.  Whatever reads or rewrites rows on the first stream waits for the event; the tables it reads belong to this level
+    // set, which acquire_level does not hand out again before the rewrite is done (a second set takes the next level).
+    const bool side = nWork > 0 && n <= 32 && !hostRows;
+    s->commit_side = false;
+    if (nWork && !side) {
+        if (s->rows_event) { HIP_TRY(hipStreamWaitEvent(st, s->rows_event, 0)); s->rows_event = nullptr; }
+        hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)((nChunks + 3) / 4)), dim3(256), 0, st, a);
+    } else if (nWork) {
+        LevelBufs *lv = s->lv;
+        if (!lv->ev_scan) { HIP_TRY(hipEventCreateWithFlags(&lv->ev_scan, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&lv->ev_apply, hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(lv->ev_scan, st));
+        HIP_TRY(hipStreamWaitEvent(d->stream2, lv->ev_scan, 0));        // (rewrites on the second stream follow each other in order)
+        HIP_TRY(hipEventRecord(d->ev2[0], d->stream2));
+        hipLaunchKernelGGL(twl::apply_path_kernel, dim3(nWork, (unsigned)((nChunks + 3) / 4)), dim3(256), 0, d->stream2, a);
+        HIP_TRY(hipEventRecord(d->ev2[1], d->stream2));
+        HIP_TRY(hipEventRecord(lv->ev_apply, d->stream2));
+        lv->apply_pending = true;
+        s->rows_event = lv->ev_apply;
+        s->commit_side = true;
+    }
     if (nMerge) {
         if (s->P == 6) hipLaunchKernelGGL(twl::merge_cache_kernel<6>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(twl::merge_cache_kernel<22>, dim3(nMerge, (unsigned)nChunks), dim3(256), 0, st, a);
@@ -980,9 +1030,10 @@ int twl_level_timing(twl_store *s, double *prepare_ms, double *commit_ms)
         std::lock_guard<std::mutex> lk(s->d->mu);
         HIP_TRY(hipSetDevice(s->d->id));
         HIP_TRY(hipEventSynchronize(s->d->ev[7]));
-        float ms = 0.f;
+        float ms = 0.f, ms2 = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, s->d->ev[6], s->d->ev[7]));
-        s->commit_ms = ms;
+        if (s->commit_side) { HIP_TRY(hipEventSynchronize(s->d->ev2[1])); HIP_TRY(hipEventElapsedTime(&ms2, s->d->ev2[0], s->d->ev2[1])); }
+        s->commit_ms = ms + ms2;
         s->commit_pending = false;
     }
     if (prepare_ms) *prepare_ms = s->prepare_ms;
