@@ -152,6 +152,33 @@ def test_device_pointer_form_equals_host_form(gpu):
     assert st.band_cells == ost.cells
 
 
+def test_device_pointer_form_with_unaligned_outputs(gpu):
+    """The caller's length / error-code arrays need not be 16-byte aligned (views into larger tensors): the zero-fill in front of the DP
+    kernels takes its byte-wise path for them, the result block comes back the same."""
+    import torch
+
+    batch = synth.make_level_batch(7, 700, members=((1, 4), (1, 4)), seed=43, length_jitter=0.3)
+    p = gpu.make_params(M)
+    a_host, n_host, e_host = gpu.align_batch(p, batch)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(getattr(batch, k))).to(dev) for k in ("freq", "gap_open", "gap_extend", "len", "num")}
+    n, sl = batch.n_pairs, batch.seq_len
+    aln = torch.zeros((n, 2 * sl), dtype=torch.int8, device=dev)
+    alen_big = torch.full((n + 3,), 99, dtype=torch.int32, device=dev)
+    err_big = torch.full((n + 5,), 7, dtype=torch.int16, device=dev)
+    alen, err = alen_big[1 : n + 1], err_big[3 : n + 3]          # 4 and 6 bytes past an aligned address
+    assert alen.data_ptr() % 16 != 0 and err.data_ptr() % 16 != 0
+    torch.cuda.synchronize()
+    gpu.align_batch_device(p, n, sl, t["freq"].data_ptr(), t["gap_open"].data_ptr(), t["gap_extend"].data_ptr(), t["len"].data_ptr(),
+                           t["num"].data_ptr(), aln.data_ptr(), alen.data_ptr(), err.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(alen.cpu().numpy(), n_host) and np.array_equal(err.cpu().numpy(), e_host)
+    assert int(alen_big[0]) == 99 and int(alen_big[n + 1]) == 99 and int(err_big[2]) == 7 and int(err_big[n + 3]) == 7      # nothing written outside the views
+    d_aln = aln.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(d_aln[i, : n_host[i]], a_host[i, : n_host[i]])
+
+
 def test_many_small_pairs_more_than_workgroups(gpu):
     # more work items than persistent workgroups: exercises the device-side work queue
     batch = synth.make_level_batch(48, 120, members=((1, 3), (1, 3)), seed=43, length_jitter=0.5)

@@ -817,7 +817,7 @@ int twl_init(const int *device_ids, int n_devices)
         hipDeviceProp_t prop;
         hipError_t e = hipSetDevice(id);
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, id);
-        if (e == hipSuccess) { d->num_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking); if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking); }
+        if (e == hipSuccess) { d->num_cu = prop.multiProcessorCount; e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking); if (e == hipSuccess) { int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest); e = hipStreamCreateWithPriority(&d->stream2, hipStreamNonBlocking, least); } }      // (the row rewrites there give way to the DP kernels of the first stream)
         for (auto &ev : d->ev2) if (e == hipSuccess) e = hipEventCreate(&ev);
         for (auto &ev : d->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
         if (e != hipSuccess) { g_err = std::string("twl_init: ") + hipGetErrorString(e); return fail(TWL_ERR_HIP); }
