@@ -654,6 +654,11 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     // the block takes part when the band touches it or will reach it on the next diagonal (its lane 0 then needs
                     // S[k-1][b-1] now, to have S[k-2][i-1] next time): Lk - 63 <= b <= Uk + 1
                     if ((unsigned)(b - lkm63) <= wlim) {
+                        // a wave with cells to compute issues ahead of the idle waves of its SIMD (their per-diagonal bookkeeping otherwise sits
+                        // in front of it: an active wave started its step up to 1100 cycles after the first wave of its SIMD); back to 0
+                        // in front of the barrier, where the idle waves must not be held up -- keeping the priority across the barrier
+                        // gave the gain away again.  Wide level 130 -> 121 ms, 100 pairs in tiles 8.2 -> 7.6 ms (tools/exp_step_cost.py).
+                        __builtin_amdgcn_s_setprio(2);
                         const int i = b + lane;
                         // ---- loads: mailbox of the previous block, reference column of this cell ----
                         float eS, eI; int eCS = 0, eCI = 0;
@@ -868,6 +873,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
                 }
                 TWL_STAMP(t_slots);
+                __builtin_amdgcn_s_setprio(0);
                 wg_barrier_lds();
                 TWL_STAMP(t_bar);
 
