@@ -249,3 +249,25 @@ def test_badly_filled_last_round_goes_through_tiles(knobs):
     assert st2.mt_tiles_predicted + st2.mt_tiles_inline == 0
     assert np.array_equal(aln, aln2) and np.array_equal(ln, ln2) and np.array_equal(err, err2)
     assert st.band_cells == st2.band_cells
+
+
+def test_badly_filled_last_round_of_a_leaf_level(knobs):
+    """The same with one-letter query rows (a leaf level): full rounds and tiles both take the four-product form of the column score (matrix mode 5)."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n = 2 * cus + 19
+    pool = synth.make_level_batch(10, 4400, members=((1, 6), (1, 1)), seed=78)
+    idx = np.arange(n) % pool.n_pairs
+    batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    p = knobs.make_params(M)
+    knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 1)
+    try:
+        aln, ln, err = knobs.align_batch(p, batch)
+        st = knobs.get_stats(0)
+    finally:
+        knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M), pool, threads=8)
+    assert st.matrix_mode == 5 and st.mt_tiles_predicted + st.mt_tiles_inline > 0, (st.matrix_mode, st.mt_tiles_predicted)
+    assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx])
+    for i in range(n):
+        assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"

@@ -664,7 +664,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             if (!rc && tail > 0) {
                 const std::vector<int32_t> tailOrder(order.begin() + bulk, order.begin() + n_run);
                 int g2 = 0, w2 = 0;
-                rc = launch_mt<6, 2, 2>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
+                // (one-letter query rows: the tiles too take the four-product form of the column score)
+                rc = mm5 ? launch_mt<6, 5, 2>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2)
+                         : launch_mt<6, 2, 2>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
                 ranMt = true;
             }
         }
