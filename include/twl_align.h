@@ -158,10 +158,12 @@ int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq
                              (twl_level.h) knows this by itself
      TWL_KNOB_MT_TAIL_PCT    levels of more than 2 * CUs pairs: a last round of the throughput kernel that would be filled to at most this
                              share (percent, default 70) runs on the tile-parallel path instead, behind the full rounds, when its pairs have 8 or more
-                             tiles each (0 = never) */
+                             tiles each (0 = never)
+     TWL_KNOB_MT_WIDE        1 (default): pairs whose band outgrew the 1024-row window re-run with all their tiles at once on the 3072-row geometry;
+                             0: tile after tile on the 2048-row kernel (the path before round 4; tests hold the two to each other) */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12 };
 int twl_set_knob(int key, int value);
 
 #ifdef __cplusplus

@@ -24,6 +24,7 @@ def knobs(gpu):
     gpu.set_knob(api.KNOB_MT_MARGIN, 40)
     gpu.set_knob(api.KNOB_MT_ROUNDS, 2)
     gpu.set_knob(api.KNOB_MT_THR_JOBS, 256)
+    gpu.set_knob(api.KNOB_MT_WIDE, 1)
 
 
 def _compare(twl, batch, **pk):
@@ -131,6 +132,63 @@ def test_long_pair_100k(knobs):
     batch = synth.make_level_batch(2, 100000, members=((1, 3), (1, 3)), seed=77, sub=0.03, indel=0.002)
     st, ost = _compare(knobs, batch)
     assert st.speculative == 3 and st.mt_tiles_predicted > 150
+
+
+# ---- pairs whose band outgrows the 1024-row window: all tiles at once on the 3072-row geometry (round 4) ----
+@pytest.mark.parametrize("xdrop,lo,hi", [(14000, 1024, 2048), (26000, 2560, 2944)])
+def test_wide_band_pairs_rerun_tile_parallel_on_the_3072_row_window(knobs, xdrop, lo, hi):
+    """A larger X-drop widens the band past the 1024-row window of the fast geometries: the pairs come back with the internal window code and
+    re-run -- scouts, tiles, stitch -- on 16 waves x 3 blocks.  Paths, error codes and band cells are the oracle's, and those of the
+    tile-after-tile path of round 3 (TWL_KNOB_MT_WIDE 0)."""
+    batch = synth.make_level_batch(3, 6000, members=((1, 6), (1, 6)), seed=101, sub=0.12, indel=0.01)
+    st, ost = _compare(knobs, batch, xdrop=xdrop)
+    assert lo < ost.max_width <= hi, ost.max_width            # the case is what it claims to be
+    assert st.n_relaunched > 0 and st.mt_tiles_predicted + st.mt_tiles_inline >= ost.tiles, (st.n_relaunched, st.mt_tiles_predicted, st.mt_tiles_inline, ost.tiles)
+    p = knobs.make_params(M, xdrop=xdrop)
+    aln, n, err = knobs.align_batch(p, batch)
+    knobs.set_knob(api.KNOB_MT_WIDE, 0)
+    aln0, n0, err0 = knobs.align_batch(p, batch)
+    st0 = knobs.get_stats(0)
+    assert np.array_equal(aln, aln0) and np.array_equal(n, n0) and np.array_equal(err, err0) and st0.band_cells == st.band_cells
+
+
+def test_wide_band_rerun_with_spoiled_predictions_and_one_round(knobs):
+    knobs.set_knob(api.KNOB_MT_PERTURB, 2)
+    knobs.set_knob(api.KNOB_MT_ROUNDS, 1)
+    batch = synth.make_level_batch(2, 5000, members=((1, 6), (1, 6)), seed=102, sub=0.12, indel=0.01)
+    st, ost = _compare(knobs, batch, xdrop=14000)
+    assert st.n_relaunched > 0 and st.mt_tiles_inline >= 1
+
+
+def test_band_wider_than_the_3072_row_window_moves_on_to_the_widest_kernel(knobs):
+    """... and a band that outgrows that one too ends on the 4608-row kernel, as before."""
+    batch = synth.make_level_batch(2, 5000, members=((1, 4), (1, 4)), seed=103, sub=0.2, indel=0.01)
+    st, ost = _compare(knobs, batch, xdrop=30000)
+    assert ost.max_width > 2944 and st.n_relaunched >= 2 * batch.n_pairs, (ost.max_width, st.n_relaunched)
+
+
+def test_wide_band_rerun_in_a_large_level_touches_only_its_own_rows(knobs):
+    """300 pairs of which two outgrow the window: the tables of the re-run are sized by the two, results unchanged."""
+    base = synth.make_level_batch(6, 4400, members=((1, 6), (1, 6)), seed=104)
+    wide = synth.make_level_batch(2, 4400, members=((1, 6), (1, 6)), seed=105, sub=0.3, indel=0.02)
+    idx = np.arange(300) % 6
+    def cat(a, b): return np.concatenate([a[idx], b])
+    big = synth.LevelBatch(P=6, seq_len=max(base.seq_len, wide.seq_len), freq=None, gap_open=None, gap_extend=None, len=None, num=None)
+    sl = big.seq_len
+    def pad(x): return np.pad(x, [(0, 0), (0, 0), (0, sl - x.shape[2])] + [(0, 0)] * (x.ndim - 3))
+    big = synth.LevelBatch(P=6, seq_len=sl, freq=cat(pad(base.freq), pad(wide.freq)), gap_open=cat(pad(base.gap_open), pad(wide.gap_open)),
+                           gap_extend=cat(pad(base.gap_extend), pad(wide.gap_extend)), len=cat(base.len, wide.len), num=cat(base.num, wide.num))
+    pk = dict(xdrop=9000)
+    p = knobs.make_params(M, **pk)
+    aln, n, err = knobs.align_batch(p, big)
+    st = knobs.get_stats(0)
+    ob = O.align_batch(O.make_params(M, **pk), base, threads=8)
+    ow = O.align_batch(O.make_params(M, **pk), wide, threads=8)
+    for i in range(big.n_pairs):
+        oa, on, oe = (ob[0][idx[i]], ob[1][idx[i]], ob[2][idx[i]]) if i < 300 else (ow[0][i - 300], ow[1][i - 300], ow[2][i - 300])
+        assert err[i] == oe and n[i] == on and np.array_equal(aln[i, : n[i]], oa[:on]), f"pair {i}"
+    assert st.band_cells == 50 * ob[3].cells + ow[3].cells
+    assert ow[3].max_width > 960 or st.n_relaunched == 0
 
 
 # ---- protein (P = 22): tile-parallel on the precomputed column scores ----

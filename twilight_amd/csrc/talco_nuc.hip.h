@@ -55,13 +55,13 @@ struct NArgs {
     unsigned long long *team; // speculative tile start (SPEC kernels): [n_items][16] mailbox words, zeroed by the host
     float *simdump;           // DUMP kernels (diagnostics, one pair): [Q][R] column scores as the DP evaluated them
     // tile-parallel alignment (MT kernels, see below)
-    const int32_t *mt_jobs;   // [n_items][2] {pair, slot} (MT 1, 2; `items` is unused there)
-    int32_t *mt_chain;        // [pair][mt_slots][2] predicted start {ref_idx, qry_idx} of tile `slot`; ref_idx < 0: unknown
-    int32_t *mt_rec;          // [pair][mt_slots][kMtRec] result of the tile that was run from the predicted start
-    int8_t *mt_seg;           // [pair][mt_slots][mt_segcap] its path segment, forward order
-    int32_t *mt_spath;        // [pair][mt_sp_pitch] scouts: query row of the path cell on anti-diagonal d; -1 = the path skips d; < -1 = unknown
+    const int32_t *mt_jobs;   // [n_items][3] {pair, slot, row of the pair in the mt_* tables} (MT 1, 2; `items` is unused there)
+    int32_t *mt_chain;        // [row][mt_slots][2]  (row = the pair's position in the stitch launch) predicted start {ref_idx, qry_idx} of tile `slot`; ref_idx < 0: unknown
+    int32_t *mt_rec;          // [row][mt_slots][kMtRec] result of the tile that was run from the predicted start
+    int8_t *mt_seg;           // [row][mt_slots][mt_segcap] its path segment, forward order
+    int32_t *mt_spath;        // [row][mt_sp_pitch] scouts: query row of the path cell on anti-diagonal d; -1 = the path skips d; < -1 = unknown
     unsigned long long *mt_stat;   // [4] {tiles taken from the records, tiles run in line, scouts that failed, -}
-    int32_t *mt_front;        // [pair][8] how far the stitch launches have come: {0 untouched / 1 suspended at a tile without a record / 2 done, tile, ref_idx, qry_idx, pos, -, cells lo, cells hi}
+    int32_t *mt_front;        // [row][8] how far the stitch launches have come: {0 untouched / 1 suspended at a tile without a record / 2 done, tile, ref_idx, qry_idx, pos, -, cells lo, cells hi}
     int32_t mt_slots, mt_segcap, mt_sp_pitch, mt_lead, mt_marg;
     int32_t mt_inline;        // MT 3: 1 = a tile without a matching record is computed in line (last round); 0 = the pair is suspended there
 };
@@ -201,9 +201,10 @@ __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_
     if (it >= n_items) return;
     const int pair = items[it];
     const int R = len[2 * pair], Q = len[2 * pair + 1];
-    const int32_t *sp = spath + (size_t)pair * (size_t)sp_pitch;
-    int32_t *ch = chain + (size_t)pair * (size_t)slots * 2;
-    const int32_t *fr = front + (size_t)pair * 8;
+    // (the tables of a tile-parallel level are indexed by the pair's position in the launch, not by its id: they cost memory and fills for the pairs that run only)
+    const int32_t *sp = spath + (size_t)it * (size_t)sp_pitch;
+    int32_t *ch = chain + (size_t)it * (size_t)slots * 2;
+    const int32_t *fr = front + (size_t)it * 8;
     if (fr[0] == 2) return;                       // the pair is finished
     int s = 0, t = 1;
     if (fr[0] == 1) {                             // later rounds: from the true start of the first tile without a record
@@ -302,8 +303,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             item = __builtin_amdgcn_readfirstlane(s_misc[0]);
         }
         if (item >= a.n_items) break;
-        const int pair = __builtin_amdgcn_readfirstlane((MT == 1 || MT == 2) ? a.mt_jobs[2 * item] : a.items[item]);
-        const int slot = (MT == 1 || MT == 2) ? __builtin_amdgcn_readfirstlane(a.mt_jobs[2 * item + 1]) : 0;
+        const int pair = __builtin_amdgcn_readfirstlane((MT == 1 || MT == 2) ? a.mt_jobs[3 * item] : a.items[item]);
+        const int slot = (MT == 1 || MT == 2) ? __builtin_amdgcn_readfirstlane(a.mt_jobs[3 * item + 1]) : 0;
+        const int mtx = (MT == 1 || MT == 2) ? __builtin_amdgcn_readfirstlane(a.mt_jobs[3 * item + 2]) : item;      // row of this pair in the mt_* tables: its position in the stitch launch
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
         // MT 2 (scout of tile boundary `slot`): the anti-diagonals it reports and its own marker behind them
         const int spLo = (a.marker - 1) * slot - 1, spHi = a.marker * slot + 1;
@@ -323,15 +325,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         bool last_tile = (R <= 0 || Q <= 0);
         if constexpr (MT == 1) {          // one tile, from its predicted start (tile 0: from the corner)
             if (slot > 0) {
-                ref_idx = __builtin_amdgcn_readfirstlane(a.mt_chain[((size_t)pair * a.mt_slots + slot) * 2]);
-                qry_idx = __builtin_amdgcn_readfirstlane(a.mt_chain[((size_t)pair * a.mt_slots + slot) * 2 + 1]);
+                ref_idx = __builtin_amdgcn_readfirstlane(a.mt_chain[((size_t)mtx * a.mt_slots + slot) * 2]);
+                qry_idx = __builtin_amdgcn_readfirstlane(a.mt_chain[((size_t)mtx * a.mt_slots + slot) * 2 + 1]);
                 tile = 1;
                 if (ref_idx < 0) last_tile = true;      // no prediction for this tile
             }
             // later rounds: only the tiles the stitch launches have not passed yet, and only where no record of the predicted start exists
-            const int32_t *fr = a.mt_front + (size_t)pair * 8;
+            const int32_t *fr = a.mt_front + (size_t)mtx * 8;
             const int fs = __builtin_amdgcn_readfirstlane(fr[0]), ft = __builtin_amdgcn_readfirstlane(fr[1]);
-            const int32_t *rc = a.mt_rec + ((size_t)pair * a.mt_slots + slot) * kMtRec;
+            const int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + slot) * kMtRec;
             const int rv = __builtin_amdgcn_readfirstlane(rc[0]), rr = __builtin_amdgcn_readfirstlane(rc[1]), rq = __builtin_amdgcn_readfirstlane(rc[2]);
             if (fs == 2 || (fs == 1 && slot < ft) || (rv == 1 && rr == ref_idx && rq == qry_idx)) last_tile = true;
         }
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         bool suspended = false, mtSkip = false;
         unsigned long long mtCells0 = 0;
         if constexpr (MT == 3) {          // where the previous stitch launch left this pair
-            const int32_t *fr = a.mt_front + (size_t)pair * 8;
+            const int32_t *fr = a.mt_front + (size_t)mtx * 8;
             const int fs = __builtin_amdgcn_readfirstlane(fr[0]);
             if (fs == 2) { mtSkip = true; last_tile = true; }
             else if (fs == 1) {
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 mtCells0 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(fr[6]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(fr[7]) << 32);
             }
         }
-        int8_t *out = (MT == 1) ? a.mt_seg + ((size_t)pair * a.mt_slots + slot) * (size_t)a.mt_segcap : a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
+        int8_t *out = (MT == 1) ? a.mt_seg + ((size_t)mtx * a.mt_slots + slot) * (size_t)a.mt_segcap : a.aln + (size_t)pair * 2 * (size_t)a.seq_len;
         unsigned long long cells = 0;
         long long steps_left = (long long)(R + Q + 2) * ((R + Q) / (max(marker, 2) - 1) + 4) + a.step_slack;
         // The row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits -- TILE-local values, so sequences of any length pass
@@ -421,14 +423,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             bool memoHit = false;
             if constexpr (MT == 3) {      // the tile that starts here may have been computed already (MT 1 launch): same start, same tile
                 if (tile < a.mt_slots) {
-                    const int32_t *rc = a.mt_rec + ((size_t)pair * a.mt_slots + tile) * kMtRec;
+                    const int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + tile) * kMtRec;
                     const int rcValid = __builtin_amdgcn_readfirstlane(rc[0]), rcRef = __builtin_amdgcn_readfirstlane(rc[1]), rcQry = __builtin_amdgcn_readfirstlane(rc[2]);
                     memoHit = (rcValid == 1 && rcRef == ref_idx && rcQry == qry_idx);
                     if (memoHit) {
                         const int cnt = __builtin_amdgcn_readfirstlane(rc[6]), tailDir = __builtin_amdgcn_readfirstlane(rc[7]), tailLen = __builtin_amdgcn_readfirstlane(rc[8]);
                         if (pos + cnt + tailLen > 2 * a.seq_len) err = 3;
                         else {
-                            const int8_t *sg = a.mt_seg + ((size_t)pair * a.mt_slots + tile) * (size_t)a.mt_segcap;
+                            const int8_t *sg = a.mt_seg + ((size_t)mtx * a.mt_slots + tile) * (size_t)a.mt_segcap;
                             for (int t = threadIdx.x; t < cnt; t += C::THREADS) out[pos + t] = sg[t];
                             for (int t = threadIdx.x; t < tailLen; t += C::THREADS) out[pos + cnt + t] = (int8_t)tailDir;
                             pos += cnt + tailLen;
@@ -912,8 +914,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             // when its two end cells hold the same convergence pointer.  The ends' pointers were left in LDS by their blocks
                             // before the barrier; two broadcast reads decide.  Until shortly before the tile converges the ends disagree, and
                             // the test proper -- ballots, three reductions, a second workgroup barrier -- is skipped: conv_S = -1, as it would find.
-                            const int cLo = lds_ld<int>(vcur + O_EDGE + 8u * (((unsigned)newL >> 6) & (unsigned)(NV - 1)));
-                            const int cHi = lds_ld<int>(vcur + O_EDGE + 8u * (((unsigned)newU >> 6) & (unsigned)(NV - 1)) + 4u);
+                            const int cLo = lds_ld<int>(vcur + O_EDGE + 8u * (((unsigned)newL >> 6) % (unsigned)NV));      // (a mask when NV is a power of two)
+                            const int cHi = lds_ld<int>(vcur + O_EDGE + 8u * (((unsigned)newU >> 6) % (unsigned)NV) + 4u);
                             const bool maybe = __builtin_amdgcn_ballot_w64(newL <= newU && cLo == cHi) != 0ull;
                             if (maybe) {
                             const unsigned cw = (unsigned)(newU - newL);
@@ -1168,7 +1170,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     // until the next tile, and the walk reads LDS.
                     constexpr int PG = 16;
                     static_assert(sizeof(s_ring) >= PG * 64 * sizeof(uint32_t), "traceback patch lives in the ring");
-                    static_assert((WINDOW & (WINDOW - 1)) == 0, "window rows wrap by a mask");
                     uint32_t *s_patch = reinterpret_cast<uint32_t *>(s_ring);
                     int kk2 = start_k, ii = conv_q, qi = conv_q, ri = conv_r, st = tb_state % 3;
                     const bool first = (tile == 0);
@@ -1180,7 +1181,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         for (int t = 0; t < PG; ++t) {
                             uint32_t word = 0u;
                             if (g0 - t >= 0 && row >= 0)
-                                word = __hip_atomic_load(&tb[(size_t)(g0 - t) * WINDOW + (size_t)(row & (WINDOW - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                word = __hip_atomic_load(&tb[(size_t)(g0 - t) * WINDOW + (size_t)((unsigned)row % (unsigned)WINDOW)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             s_patch[t * 64 + lane] = word;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order)
@@ -1224,14 +1225,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if (cnt <= a.mt_segcap) {
                         for (int t = lane; t < cnt; t += 64) out[t] = s_rev[n - 1 - skip - t];
                         if (lane == 0) {
-                            int32_t *rc = a.mt_rec + ((size_t)pair * a.mt_slots + slot) * kMtRec;
+                            int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + slot) * kMtRec;
                             rc[1] = jobRef; rc[2] = jobQry; rc[3] = ref_idx; rc[4] = qry_idx; rc[5] = last_tile ? 1 : 0; rc[6] = cnt;
                             rc[7] = tailDir; rc[8] = tailLen; rc[9] = (int32_t)tile_cells; rc[0] = 1;
                         }
                     }
                 } else if constexpr (MT == 2) {   // where the scout's path crosses the anti-diagonals of its tile boundary
                     if (lane == 0) {
-                        int32_t *sp = a.mt_spath + (size_t)pair * (size_t)a.mt_sp_pitch;
+                        int32_t *sp = a.mt_spath + (size_t)mtx * (size_t)a.mt_sp_pitch;
                         const int dMax = min(spHi, R + Q - 2);
                         for (int d = spLo; d <= dMax; ++d) sp[d] = -1;
                         int r = jobRef, q = jobQry;
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         }
         if constexpr (MT == 3) {
             if (threadIdx.x == 0 && !mtSkip) {
-                int32_t *fr = a.mt_front + (size_t)pair * 8;
+                int32_t *fr = a.mt_front + (size_t)mtx * 8;
                 const unsigned long long c = cells + mtCells0;
                 fr[1] = tile; fr[2] = ref_idx; fr[3] = qry_idx; fr[4] = pos; fr[6] = (int32_t)(unsigned)(c & 0xFFFFFFFFull); fr[7] = (int32_t)(unsigned)(c >> 32);
                 fr[0] = suspended ? 1 : 2;

@@ -286,6 +286,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     return TWL_OK;
 }
 
+constexpr int kMtMaxRounds = 7, kMtCounters = 16;      // 1 + 2 * rounds launches, each with its own work counter (the count is clamped wherever it is set)
 // One launch of a tile-parallel kernel (MT 1 tiles / 2 scouts / 3 stitch) of geometry <W, RPL>; the caller has filled the NArgs.
 template <int P, int W, int RPL, int MM, int MINW, int MT>
 int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *grid_out = nullptr)
@@ -303,7 +304,7 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
     if (rc) return rc;
     a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
     // (every launch of a tile-parallel level has its own work counter: launch_mt zeroed the 16 of them in one go)
-    a.queue = (int32_t *)d->queue.p + (d->mt_launch++ & 15);
+    a.queue = (int32_t *)d->queue.p + (d->mt_launch++ % kMtCounters);
     FILL_TRY(flush_fills(d, st));
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
@@ -317,21 +318,27 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
+int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
 int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 
-template <int P, int MM, int TRPL>      // TRPL: 64-row blocks per wave of the throughput geometry (nucleotide 2: 1024 rows, protein 1: 512 rows)
+template <int P, int MM, int TRPL, bool WIDE = false>      // TRPL: 64-row blocks per wave of the throughput geometry (nucleotide 2: 1024 rows, protein 1: 512 rows)
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
               const int32_t *h_len, int *grid_out, int *window_out)
 {
-    if (window_out) *window_out = twl::NCfg<16, 1>::WINDOW;
+    // WIDE (nucleotide): the tiles and the stitch launch on 16 waves x 3 blocks, a 3072-row window -- for the pairs whose band outgrew the
+    // 1024-row window of the fast geometries.  Until round 4 those ran their ~20 tiles one after the other on the 2048- and 4608-row kernels
+    // (0.2-0.6 s per 10 kbp pair); their tiles are as independent as anybody's.  The scouts keep the narrow geometry: a scout's band opens
+    // from one cell by a row per diagonal over the ~400 diagonals it runs.
+    constexpr int SW = 16, SR = WIDE ? 3 : 1;       // geometry of the stitch launch and of tiles while they fit the device at once
+    if (window_out) *window_out = twl::NCfg<SW, SR>::WINDOW;
     const int marker = base.marker;
     const int slots = (2 * base.seq_len) / (marker - 1) + 2;
     const int segcap = 2 * marker + 16;
     const int sp_pitch = 2 * base.seq_len + 8;
-    const size_t np = (size_t)base.n_pairs_total;
-    // jobs: scouts for every tile boundary t >= 1 that exists, tiles for t >= 0 (tile-major, so that the tiles of a pair spread over the launch)
+    const size_t np = (size_t)n_run;               // the tables are indexed by the position of a pair in `order` (not by pair id)
+    // jobs {pair, slot, row}: scouts for every tile boundary t >= 1 that exists, tiles for t >= 0 (tile-major, so that the tiles of a pair spread over the launch)
     std::vector<int32_t> &jobs = d->mt_jobs_host;       // scouts first, then tiles (kept with the device: the upload below is asynchronous)
     jobs.clear();
     int maxT = 0;
@@ -343,10 +350,10 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         while (n < slots && (long long)(marker - 1) * n - 1 <= RQ - 2) ++n;
         T[t] = n; maxT = std::max(maxT, n);
     }
-    for (int s = 1; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); }
-    const int nScout = (int)(jobs.size() / 2);
-    for (int s = 0; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); }
-    const int nTile = (int)(jobs.size() / 2) - nScout;
+    for (int s = 1; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); jobs.push_back(t); }
+    const int nScout = (int)(jobs.size() / 3);
+    for (int s = 0; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); jobs.push_back(t); }
+    const int nTile = (int)(jobs.size() / 3) - nScout;
     int rc;
     if ((rc = d->mt_chain.ensure(np * slots * 2 * sizeof(int32_t)))) return rc;
     if ((rc = d->mt_rec.ensure(np * slots * twl::kMtRec * sizeof(int32_t)))) return rc;
@@ -358,7 +365,8 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     FILL_TRY(queue_fill(d, st, d->mt_rec.p, np * slots * twl::kMtRec * sizeof(int32_t), 0));
     FILL_TRY(queue_fill(d, st, d->mt_spath.p, np * (size_t)sp_pitch * sizeof(int32_t), 0xFE));
     FILL_TRY(queue_fill(d, st, d->mt_stat.p, 4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t), 0));
-    FILL_TRY(queue_fill(d, st, d->queue.p, 16 * sizeof(int32_t), 0));
+    const int rounds = std::max(1, std::min(g_mt_rounds, kMtMaxRounds));
+    FILL_TRY(queue_fill(d, st, d->queue.p, kMtCounters * sizeof(int32_t), 0));      // one work counter per launch: scouts + rounds x (tiles, stitch)
     d->mt_launch = 0;
     twl::NArgs a{};
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
@@ -372,30 +380,30 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.mt_stat = (unsigned long long *)d->mt_stat.p;
     a.mt_front = (int32_t *)((unsigned long long *)d->mt_stat.p + 4);
     a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
-    const bool thr = nTile > g_mt_thr_jobs;
-    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, thr ? "8 waves, 2 per CU" : "16x1");
+    const bool thr = !WIDE && nTile > g_mt_thr_jobs;
+    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, WIDE ? "16x3 (wide)" : (thr ? "8 waves, 2 per CU" : "16x1"));
     if (!d->kname[0]) {
         if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 8, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TRPL, MM, P, MM);
-        else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, 1, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, MM);
+        else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, %d, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, SR, MM);
     }
     if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
-        rc = thr ? launch_mt_kernel<P, 8, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
+        const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
+        rc = thrS ? launch_mt_kernel<P, 8, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
         if (rc) return rc;
     }
-    const int rounds = std::max(1, g_mt_rounds);
     for (int r = 0; r < rounds; ++r) {
         FILL_TRY(flush_fills(d, st));
         hipLaunchKernelGGL(twl::mt_chain_kernel, dim3((n_run + 63) / 64), dim3(64), 0, st, (const int32_t *)d->mt_spath.p, sp_pitch, base.len, d_items, n_run,
                            (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
         HIP_TRY(hipGetLastError());
-        a.mt_jobs = (const int32_t *)d->mt_jobs.p + 2 * (size_t)nScout;
-        rc = thr ? launch_mt_kernel<P, 8, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, 16, 1, MM, 1, 1>(d, st, a, nTile, grid_out);
+        a.mt_jobs = (const int32_t *)d->mt_jobs.p + 3 * (size_t)nScout;
+        rc = thr ? launch_mt_kernel<P, 8, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
         if (rc) return rc;
         a.mt_jobs = nullptr;
         a.mt_inline = (r == rounds - 1) ? 1 : 0;
         a.dbg = a.mt_inline ? base.dbg : nullptr;
-        if ((rc = launch_mt_kernel<P, 16, 1, MM, 1, 3>(d, st, a, n_run))) return rc;
+        if ((rc = launch_mt_kernel<P, SW, SR, MM, 1, 3>(d, st, a, n_run))) return rc;
     }
     return TWL_OK;
 }
@@ -691,6 +699,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     std::vector<int16_t> h_err((size_t)n_pairs);
     std::vector<unsigned long long> cells((size_t)n_pairs);
     unsigned long long mtStat[4] = {0, 0, 0, 0};
+    bool redoMt = false;      // a re-run went through the tile-parallel path (launch_mt, WIDE)
     // (one small kernel writes them into a pinned host block: three device-to-host copies into pageable memory before)
     const size_t resBytes = 4 * sizeof(unsigned long long) + (size_t)n_pairs * (sizeof(unsigned long long) + sizeof(int32_t) + sizeof(int16_t));
     if (resBytes > d->res_cap) {
@@ -701,7 +710,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     auto collect = [&](bool withCells) -> int {
         hipLaunchKernelGGL(twl::collect_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, (int)n_pairs, (const int16_t *)d_err, (const int32_t *)d_alnlen,
-                           (const unsigned long long *)d->cells.p, ranMt ? (const unsigned long long *)d->mt_stat.p : nullptr, (unsigned long long *)d->res_h);
+                           (const unsigned long long *)d->cells.p, (ranMt || redoMt) ? (const unsigned long long *)d->mt_stat.p : nullptr, (unsigned long long *)d->res_h);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         const unsigned long long *r = (const unsigned long long *)d->res_h;
@@ -709,7 +718,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const int16_t *re = (const int16_t *)(rl + n_pairs);
         std::copy(re, re + n_pairs, h_err.begin());
         d->last_alnlen.assign(rl, rl + n_pairs);
-        if (withCells) { std::copy(r + 4, r + 4 + n_pairs, cells.begin()); if (ranMt) for (int t = 0; t < 4; ++t) mtStat[t] = r[t]; }
+        if (withCells) { std::copy(r + 4, r + 4 + n_pairs, cells.begin()); if (ranMt || redoMt) for (int t = 0; t < 4; ++t) mtStat[t] = r[t]; }
         return TWL_OK;
     };
     bool reran = false;
@@ -732,8 +741,15 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (guardRound) rc = prot ? launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2)
                                   : launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
         else if (mid && prot) rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
-        // nucleotide, default matrix structure: the lean kernel on a 2048-row window (8 waves x 4 blocks, reference ring still in LDS)
-        else if (mid && leanMid) rc = launch_lean<6, 8, 4, 2, 2>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        // nucleotide, default matrix structure: every tile of these pairs at once on a 3072-row window (launch_mt, WIDE) when they have tiles
+        // to spread; otherwise the lean kernel on a 2048-row window (8 waves x 4 blocks, reference ring still in LDS), tile after tile
+        else if (mid && leanMid) {
+            long long redoLen = 0;
+            for (int32_t n : redo) redoLen += (long long)h_len[2 * n] + h_len[2 * n + 1];
+            const bool wideMt = g_mt_wide && (int)redo.size() <= g_mt_max_pairs && p->marker >= g_mt_min_marker && redoLen >= 3ll * p->marker * (long long)redo.size();
+            if (wideMt) { rc = launch_mt<6, 2, 2, true>(d, st, a, (const int32_t *)d->items.p, redo, (int)redo.size(), h_len, &grid2, &w2); redoMt = true; }
+            else rc = launch_lean<6, 8, 4, 2, 2>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        }
         else if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
         else rc = launch_wide((const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         if (rc) return rc;
@@ -751,13 +767,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     if (reran) {
         const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
         if ((rc = collect(true))) return rc;
-        for (int t = 0; t < 4; ++t) mtStat[t] = keep[t];      // (the counters of the first launch: a re-run does not touch them)
+        for (int t = 0; t < 4; ++t) mtStat[t] = keep[t] + (redoMt ? mtStat[t] : 0ull);      // (the counters of the first launch, plus those of a tile-parallel re-run)
     }
     for (int32_t n = 0; n < n_pairs; ++n)
         if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
     uint64_t total = 0;
     for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
-    if (ranMt) { d->stats.mt_tiles_predicted = (int32_t)mtStat[0]; d->stats.mt_tiles_inline = (int32_t)mtStat[1]; d->stats.mt_scouts_failed = (int32_t)mtStat[2]; }
+    if (ranMt || redoMt) { d->stats.mt_tiles_predicted = (int32_t)mtStat[0]; d->stats.mt_tiles_inline = (int32_t)mtStat[1]; d->stats.mt_scouts_failed = (int32_t)mtStat[2]; }
     d->last_err = h_err;      // (twl_level_align hands them to its caller without another copy)
     if (want_dbg) {
         d->dbg_host.resize((size_t)n_pairs * 16);
@@ -826,14 +842,10 @@ int twl_init(const int *device_ids, int n_devices)
     }
     g_devs = devs;
     g_init = true;
-#ifdef TWL_DEV      // development builds (__graft_entry__.build() with TWL_DEV_BUILD=1): the knobs of twl_set_knob from the environment
-    if (const char *v = getenv("TWL_MT_MAX_PAIRS")) g_mt_max_pairs = atoi(v);
-    if (const char *v = getenv("TWL_MT_LEAD")) g_mt_lead = atoi(v);
-    if (const char *v = getenv("TWL_MT_MARGIN")) g_mt_marg = atoi(v);
-    if (const char *v = getenv("TWL_MT_PERTURB")) g_mt_perturb = atoi(v);
-    if (const char *v = getenv("TWL_MT_ROUNDS")) g_mt_rounds = atoi(v);
-    if (const char *v = getenv("TWL_MT_THR_JOBS")) g_mt_thr_jobs = atoi(v);
-    if (const char *v = getenv("TWL_MT_TAIL_PCT")) g_mt_tail_pct = atoi(v);
+#ifdef TWL_DEV      // development builds (__graft_entry__.build() with TWL_DEV_BUILD=1): the knobs of twl_set_knob from the environment, through its clamps
+    static const struct { const char *env; int knob; } kEnvKnobs[] = {{"TWL_MT_MAX_PAIRS", TWL_KNOB_MT_MAX_PAIRS}, {"TWL_MT_LEAD", TWL_KNOB_MT_LEAD}, {"TWL_MT_MARGIN", TWL_KNOB_MT_MARGIN},
+        {"TWL_MT_PERTURB", TWL_KNOB_MT_PERTURB}, {"TWL_MT_ROUNDS", TWL_KNOB_MT_ROUNDS}, {"TWL_MT_THR_JOBS", TWL_KNOB_MT_THR_JOBS}, {"TWL_MT_TAIL_PCT", TWL_KNOB_MT_TAIL_PCT}};
+    for (const auto &k : kEnvKnobs) if (const char *v = getenv(k.env)) (void)twl_set_knob(k.knob, atoi(v));
 #endif
     return TWL_OK;
 }
@@ -1166,6 +1178,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_PROT_MODE: if (value < 0 || value > 6) { g_err = "protein mode 0..6"; return TWL_ERR_BAD_ARGUMENT; } g_prot_mode = value; return TWL_OK;
     case TWL_KNOB_ASSUME_ONEHOT_QUERY: g_assume_onehot_query = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_MT_TAIL_PCT: g_mt_tail_pct = std::max(0, std::min(100, value)); return TWL_OK;
+    case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }
