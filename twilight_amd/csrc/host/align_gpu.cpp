@@ -302,6 +302,28 @@ static void runBatch(RunCtx &ctx, LevelRecord &rec, const twl_params &tp, const 
     }
     const size_t sl = (size_t)stride;
     int8_t *aln = g_stage.aln + (size_t)first * 2 * sl;
+#ifdef TWL_DEV      // development builds: the inputs of up to TWL_DUMP_BATCH_N calls as raw arrays (tools/load_dump.py), to replay a call on the CPU checker
+    if (const char *dump = getenv("TWL_DUMP_BATCH")) {
+        static int left = getenv("TWL_DUMP_BATCH_N") ? atoi(getenv("TWL_DUMP_BATCH_N")) : 4;
+        const int minStride = getenv("TWL_DUMP_BATCH_MIN") ? atoi(getenv("TWL_DUMP_BATCH_MIN")) : 0;
+        if (left > 0 && stride >= minStride) {
+            if (FILE *f = fopen(dump, "ab")) {
+                --left;
+                const int32_t hd[8] = {0x7477626c, P, n, stride, tp.xdrop, tp.flen, tp.marker, 0};
+                fwrite(hd, sizeof hd, 1, f);
+                const float gp[4] = {tp.gap_open, tp.gap_extend, tp.gap_char, 0.f};
+                fwrite(gp, sizeof gp, 1, f);
+                fwrite(tp.matrix, sizeof(float), (size_t)(P - 1) * (P - 1), f);
+                fwrite(len.data(), sizeof(int32_t), len.size(), f);
+                fwrite(num.data(), sizeof(int32_t), num.size(), f);
+                fwrite(g_stage.freq + (size_t)first * 2 * sl * P, sizeof(float), (size_t)n * 2 * sl * P, f);
+                fwrite(g_stage.gop + (size_t)first * 2 * sl, sizeof(float), (size_t)n * 2 * sl, f);
+                fwrite(g_stage.gex + (size_t)first * 2 * sl, sizeof(float), (size_t)n * 2 * sl, f);
+                fclose(f);
+            }
+        }
+    }
+#endif
     const double tCall = nowMs();
     ctx.totals.stage_ms += tCall - tStage;
     int rc = twl_align_batch(&tp, n, stride, g_stage.freq + (size_t)first * 2 * sl * P, g_stage.gop + (size_t)first * 2 * sl,

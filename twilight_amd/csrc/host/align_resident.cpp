@@ -7,8 +7,11 @@
 // Differences from the host-staged kernel that do not change the result:
 //  * groups of > 1000 sequences are not compressed into one negative id (alignment-helper.cpp:479-500): that device only saves the
 //    reference per-level row rewriting, which here is a sub-millisecond kernel; every row is simply kept up to date.
-//  * the pass covers currentTask == 0; before the deferred pass (currentTask 1) rows and cached profiles are brought back to the
-//    host and alignmentKernel_GPU takes over.
+//  * the deferred pass (currentTask 1, /root/reference/src/progressive.cpp:270-298) runs here too since round 4: the rows and the cached
+//    profiles of the root and of the deferred nodes stay in HBM, every pair takes gapCharScore 0 and a failed pair is retried with the
+//    larger X-drop / band limit of /root/reference/src/alignment-cpu.cpp:116-129 (per pair: twl_level_align with a one-pair mask).  Its
+//    profiles cannot be batched: each is aligned to the root the previous one has just been merged into (:283-285).  Rows come back to
+//    the host after it (progressive.cpp of this directory); currentTask 2 and a run whose rows are on the host already take alignmentKernel_GPU.
 //
 // Several devices (phase 2) without any collective: every device holds a replica of the store.  Profile building and the
 // write-back are ~1 % of a level's device time, so EVERY device runs them for ALL pairs of the level (the replicas stay identical by
@@ -186,6 +189,7 @@ void uploadSequences(SequenceDB *database, Option *option)
     }
     if (option->printDetail) std::cerr << "Sequences resident on " << g_stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
     database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
+    database->residentDeferred = true;      // the level kernel that set this up also takes the deferred pass with the rows in HBM
 }
 
 void downloadRows(SequenceDB *database, Tree *T)
@@ -196,7 +200,8 @@ void downloadRows(SequenceDB *database, Tree *T)
 void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database, Option *option, Params &param)
 {
     RunCtx &ctx = ctxOf(database);
-    if (database->currentTask != 0 || g_finished) {      // deferred pass: host-staged kernel
+    const int task = database->currentTask;
+    if ((task != 0 && task != 1) || g_finished) {      // merging sub-alignments, or the rows are on the host already: host-staged kernel
         if (g_store) materialise(T, database, option);
         alignmentKernel_GPU(T, nodes, database, option, param);
         return;
@@ -207,6 +212,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (ctx.shard.world > 1 && g_stores.size() > 1) { std::cerr << "ERROR: several processes with several device replicas each are not supported.\n"; exit(1); }
     LevelRecord rec;
     rec.pairs = (int32_t)nodes.size();
+    rec.task = task;
     const LevelTotals before = ctx.totals;
     const double tPrep = nowMs();
     const int n = (int)nodes.size();
@@ -333,7 +339,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         if (ps[i].refLen == 0) paths[i].assign(ps[i].qryLen, 1);
         if (ps[i].qryLen == 0) paths[i].insert(paths[i].end(), ps[i].refLen, 2);
         if (!paths[i].empty() || ps[i].lowQ_r || ps[i].lowQ_q) continue;
-        const bool zg = (ps[i].refNum > 10000 || ps[i].qryNum > 10000);
+        const bool zg = (task == 1 || ps[i].refNum > 10000 || ps[i].qryNum > 10000);      // alignment-cpu.cpp:88
         if (zg) { maskZero[i] = 1; ++nZero; } else { maskPlain[i] = 1; ++nPlain; }
     }
     // deal the pairs, longest first (cost ~ R + Q after gappy-column removal), to the device replicas of this process or, with several
@@ -369,9 +375,36 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             const int r = twl_level_align(g_stores[d], grp ? &tz : &tp, mask.data(), aln, alnLen.data(), err.data());
             if (r != TWL_OK) return r;
             callMs[d] += nowMs() - tCall;
-            twl_stats st{};
-            if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
-                if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); } if (d == 0) { rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; } }
+            auto addStats = [&]() {
+                twl_stats st{};
+                if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
+                    if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); } if (d == 0) { rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; } }
+                }
+            };
+            addStats();
+            // alignment-cpu.cpp:116-129: in the deferred pass a failed pair is retried, by whoever owns it, with a larger X-drop / band limit until it passes
+            if (task == 1) {
+                for (int i = 0; i < n; ++i) {
+                    if (!mask[i] || err[i] == 0) continue;
+                    twl_params tr = grp ? tz : tp;
+                    const int minLen = std::min(ps[i].lens.first, ps[i].lens.second);
+                    std::vector<uint8_t> one(n, 0);
+                    one[i] = 1;
+                    std::vector<int32_t> len1(n);
+                    std::vector<int16_t> err1(n);
+                    while (err[i] != 0) {
+                        if (err[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
+                        if (err[i] == 2) tr.flen = std::min(static_cast<int32_t>(tr.flen * 1.2) << 1, minLen);
+                        else { tr.xdrop = static_cast<int32_t>(tr.xdrop * 2); tr.flen = std::min(static_cast<int32_t>(tr.xdrop * 4) << 1, minLen); }
+                        if (option->printDetail) std::cout << "Retry pair No. " << i << "\txdrop " << tr.xdrop << " flen " << tr.flen << '\n';
+                        const double tRetry = nowMs();
+                        const int rr = twl_level_align(g_stores[d], &tr, one.data(), aln, len1.data(), err1.data());
+                        if (rr != TWL_OK) return rr;
+                        callMs[d] += nowMs() - tRetry;
+                        addStats();
+                        err[i] = err1[i]; alnLen[i] = len1[i];
+                    }
+                }
             }
             std::vector<int32_t> fetch, fetchLen, restore, restoreLen;
             for (int i = 0; i < n; ++i) {
@@ -380,7 +413,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
                 const int32_t len = (err[i] == 0) ? alnLen[i] : 0;
                 if (!inPlace) paths[i].assign(&aln[(size_t)i * 2 * stride], &aln[(size_t)i * 2 * stride] + len);
                 else if (needsHost[i]) {
-                    const bool lowQ = (ps[i].refNum == 1 || ps[i].qryNum == 1) && (ps[i].lowQ_r || ps[i].lowQ_q);      // (deferred below: its path is dropped)
+                    const bool lowQ = task == 0 && (ps[i].refNum == 1 || ps[i].qryNum == 1) && (ps[i].lowQ_r || ps[i].lowQ_q);      // (deferred below: its path is dropped)
                     if (len > 0 && !lowQ) { restore.push_back(i); restoreLen.push_back(len); } else paths[i].clear();
                 }
                 else if (len > 0) { fromDp[i] = 1; dpLen[i] = len; }
@@ -453,7 +486,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<int> fallbackPairs;
     for (int i = 0; i < n; ++i) {
         if (errs[i] == 0) continue;
-        if (errs[i] == 3) { std::cout << "There might be some bugs in the code!\n"; exit(1); }
+        if (errs[i] == 3 || task != 0) { std::cout << "There might be some bugs in the code!\n"; exit(1); }      // (the deferred pass retried until errorType 0)
         paths[i].clear();                       // currentTask == 0: a failed pair is deferred (alignment-cpu.cpp:108-115)
         fromDp[i] = 0;
         fallbackPairs.push_back(i);
@@ -467,7 +500,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     std::vector<int> onHost;                 // pairs whose final path the host still has to make (none in the in-place mode: their paths are in HBM)
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
-        deferred[i] = ((s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144
+        deferred[i] = (task == 0 && (s.refNum == 1 || s.qryNum == 1) && (s.lowQ_r || s.lowQ_q)) ? 1 : 0;          // :136-144
         if (deferred[i]) { paths[i].clear(); fromDp[i] = 0; }
         if (fromDp[i]) { finalLen[i] = dpLen[i]; continue; }      // no column was removed: the DP path is the final path, and it is in HBM
         if (!paths[i].empty()) onHost.push_back(i);

@@ -204,8 +204,10 @@ void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, 
         T->root->alnWeight = last->alnWeight;
         last->seqsIncluded.clear();
         last->msaFreq.clear();
-        // device-resident mode: the rows come back now, unless nothing on the host needs them yet (no deferred pass, library caller)
-        if (database->afterMainPass && !(database->lazyRows && database->fallback_nodes.empty())) { database->afterMainPass(T); database->afterMainPass = nullptr; }
+        // device-resident mode: the rows come back now, unless nothing on the host needs them yet (library caller without a deferred pass) or the
+        // deferred pass runs on the resident rows as well (then they come back after it, below)
+        const bool stayResident = database->fallback_nodes.empty() ? database->lazyRows : database->residentDeferred;
+        if (database->afterMainPass && !stayResident) { database->afterMainPass(T); database->afterMainPass = nullptr; }
     }
     if (database->fallback_nodes.empty()) updateAlignment(T->root, database);
     if (option->printDetail) std::cerr << "After the last level: " << std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - tLoop).count() << " ms\n";
@@ -226,6 +228,7 @@ void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, 
     std::cerr << "Realign profiles that have been deferred. Total profiles/sequences: " << database->fallback_nodes.size() << " / " << deferredSeqs << '\n';
     database->fallback_nodes.clear();
     progressiveAlignment(T, database, option, levels, param, deferredKernel);
+    if (database->afterMainPass && !database->lazyRows) { database->afterMainPass(T); database->afterMainPass = nullptr; }
     updateAlignment(T->root, database);
     database->currentTask = 0;
 }

@@ -169,6 +169,7 @@ struct SequenceDB {
     void *gpuCtx = nullptr;                        // per-run state of the GPU level kernels (progressive::gpu::RunCtx), freed through gpuCtxFree
     void (*gpuCtxFree)(void *) = nullptr;
     std::function<void(Tree *)> afterMainPass;    // set by the device-resident level kernel: bring rows/caches back to the host
+    bool residentDeferred = false;                 // ... and that kernel runs the deferred pass on the resident rows too: they come back after it
     bool lazyRows = false;                         // library use (twl_msa.h): leave the rows in HBM after the main pass until somebody needs them
     void addSequence(int id, const std::string &name, std::string &seq, int subtreeIdx, float weight, bool debug);
     bool debug();      // --check: true when every aligned row reproduces its input sequence and all rows are equally long

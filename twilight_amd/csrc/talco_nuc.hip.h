@@ -181,6 +181,10 @@ __device__ __forceinline__ unsigned score_key(float f)
 //                  the straight line between the corners, stopped right after its own marker (placed mt_marg diagonals behind the boundary
 //                  range), traced back from the better of the best cells of its two marker diagonals; writes where its path crosses the
 //                  anti-diagonals [(marker-1)*t - 1, marker*t + 1] into mt_spath
+//   MT 4  pair scout  one workgroup per pair (wide re-runs, round 4): the DP from (0, 0) to the last anti-diagonal with every traceback word kept, no
+//                  marker and no convergence test; its path from the end cell gives mt_spath for ALL anti-diagonals.  For pairs whose tiles do not
+//                  converge (diffuse profiles: every tile runs to the end of the pair and its successor starts where the path from the END cell
+//                  crosses the marker diagonal) a local scout cannot know that path; the suffix of the pair's global path does
 //   (mt_chain_kernel: walks mt_spath from (0, 0): start of tile t = the path cell on diagonal s + marker, or on s + marker - 1 when the
 //                  path steps over that diagonal -- the reference's state 3, :520-524)
 //   MT 1  tiles    one workgroup per (pair, tile): the tile from the predicted start, result + path segment into mt_rec / mt_seg
@@ -191,7 +195,7 @@ __device__ __forceinline__ unsigned score_key(float f)
 // matching record (mt_front), the next chain launch re-derives the pair's remaining starts from that TRUE cell, the next tile launch runs
 // the tiles whose record does not match the new prediction; the last stitch launch computes whatever is still missing in line.
 // Results are those of the plain loop by construction; predictions only decide how much of it is already done.
-constexpr int kMtRec = 12;     // {1 = valid, start ref, start qry, next ref, next qry, last_tile, segment bytes, tail dir, tail len, band cells, -, -}
+constexpr int kMtRec = 12;     // {1 = valid / 2 = the job failed, start ref, start qry, next ref, next qry, last_tile, segment bytes, tail dir, tail len, band cells, error code of a failed job, -}
 
 // start cells of all tiles of a pair from the scouts' path samples (one thread per pair)
 __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_t *len, const int32_t *items, int n_items, int32_t *chain, int slots,
@@ -255,6 +259,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     // sums of two rows are one packed instruction each with every operand in an aligned register pair: NQP pairs (+ row 4 in mode 0)
     constexpr int NQP = (MM == 2 || MM == 1) ? 8 : (MM == 0 ? 10 : (MM == 5 ? 2 : 1));
     constexpr int NQM = (MM == 0) ? 5 : 1;
+    // Geometries of three or more blocks per wave (the wide windows) do not keep the first products per row: sixteen registers per block put
+    // the 16-wave x 3-block kernel 60 registers over its budget of 128 (212-244 B of scratch per lane, reloaded on the diagonal's critical
+    // path: 2.6-3.8 us per diagonal of a 2300-row band).  They form q[m]*M[l][m] again in every cell -- the same first rounding (:386), eight packed multiplies more.
+    constexpr bool QPRE = !(RPL >= 3 && MM == 2);
     constexpr int F4 = (P + 2) / 4;                       // float4 per packed column: 2 or 6
     constexpr bool SPARSE = (MM == 3), PRESIM = (MM == 4);
     constexpr int RP = PRESIM ? 1 : F4;                  // ring planes: presim keeps only {X letter, gap, gapOpen, gapExtend}
@@ -310,7 +318,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         // MT 2 (scout of tile boundary `slot`): the anti-diagonals it reports and its own marker behind them
         const int spLo = (a.marker - 1) * slot - 1, spHi = a.marker * slot + 1;
         const int scoutD0 = max(spLo - a.mt_lead, 0);
-        const int marker = (MT == 2) ? min(spHi + a.mt_marg - scoutD0, kMaxMarker) : a.marker;
+        // MT 4 (the scout of a whole pair): no marker at all -- phase A to the last anti-diagonal, every traceback word kept
+        const int marker = (MT == 2) ? min(spHi + a.mt_marg - scoutD0, kMaxMarker) : ((MT == 4) ? R + Q + 8 : a.marker);
         const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
         const bool denomOne = (denom == 1.0f);
         const float rden = refined_rcp(denom);
@@ -347,6 +356,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 if (ref_idx > R - 1) { ref_idx = R - 1; qry_idx = scoutD0 - ref_idx; }
                 if (qry_idx > Q - 1 || ref_idx < 0) last_tile = true;
             }
+        }
+        if constexpr (MT == 4) {          // the row tags hold k + 1 in 16 bits; every group of 8 diagonals needs its traceback words
+            if (R < 2 || Q < 2 || R + Q > 65000 || (size_t)(((R + Q) >> 3) + 2) * (size_t)WINDOW > (size_t)a.tb_words) last_tile = true;
         }
         const int jobRef = ref_idx, jobQry = qry_idx;
         int mtHits = 0, mtInline = 0;
@@ -426,6 +438,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     const int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + tile) * kMtRec;
                     const int rcValid = __builtin_amdgcn_readfirstlane(rc[0]), rcRef = __builtin_amdgcn_readfirstlane(rc[1]), rcQry = __builtin_amdgcn_readfirstlane(rc[2]);
                     memoHit = (rcValid == 1 && rcRef == ref_idx && rcQry == qry_idx);
+                    // ... or the tile job FAILED from this very start (its band outgrew the window, X-drop emptied it, ...): computing it in line
+                    // again would end the same way some thousand diagonals later -- the pair takes the job's verdict
+                    if (rcValid == 2 && rcRef == ref_idx && rcQry == qry_idx) { err = __builtin_amdgcn_readfirstlane(rc[10]); if (err == 0) err = 3; }
                     if (memoHit) {
                         const int cnt = __builtin_amdgcn_readfirstlane(rc[6]), tailDir = __builtin_amdgcn_readfirstlane(rc[7]), tailLen = __builtin_amdgcn_readfirstlane(rc[8]);
                         if (pos + cnt + tailLen > 2 * a.seq_len) err = 3;
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
             int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
             float qv[RPL][QN], gopq[RPL], gexq[RPL], qM[RPL][NQM];
-            nuc_f2 qP[RPL][NQP];           // qP[2*m + h] = {q[m]*M[2h][m], q[m]*M[2h+1][m]}
+            nuc_f2 qP[QPRE ? RPL : 1][NQP];           // qP[2*m + h] = {q[m]*M[2h][m], q[m]*M[2h+1][m]}
             float simNext[RPL];            // presim: the score of this row on the NEXT diagonal, loaded one diagonal ahead
             int simFor[RPL];               // ... and the diagonal it belongs to
             const int simK0 = ref_idx + qry_idx;   // global anti-diagonal of the tile's first cell
@@ -486,7 +501,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     for (int t = 0; t < P; ++t) qv[r][t] = cb[t];
                     gopq[r] = cb[P]; gexq[r] = cb[P + 1];
                     // first rounding of (q[m]*M[l][m])*r[l], :386
-                    if constexpr (MM == 2) {
+                    if constexpr (MM == 2 && !QPRE) {}
+                    else if constexpr (MM == 2) {
                         const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
@@ -682,9 +698,21 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             // rows {0,1} and {2,3} side by side: t[l][m] = (q[m]*M[l][m]) * r[l]; s_l = ((t0 + t1) + t2) + t3 (+ t4)
                             constexpr int NM = (MM == 0) ? 5 : (MM == 5 ? 1 : 4);
                             const nuc_f2 r01 = nuc_f2{c0.x, c0.y}, r23 = nuc_f2{c0.z, c0.w};
-                            nuc_f2 s01 = qP[r][0] * r01, s23 = qP[r][1] * r23;
+                            nuc_f2 s01, s23;
+                            if constexpr (QPRE) {
+                                s01 = qP[r][0] * r01; s23 = qP[r][1] * r23;
 #pragma unroll
-                            for (int m = 1; m < NM; ++m) { s01 = s01 + qP[r][2 * m] * r01; s23 = s23 + qP[r][2 * m + 1] * r23; }
+                                for (int m = 1; m < NM; ++m) { s01 = s01 + qP[r][2 * m] * r01; s23 = s23 + qP[r][2 * m + 1] * r23; }
+                            } else {      // the first products of this row formed here (see QPRE): same operations, same order
+                                const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
+                                auto fp = [&](int m, int h) __attribute__((always_inline)) {
+                                    const int l0 = 2 * h, l1 = 2 * h + 1;
+                                    return nuc_f2{qv[r][m] * ((l0 == m) ? mA : (((l0 ^ m) == 2) ? mB : mC)), qv[r][m] * ((l1 == m) ? mA : (((l1 ^ m) == 2) ? mB : mC))};
+                                };
+                                s01 = fp(0, 0) * r01; s23 = fp(0, 1) * r23;
+#pragma unroll
+                                for (int m = 1; m < 4; ++m) { s01 = s01 + fp(m, 0) * r01; s23 = s23 + fp(m, 1) * r23; }
+                            }
                             numer = ((s01.x + s01.y) + s23.x) + s23.y;
                             if constexpr (MM == 0) {
                                 float s4 = qM[r][0] * rc[4];
@@ -1202,7 +1230,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 if (dir == 0) { kk2 -= 2; ii -= 1; qi--; ri--; }
                                 else if (dir == 1) { kk2 -= 1; ii -= 1; qi--; }
                                 else { kk2 -= 1; ri--; }
-                                s_rev[n++] = (int8_t)dir;
+                                if constexpr (MT == 4) {      // the pair's scout keeps no path, only where it crosses every anti-diagonal (tile starts are read off it)
+                                    int32_t *sp = a.mt_spath + (size_t)mtx * (size_t)a.mt_sp_pitch;
+                                    const int dHere = (dir == 0) ? kk2 + 2 : kk2 + 1;      // the diagonal of the cell just left
+                                    sp[dHere] = qi + ((dir != 2) ? 1 : 0);
+                                    if (dir == 0 && dHere >= 1) sp[dHere - 1] = -1;
+                                } else s_rev[n++] = (int8_t)dir;
                                 if (kk2 < 0) { done = true; break; }
                                 if (first && (ri < 0 || qi < 0)) { done = true; break; }
                                 if (ii < 0) { done = true; break; }   // defensive: a pointer chain left the tile (never on valid data)
@@ -1213,7 +1246,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         done = __builtin_amdgcn_readfirstlane((int)done) != 0;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the walk's reads, before the next patch overwrites them
                     }
-                    if (lane == 0 && first) {
+                    if (lane == 0 && first && MT != 4) {
                         while (ri > -1) { s_rev[n++] = 2; ri--; }
                         while (qi > -1) { s_rev[n++] = 1; qi--; }
                     }
@@ -1243,6 +1276,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             if (d >= spLo && d <= dMax) sp[d] = q;
                         }
                     }
+                } else if constexpr (MT == 4) {
                 } else
                 if (pos + cnt + tailLen > 2 * a.seq_len) { err = 3; }
                 else {
@@ -1264,7 +1298,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #endif
             if (err != 0) break;
             tile += SPEC ? 2 : 1;
-            if constexpr (MT == 1 || MT == 2) last_tile = true;      // one tile per job
+            if constexpr (MT == 1 || MT == 2 || MT == 4) last_tile = true;      // one tile per job
             }      // (tile not thrown away)
             }      // (tile started)
         }
@@ -1288,8 +1322,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         }
 #endif
         __syncthreads();
-        if constexpr (MT == 2) {
+        if constexpr (MT == 2 || MT == 4) {
             if (threadIdx.x == 0 && err != 0 && a.mt_stat) atomicAdd(&a.mt_stat[2], 1ull);
+        }
+        if constexpr (MT == 1) {          // a tile job that ended with an error code leaves that as its record (read by the stitch launch)
+            if (threadIdx.x == 0 && err != 0 && jobRef >= 0) {
+                int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + slot) * kMtRec;
+                rc[1] = jobRef; rc[2] = jobQry; rc[10] = err; rc[0] = 2;
+            }
         }
         if constexpr (MT == 3) {
             if (threadIdx.x == 0 && !mtSkip) {
@@ -1301,7 +1341,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             }
             cells += mtCells0;
         }
-        if (threadIdx.x == 0 && MT != 1 && MT != 2 && !(MT == 3 && (suspended || mtSkip))) {
+        if (threadIdx.x == 0 && MT != 1 && MT != 2 && MT != 4 && !(MT == 3 && (suspended || mtSkip))) {
             if (iEnded || err != 0) {
                 a.err[pair] = (int16_t)err;
                 a.aln_len[pair] = (err == 0) ? pos : 0;

@@ -289,7 +289,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
 constexpr int kMtMaxRounds = 7, kMtCounters = 16;      // 1 + 2 * rounds launches, each with its own work counter (the count is clamped wherever it is set)
 // One launch of a tile-parallel kernel (MT 1 tiles / 2 scouts / 3 stitch) of geometry <W, RPL>; the caller has filled the NArgs.
 template <int P, int W, int RPL, int MM, int MINW, int MT>
-int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *grid_out = nullptr)
+int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *grid_out = nullptr, size_t tb_groups = 0)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};
@@ -298,8 +298,10 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
-    const int grid = std::max(1, std::min(n_items, d->num_cu * cached.load()));
-    const size_t tbw = ((size_t)(a.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
+    int grid = std::max(1, std::min(n_items, d->num_cu * cached.load()));
+    // traceback words of a workgroup: the groups of 8 anti-diagonals up to the marker, or (pair scouts, MT 4) of a whole pair
+    const size_t tbw = (tb_groups ? tb_groups : (size_t)(a.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
+    if (tb_groups) grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)8 << 30) / (tbw * sizeof(uint32_t))));      // (at most 8 GB of them: fewer workgroups take the pairs in turn)
     int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
     a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
@@ -386,7 +388,15 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 8, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TRPL, MM, P, MM);
         else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, %d, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, SR, MM);
     }
-    if (nScout > 0) {
+    if (WIDE) {
+        // pairs that outgrew the fast window are, more often than not, pairs whose tiles converge late or never (diffuse profiles): a tile then runs
+        // to the end of the pair and the next one starts where the path from the END cell crosses the marker diagonal -- nothing a scout that
+        // starts 320 diagonals ahead can know.  One workgroup per pair runs the whole DP once with every traceback word kept (MT 4) and leaves the
+        // global path's crossing of every anti-diagonal; its suffixes are what the tiles' own paths follow.
+        int maxRQ = 0;
+        for (int t = 0; t < n_run; ++t) maxRQ = std::max(maxRQ, h_len[2 * order[t]] + h_len[2 * order[t] + 1]);
+        if constexpr (P == 6) { if ((rc = launch_mt_kernel<P, SW, SR, MM, 1, 4>(d, st, a, n_run, nullptr, (size_t)(maxRQ >> 3) + 2))) return rc; }
+    } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
         rc = thrS ? launch_mt_kernel<P, 8, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
