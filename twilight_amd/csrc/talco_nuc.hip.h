@@ -440,7 +440,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     memoHit = (rcValid == 1 && rcRef == ref_idx && rcQry == qry_idx);
                     // ... or the tile job FAILED from this very start (its band outgrew the window, X-drop emptied it, ...): computing it in line
                     // again would end the same way some thousand diagonals later -- the pair takes the job's verdict
-                    if (rcValid == 2 && rcRef == ref_idx && rcQry == qry_idx) { err = __builtin_amdgcn_readfirstlane(rc[10]); if (err == 0) err = 3; }
+                    if (rcValid == 2 && rcRef == ref_idx && rcQry == qry_idx) {
+                        err = __builtin_amdgcn_readfirstlane(rc[10]); if (err == 0) err = 3;
+                        cells += (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rc[9]);      // (the band cells of the failed tile count, as they do in line)
+                    }
                     if (memoHit) {
                         const int cnt = __builtin_amdgcn_readfirstlane(rc[6]), tailDir = __builtin_amdgcn_readfirstlane(rc[7]), tailLen = __builtin_amdgcn_readfirstlane(rc[8]);
                         if (pos + cnt + tailLen > 2 * a.seq_len) err = 3;
@@ -1328,7 +1331,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         if constexpr (MT == 1) {          // a tile job that ended with an error code leaves that as its record (read by the stitch launch)
             if (threadIdx.x == 0 && err != 0 && jobRef >= 0) {
                 int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + slot) * kMtRec;
-                rc[1] = jobRef; rc[2] = jobQry; rc[10] = err; rc[0] = 2;
+                rc[1] = jobRef; rc[2] = jobQry; rc[9] = (int32_t)(unsigned)cells; rc[10] = err; rc[0] = 2;
             }
         }
         if constexpr (MT == 3) {
