@@ -36,7 +36,7 @@ def _compare(twl, batch, **pk):
     assert np.array_equal(n, on), f"path length differs: gpu {n.tolist()} oracle {on.tolist()}"
     for i in range(batch.n_pairs):
         assert np.array_equal(aln[i, : n[i]], oa[i, : on[i]]), f"pair {i}: path differs"
-    if np.all(oerr == 0):
+    if np.all(oerr == 0) or st.n_relaunched == 0:      # (band cells of failed pairs count as well; only attempts in a window that was outgrown do not)
         assert st.band_cells == ost.cells, f"band cells gpu {st.band_cells} oracle {ost.cells}"
     return st, ost
 

@@ -460,10 +460,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         }
                     }
                 }
+                if (err != 0) break;                                            // (a failed record: the pair ends here, in whichever round)
                 if (!memoHit && !a.mt_inline) { suspended = true; break; }      // not the last round: the next one predicts again from here
                 if (!memoHit) mtInline += 1;
             }
-            if constexpr (MT == 3) { if (err != 0) break; }
             if (!(SPEC && teamExit) && !memoHit) {
             const int refLen = R - ref_idx, qLen = Q - qry_idx;
             const int fLen = min(a.flen, min(refLen, qLen));                          // :258
