@@ -195,7 +195,7 @@ __device__ __forceinline__ unsigned score_key(float f)
 // matching record (mt_front), the next chain launch re-derives the pair's remaining starts from that TRUE cell, the next tile launch runs
 // the tiles whose record does not match the new prediction; the last stitch launch computes whatever is still missing in line.
 // Results are those of the plain loop by construction; predictions only decide how much of it is already done.
-constexpr int kMtRec = 12;     // {1 = valid / 2 = the job failed, start ref, start qry, next ref, next qry, last_tile, segment bytes, tail dir, tail len, band cells, error code of a failed job, -}
+constexpr int kMtRec = 12;     // {1 = valid / 2 = the job failed, start ref, start qry, next ref, next qry, last_tile, segment bytes, tail dir, tail len, band cells, error code of a failed job, its window rows}
 
 // start cells of all tiles of a pair from the scouts' path samples (one thread per pair)
 __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_t *len, const int32_t *items, int n_items, int32_t *chain, int slots,
@@ -440,7 +440,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     memoHit = (rcValid == 1 && rcRef == ref_idx && rcQry == qry_idx);
                     // ... or the tile job FAILED from this very start (its band outgrew the window, X-drop emptied it, ...): computing it in line
                     // again would end the same way some thousand diagonals later -- the pair takes the job's verdict
-                    if (rcValid == 2 && rcRef == ref_idx && rcQry == qry_idx) {
+                    // (a band that outgrew the job's window says nothing when this launch has a wider one: protein tiles on 8 waves x 1 block)
+                    if (rcValid == 2 && rcRef == ref_idx && rcQry == qry_idx && !(__builtin_amdgcn_readfirstlane(rc[10]) == kErrOverflow && __builtin_amdgcn_readfirstlane(rc[11]) < WINDOW)) {
                         err = __builtin_amdgcn_readfirstlane(rc[10]); if (err == 0) err = 3;
                         cells += (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rc[9]);      // (the band cells of the failed tile count, as they do in line)
                     }
@@ -1331,7 +1332,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         if constexpr (MT == 1) {          // a tile job that ended with an error code leaves that as its record (read by the stitch launch)
             if (threadIdx.x == 0 && err != 0 && jobRef >= 0) {
                 int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + slot) * kMtRec;
-                rc[1] = jobRef; rc[2] = jobQry; rc[9] = (int32_t)(unsigned)cells; rc[10] = err; rc[0] = 2;
+                rc[1] = jobRef; rc[2] = jobQry; rc[9] = (int32_t)(unsigned)cells; rc[10] = err; rc[11] = WINDOW; rc[0] = 2;
             }
         }
         if constexpr (MT == 3) {
