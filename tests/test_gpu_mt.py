@@ -160,6 +160,24 @@ def test_wide_band_rerun_with_spoiled_predictions_and_one_round(knobs):
     assert st.n_relaunched > 0 and st.mt_tiles_inline >= 1
 
 
+def test_a_streak_of_wide_pairs_starts_on_the_wide_window(knobs):
+    """The deferred pass aligns one pair per level against the same growing root: when the pairs of consecutive small calls all outgrew the fast
+    window the next call does not try it first (every 8th does).  Same results either way."""
+    batch = synth.make_level_batch(1, 5000, members=((1, 6), (1, 6)), seed=102, sub=0.12, indel=0.01)
+    narrow = synth.make_level_batch(1, 5000, members=((1, 6), (1, 6)), seed=31)
+    _compare(knobs, narrow)                        # (whatever earlier tests left behind: a small call that fits the fast window ends a streak)
+    relaunched = []
+    for _ in range(10):
+        st, ost = _compare(knobs, batch, xdrop=14000)
+        relaunched.append(int(st.n_relaunched))
+    assert relaunched[:2] == [1, 1] and relaunched[2:7] == [0] * 5 and relaunched[7] == 1 and relaunched[8:] == [0, 0], relaunched
+    st, ost = _compare(knobs, narrow)              # a pair that fits the fast window, through the wide one: still the same answer ...
+    assert st.n_relaunched == 0
+    st, ost = _compare(knobs, narrow)
+    st, ost = _compare(knobs, batch, xdrop=14000)  # ... and the streak is over once the probe call (every 8th) finds the fast window wide enough
+    assert st.n_relaunched in (0, 1)
+
+
 def test_band_wider_than_the_3072_row_window_moves_on_to_the_widest_kernel(knobs):
     """... and a band that outgrows that one too ends on the 4608-row kernel, as before."""
     batch = synth.make_level_batch(2, 5000, members=((1, 4), (1, 4)), seed=103, sub=0.2, indel=0.01)

@@ -116,6 +116,7 @@ struct Device {
     std::vector<int32_t> mt_jobs_host;
     std::vector<int16_t> last_err;                                               // error codes of the last run_device call, as read back by it
     int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
+    int wide_streak = 0;                                                         // consecutive small calls whose pairs all outgrew the fast window (run_device: wideFirst)
     int mt_launch = 0;                                                           // launches of the tile-parallel level in flight (work counter index)
     char kname[160] = {0};                                                       // the kernel of the first DP launch of the call in flight
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
@@ -506,7 +507,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
-    bool ranMt = false, leanMid = false;
+    bool ranMt = false, leanMid = false, startedWide = false;
     const bool force_wide = dev_env("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = dev_env("TWL_FAST_CFG");      // pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
@@ -639,12 +640,19 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const double roundsThr = (double)n_run / (2.0 * d->num_cu);
         const bool mtOk = lean && mm == 2 && !mm5 && !d->dump_on && n_run <= g_mt_max_pairs && p->marker >= g_mt_min_marker &&
                           sumLen >= 3ll * p->marker * n_run && (2 * n_run <= d->num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
+        const bool wideFirst = g_mt_wide && n_run <= 8 && d->wide_streak >= 2 && (d->wide_streak & 7) != 7;
         if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
             if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_run, &grid, &window);
+        }
+        else if (mtOk && wideFirst) {
+            // the last calls' pairs all outgrew the fast window (the deferred pass: one pair per level against the same growing root): no point in
+            // finding that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
+            rc = launch_mt<6, 2, 2, true>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            statSpec = 3; ranMt = true; startedWide = true;
         }
         else if (mtOk) {
             // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
@@ -744,7 +752,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         else for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
         if (redo.empty()) break;
         if (force_wide) { g_err = "band wider than the wide window"; return TWL_ERR_UNSUPPORTED; }
-        const bool mid = (stage == 1) && (!prot || protSmall);
+        const bool mid = (stage == 1) && (!prot || protSmall) && !startedWide;      // (a call that started on the 3072-row geometry goes on to the widest kernel)
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
         int grid2 = 0, w2 = 0;
@@ -773,6 +781,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         d->stats.n_relaunched += (int32_t)redo.size();
         if (!mid && !guardRound) { stage = 2; }
     }
+    // how the fast window fared (see wideFirst): every pair of a small call outgrew it / the call started wide -> the streak goes on
+    if (!prot && leanMid && n_run > 0 && n_run <= 8) d->wide_streak = (startedWide || (redoMt && d->stats.n_relaunched >= n_run)) ? d->wide_streak + 1 : 0;
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     if (reran) {
         const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
