@@ -262,7 +262,11 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     // Geometries of three or more blocks per wave (the wide windows) do not keep the first products per row: sixteen registers per block put
     // the 16-wave x 3-block kernel 60 registers over its budget of 128 (212-244 B of scratch per lane, reloaded on the diagonal's critical
     // path: 2.6-3.8 us per diagonal of a 2300-row band).  They form q[m]*M[l][m] again in every cell -- the same first rounding (:386), eight packed multiplies more.
+#if defined(TWL_EXP_QPRE)      // experiment builds: force either form for every geometry
+    constexpr bool QPRE = !(MM == 2) || TWL_EXP_QPRE;
+#else
     constexpr bool QPRE = !(RPL >= 3 && MM == 2);
+#endif
     constexpr int F4 = (P + 2) / 4;                       // float4 per packed column: 2 or 6
     constexpr bool SPARSE = (MM == 3), PRESIM = (MM == 4);
     constexpr int RP = PRESIM ? 1 : F4;                  // ring planes: presim keeps only {X letter, gap, gapOpen, gapExtend}

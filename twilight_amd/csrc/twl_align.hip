@@ -326,7 +326,7 @@ int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a la
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 
-template <int P, int MM, int TRPL, bool WIDE = false>      // TRPL: 64-row blocks per wave of the throughput geometry (nucleotide 2: 1024 rows, protein 1: 512 rows)
+template <int P, int MM, int TRPL, bool WIDE = false, int TW = 8>      // TW x TRPL: waves and 64-row blocks per wave of the throughput geometry (nucleotide 4 x 3: 768 rows, four workgroups per CU; protein 8 x 1: 512 rows, two)
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
               const int32_t *h_len, int *grid_out, int *window_out)
 {
@@ -384,9 +384,9 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.mt_front = (int32_t *)((unsigned long long *)d->mt_stat.p + 4);
     a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
     const bool thr = !WIDE && nTile > g_mt_thr_jobs;
-    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, WIDE ? "16x3 (wide)" : (thr ? "8 waves, 2 per CU" : "16x1"));
+    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, WIDE ? "16x3 (wide)" : (thr ? "throughput geometry" : "16x1"));
     if (!d->kname[0]) {
-        if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 8, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TRPL, MM, P, MM);
+        if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TW, TRPL, MM, P, MM);
         else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, %d, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, SR, MM);
     }
     if (WIDE) {
@@ -400,7 +400,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
-        rc = thrS ? launch_mt_kernel<P, 8, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
+        rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
         if (rc) return rc;
     }
     for (int r = 0; r < rounds; ++r) {
@@ -409,7 +409,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
                            (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
         HIP_TRY(hipGetLastError());
         a.mt_jobs = (const int32_t *)d->mt_jobs.p + 3 * (size_t)nScout;
-        rc = thr ? launch_mt_kernel<P, 8, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
+        rc = thr ? launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
         if (rc) return rc;
         a.mt_jobs = nullptr;
         a.mt_inline = (r == rounds - 1) ? 1 : 0;
@@ -507,7 +507,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
-    bool ranMt = false, leanMid = false, startedWide = false;
+    bool ranMt = false, leanMid = false, startedWide = false, thr768 = false;
     const bool force_wide = dev_env("TWL_FORCE_WIDE") != nullptr;
     const char *cfg = dev_env("TWL_FAST_CFG");      // pick the fast-path geometry (nucleotide only)
     const std::string c = cfg ? cfg : "nuc";
@@ -637,7 +637,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the
         // pairs fill the ONE round of the throughput kernel badly (2 * CUs persistent workgroups) -- tiles spread evenly, at the price of
         // the scouts (~1.2x the work).  Levels of several rounds: see the remainder rule at the throughput launch below.
-        const double roundsThr = (double)n_run / (2.0 * d->num_cu);
+        const double roundsThr = (double)n_run / (((mm == 2 || mm5) ? 4.0 : 2.0) * d->num_cu);
         const bool mtOk = lean && mm == 2 && !mm5 && !d->dump_on && n_run <= g_mt_max_pairs && p->marker >= g_mt_min_marker &&
                           sumLen >= 3ll * p->marker * n_run && (2 * n_run <= d->num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
         const bool wideFirst = g_mt_wide && n_run <= 8 && d->wide_streak >= 2 && (d->wide_streak & 7) != 7;
@@ -651,12 +651,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         else if (mtOk && wideFirst) {
             // the last calls' pairs all outgrew the fast window (the deferred pass: one pair per level against the same growing root): no point in
             // finding that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
-            rc = launch_mt<6, 2, 2, true>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            rc = launch_mt<6, 2, 3, true, 4>(d, st, a, items, order, n_run, h_len, &grid, &window);
             statSpec = 3; ranMt = true; startedWide = true;
         }
         else if (mtOk) {
             // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
-            rc = launch_mt<6, 2, 2>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            rc = launch_mt<6, 2, 3, false, 4>(d, st, a, items, order, n_run, h_len, &grid, &window);
             statSpec = 3; ranMt = true;
         }
         else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || dev_env("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !dev_env("TWL_NO_SPEC") && !dev_env("TWL_NO_SPEC_SHARED")) {
@@ -674,25 +674,35 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_run, &grid, &window);
         } else if (lean) {
-            // Many pairs: 2 * CUs persistent workgroups take them in rounds.  A last round that is badly filled costs a whole round: when
-            // the remainder is small enough its pairs (the shortest ones, the order is longest first) go through the tile-parallel path
-            // instead, where they spread over all CUs (1301 pairs of 10 kbp = 2.54 rounds: 3 rounds 84 ms, 2 rounds + 277 pairs in tiles 76 ms).
-            const int R = 2 * d->num_cu;
+            // Many pairs: persistent workgroups take them in rounds.  Default matrix structure (modes 2 and 5): 4 waves x 3 blocks, a 768-row window,
+            // FOUR workgroups per CU (round 4: the same 16 waves per CU as 8 waves x 2 blocks twice, but four independent anti-diagonal chains per SIMD
+            // instead of two, a barrier of four waves instead of eight, and no first products kept per row -- 2048 pairs of 10 kbp 120 -> 95 ms, a leaf
+            // level 96 -> 66 ms, tools/exp_thr.py); a pair whose band outgrows 640 rows re-runs on 8 waves x 2 blocks (1024 rows) below.
+            // A last round that is badly filled costs a whole round: when the remainder is small enough its pairs (the shortest ones, the order is
+            // longest first) go through the tile-parallel path instead, where they spread over all CUs.
+            const bool four = (mm5 || mm == 2);
+            const int R = (four ? 4 : 2) * d->num_cu;
             int tail = n_run % R;
             long long tailLen = 0;
             for (int32_t t = n_run - tail; t < n_run; ++t) tailLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
-            if (!(n_run > R && tail > 0 && tail * 100 <= g_mt_tail_pct * R && mm == 2 && p->marker >= g_mt_min_marker && tailLen >= 8ll * p->marker * tail)) tail = 0;      // (pairs of 8+ tiles: with fewer the scouts and extra launches cost more than the idle workgroups)
+            if (!(n_run > R && tail > 0 && tail * 100 <= g_mt_tail_pct * R && tail <= g_mt_max_pairs && (mm == 2 || mm5) && p->marker >= g_mt_min_marker && tailLen >= 8ll * p->marker * tail)) tail = 0;      // (pairs of 8+ tiles: with fewer the scouts and extra launches cost more than the idle workgroups)
             const int bulk = n_run - tail;
-            if (mm5) rc = launch_lean<6, 8, 2, 5, 4>(d, st, a, items, bulk, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 8, 2, 2, 4>(d, st, a, items, bulk, &grid, &window);
+#if defined(TWL_EXP_THR_W)      // geometry experiments (tools/exp_thr.py on cross-compiled variants): waves, blocks per wave, waves per SIMD of the throughput launch
+            if (mm5) rc = launch_lean<6, TWL_EXP_THR_W, TWL_EXP_THR_RPL, 5, TWL_EXP_THR_MINW>(d, st, a, items, bulk, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, TWL_EXP_THR_W, TWL_EXP_THR_RPL, 2, TWL_EXP_THR_MINW>(d, st, a, items, bulk, &grid, &window);
+#else
+            if (mm5) rc = launch_lean<6, 4, 3, 5, 4>(d, st, a, items, bulk, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 4, 3, 2, 4>(d, st, a, items, bulk, &grid, &window);
+#endif
             else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, bulk, &grid, &window);
             else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, bulk, &grid, &window);
+            thr768 = four;
             if (!rc && tail > 0) {
                 const std::vector<int32_t> tailOrder(order.begin() + bulk, order.begin() + n_run);
                 int g2 = 0, w2 = 0;
                 // (one-letter query rows: the tiles too take the four-product form of the column score)
-                rc = mm5 ? launch_mt<6, 5, 2>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2)
-                         : launch_mt<6, 2, 2>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
+                rc = mm5 ? launch_mt<6, 5, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2)
+                         : launch_mt<6, 2, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
                 ranMt = true;
             }
         }
@@ -756,7 +766,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
         int grid2 = 0, w2 = 0;
-        if (guardRound) rc = prot ? launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2)
+        const bool from768 = thr768 && !guardRound;      // the throughput launch's 768-row window was outgrown: first the 1024-row one (8 waves x 2 blocks), then the stages below
+        if (from768) {
+            thr768 = false; --stage;
+            rc = (statMode == 5) ? launch_lean<6, 8, 2, 5, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2)
+                                 : launch_lean<6, 8, 2, 2, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        }
+        else if (guardRound) rc = prot ? launch_dp<22, 8, 2, false, true, true, 1, 3>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2)
                                   : launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
         else if (mid && prot) rc = launch_lean<22, 16, 1, 3, 1>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         // nucleotide, default matrix structure: every tile of these pairs at once on a 3072-row window (launch_mt, WIDE) when they have tiles
@@ -765,7 +781,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             long long redoLen = 0;
             for (int32_t n : redo) redoLen += (long long)h_len[2 * n] + h_len[2 * n + 1];
             const bool wideMt = g_mt_wide && (int)redo.size() <= g_mt_max_pairs && p->marker >= g_mt_min_marker && redoLen >= 3ll * p->marker * (long long)redo.size();
-            if (wideMt) { rc = launch_mt<6, 2, 2, true>(d, st, a, (const int32_t *)d->items.p, redo, (int)redo.size(), h_len, &grid2, &w2); redoMt = true; }
+            if (wideMt) { rc = launch_mt<6, 2, 3, true, 4>(d, st, a, (const int32_t *)d->items.p, redo, (int)redo.size(), h_len, &grid2, &w2); redoMt = true; }
             else rc = launch_lean<6, 8, 4, 2, 2>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         }
         else if (mid) rc = launch_dp<6, 16, 2, false, true, true, 1, 0>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), 0, &grid2, &w2);
@@ -779,7 +795,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         ms_redo += ms;
         d->stats.n_launches += 1;
         d->stats.n_relaunched += (int32_t)redo.size();
-        if (!mid && !guardRound) { stage = 2; }
+        if (!mid && !guardRound && !from768) { stage = 2; }
     }
     // how the fast window fared (see wideFirst): every pair of a small call outgrew it / the call started wide -> the streak goes on
     if (!prot && leanMid && n_run > 0 && n_run <= 8) d->wide_streak = (startedWide || (redoMt && d->stats.n_relaunched >= n_run)) ? d->wide_streak + 1 : 0;
