@@ -66,11 +66,11 @@ def test_wrong_predictions_are_repaired(knobs, perturb, rounds):
 
 
 def test_throughput_geometry_for_scouts_and_tiles(knobs):
-    """The 8-wave x 2-block geometry (two workgroups per CU) for the scout and tile launches, forced on a small level."""
+    """The throughput geometry (4 waves x 3 blocks, four workgroups per CU) for the scout and tile launches, forced on a small level."""
     knobs.set_knob(api.KNOB_MT_THR_JOBS, 0)
     batch = synth.make_level_batch(6, 6000, members=((1, 8), (1, 8)), seed=31)
     st, ost = _compare(knobs, batch)
-    assert st.speculative == 3 and b"8, 2" in st.kernel
+    assert st.speculative == 3 and b"<6, 4, 3" in st.kernel
     assert st.mt_tiles_predicted >= 0.8 * ost.tiles
 
 
@@ -207,6 +207,30 @@ def test_wide_band_rerun_in_a_large_level_touches_only_its_own_rows(knobs):
         assert err[i] == oe and n[i] == on and np.array_equal(aln[i, : n[i]], oa[:on]), f"pair {i}"
     assert st.band_cells == 50 * ob[3].cells + ow[3].cells
     assert ow[3].max_width > 960 or st.n_relaunched == 0
+
+
+@pytest.mark.parametrize("onehot", [0, 1])
+def test_throughput_level_pairs_that_outgrow_the_768_row_window(knobs, onehot):
+    """A level of more pairs than CUs runs on 4 waves x 3 blocks (768-row window, bands up to 640 rows); pairs whose band is wider re-run on
+    8 waves x 2 blocks (1024 rows), and on from there.  Pool of 8 pairs (X-drop 9000: bands of ~700-900 rows in most) replicated to 304."""
+    pool = synth.make_level_batch(8, 3000, members=((1, 6), (1, 1) if onehot else (1, 6)), seed=106)
+    idx = np.arange(304) % pool.n_pairs
+    batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    pk = dict(xdrop=9000)
+    p = knobs.make_params(M, **pk)
+    knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, onehot)
+    try:
+        aln, ln, err = knobs.align_batch(p, batch)
+        st = knobs.get_stats(0)
+    finally:
+        knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), pool, threads=8)
+    assert 640 < ost.max_width <= 960, ost.max_width
+    assert b"<6, 4, 3" in st.kernel and st.n_relaunched > 0 and st.matrix_mode == (5 if onehot else 2), (st.kernel, st.n_relaunched, st.matrix_mode)
+    assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx])
+    for i in range(304):
+        assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"
+    assert st.band_cells == ost.cells * 38
 
 
 # ---- protein (P = 22): tile-parallel on the precomputed column scores ----
