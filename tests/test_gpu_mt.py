@@ -182,7 +182,7 @@ def test_band_wider_than_the_3072_row_window_moves_on_to_the_widest_kernel(knobs
     """... and a band that outgrows that one too ends on the 4608-row kernel, as before."""
     batch = synth.make_level_batch(2, 5000, members=((1, 4), (1, 4)), seed=103, sub=0.2, indel=0.01)
     st, ost = _compare(knobs, batch, xdrop=30000)
-    assert ost.max_width > 2944 and st.n_relaunched >= 2 * batch.n_pairs, (ost.max_width, st.n_relaunched)
+    assert ost.max_width > 2944 and st.n_relaunched >= batch.n_pairs, (ost.max_width, st.n_relaunched)      # (twice that unless the call started on the wide window: a streak left by the tests above)
 
 
 def test_wide_band_rerun_in_a_large_level_touches_only_its_own_rows(knobs):
