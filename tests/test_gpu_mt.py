@@ -212,9 +212,9 @@ def test_wide_band_rerun_in_a_large_level_touches_only_its_own_rows(knobs):
 @pytest.mark.parametrize("onehot", [0, 1])
 def test_throughput_level_pairs_that_outgrow_the_768_row_window(knobs, onehot):
     """A level of more pairs than CUs runs on 4 waves x 3 blocks (768-row window, bands up to 640 rows); pairs whose band is wider re-run on
-    8 waves x 2 blocks (1024 rows), and on from there.  Pool of 8 pairs (X-drop 9000: bands of ~700-900 rows in most) replicated to 304."""
+    8 waves x 2 blocks (1024 rows), and on from there.  Pool of 8 pairs (X-drop 9000: bands of ~700-900 rows in most) replicated to 1104."""
     pool = synth.make_level_batch(8, 3000, members=((1, 6), (1, 1) if onehot else (1, 6)), seed=106)
-    idx = np.arange(304) % pool.n_pairs
+    idx = np.arange(1104) % pool.n_pairs      # (more than one round of 4 workgroups on each of 256 CUs: the throughput launch, not the tile-parallel path)
     batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
     pk = dict(xdrop=9000)
     p = knobs.make_params(M, **pk)
@@ -228,9 +228,9 @@ def test_throughput_level_pairs_that_outgrow_the_768_row_window(knobs, onehot):
     assert 640 < ost.max_width <= 960, ost.max_width
     assert b"<6, 4, 3" in st.kernel and st.n_relaunched > 0 and st.matrix_mode == (5 if onehot else 2), (st.kernel, st.n_relaunched, st.matrix_mode)
     assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx])
-    for i in range(304):
+    for i in range(1104):
         assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"
-    assert st.band_cells == ost.cells * 38
+    assert st.band_cells == ost.cells * 138
 
 
 # ---- protein (P = 22): tile-parallel on the precomputed column scores ----
@@ -324,11 +324,11 @@ def test_random_campaign_on_the_tile_parallel_path(knobs):
 
 
 def test_badly_filled_last_round_goes_through_tiles(knobs):
-    """More pairs than persistent workgroups (2 per CU) with a small remainder: the full rounds run on the throughput kernel, the remainder
+    """More pairs than persistent workgroups (4 per CU) with a small remainder: the full rounds run on the throughput kernel, the remainder
     (the shortest pairs) on the tile-parallel path behind it -- one call, two kinds of launches, same results.  12 distinct pairs replicated."""
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    n = 2 * cus + 27
+    n = 4 * cus + 27
     pool = synth.make_level_batch(12, 4400, members=((1, 6), (1, 6)), seed=77)      # 8+ tiles of 1024 anti-diagonals each
     idx = np.arange(n) % pool.n_pairs
     batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
@@ -355,7 +355,7 @@ def test_badly_filled_last_round_of_a_leaf_level(knobs):
     """The same with one-letter query rows (a leaf level): full rounds and tiles both take the four-product form of the column score (matrix mode 5)."""
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    n = 2 * cus + 19
+    n = 4 * cus + 19
     pool = synth.make_level_batch(10, 4400, members=((1, 6), (1, 1)), seed=78)
     idx = np.arange(n) % pool.n_pairs
     batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
