@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
     const float gc = a.gap_char;
+    const bool gcNZ = (gc != 0.0f);
     if constexpr (SPARSE) {
         for (int t = threadIdx.x; t < 21 * 6; t += C::THREADS) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
     }
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 for (int m = 1; m < NM; ++m) { s01 = s01 + qP[r][2 * m] * r01; s23 = s23 + qP[r][2 * m + 1] * r23; }
                             } else {      // the first products of this row formed here (see QPRE): same operations, same order
                                 const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
+                                // (two plain multiplies: as ONE packed multiply -- q[m] in both halves, the matrix entries a scalar pair -- the wide level ran 4 % slower, round 4)
                                 auto fp = [&](int m, int h) __attribute__((always_inline)) {
                                     const int l0 = 2 * h, l1 = 2 * h + 1;
                                     return nuc_f2{qv[r][m] * ((l0 == m) ? mA : (((l0 ^ m) == 2) ? mB : mC)), qv[r][m] * ((l1 == m) ? mA : (((l1 ^ m) == 2) ? mB : mC))};
@@ -728,13 +730,17 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 for (int m = 1; m < 5; ++m) s4 = s4 + qM[r][m] * rc[4];
                                 numer = numer + s4;
                             }
-                            if (q5any[r]) {
+                            // the gap-letter terms, :394-395.  With gapCharScore 0 (the deferred pass, groups of > 10 000 sequences: alignment-cpu.cpp:88)
+                            // every one of them is +-0 and the running sum keeps its value (up to the sign of a zero, which nothing downstream sees)
+                            if (gcNZ) {
+                                if (q5any[r]) {
 #pragma unroll
-                                for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
-                            }
-                            if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
+                                    for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
+                                }
+                                if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
 #pragma unroll
-                                for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
+                                    for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
+                                }
                             }
                         } else if constexpr (SPARSE) {
                             // protein column score, :409-433, over the NON-ZERO letters of the reference column only: a skipped letter has r[l] == 0,
