@@ -48,7 +48,7 @@ CONFIGS = {
     "rnasim1k_band512": dict(kind="level", pairs=320, length=1600, type="n", P=6, bcell=64, flen=512, xdrop=4000,
                              name="RNASim-shaped 1k seqs x 1.6 kbp: the leaf level (320 sibling pairs) as ONE batch, fLen 512 / xdrop 4000 (BASELINE configs[1])"),
 }
-PMC = os.path.join(ROOT, "profiles", "r03", "bench_pmc_summary.json")
+PMC = os.path.join(ROOT, "profiles", "r04", "bench_pmc_summary.json")
 
 
 def parse():
@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-peak", action="store_true", help="skip the single-level peak leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the wall-clock-to-final-MSA leg (product CLI as a child process)")
+    ap.add_argument("--no-survey8d", action="store_true", help="skip the one-pass sub-record on the family of SURVEY.md 8d as written (default configuration only)")
     ap.add_argument("--keep", default="", help="directory for the generated family (kept)")
     ap.add_argument("--workload", default="calibrated", choices=["calibrated", "survey8d"],
                     help="family parameters: calibrated on the reference's RNASim sample (default), or SURVEY.md 8d as written (per-branch substitution U(0.03, 0.10), "
@@ -217,6 +218,45 @@ def wallclock_to_msa(tree, fasta, typ, d):
     os.remove(out)
     return {"value": wall, "unit": "s", "higher_is_better": False, "summary": tail, "msa_md5": md5,
             "note": "twilight-mi355x on the same family files, 1 GPU, time of the whole process (HIP start-up, read FASTA + tree, align, write MSA)"}
+
+
+def survey8d_record(cfg, local_rank, base):
+    """One pass over the family of SURVEY.md 8d exactly as written (per-branch substitution U(0.03, 0.10), indel 0.005/site): the regime in
+    which most pairs outgrow the fast window, tiles stop converging and 96 % of the sequences come back through the deferred pass.  The
+    headline family is calibrated on the reference's RNASim sample; this record keeps the other one in the driver's line."""
+    from twilight_amd import msa
+    c8 = dict(cfg)
+    c8["workload"] = "survey8d"
+    d = os.path.join(base, "s8d")
+    os.makedirs(d, exist_ok=True)
+    t0 = time.perf_counter()
+    tree, fasta = write_family(c8, d)
+    gen = time.perf_counter() - t0
+    m = msa.Msa(["-t", tree, "-i", fasta, "-o", os.path.join(d, "o.aln"), "--type", c8["type"], "--gpu-index", str(local_rank)])
+    m.upload()
+    t0 = time.perf_counter()
+    m.align()
+    dt = time.perf_counter() - t0
+    tot, levels = m.report()
+    out = os.path.join(d, "o.aln")
+    m.write(out)
+    md5 = hashlib.md5(open(out, "rb").read()).hexdigest()
+    m.close()
+    for f in (out, tree, fasta):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    try:
+        os.rmdir(d)
+    except OSError:
+        pass
+    deferred = sum(1 for lv in levels if int(lv.task) == 1)
+    return {"cells_per_s": tot.band_cells / dt, "s_per_pass": dt, "band_cells": int(tot.band_cells), "frac_of_hbm_roofline": tot.band_cells * cfg["bcell"] / dt / 1e9 / HBM_PEAK_GBS,
+            "dp_kernel_ms": tot.kernel_ms, "levels_main_pass": int(tot.n_levels) - deferred, "deferred_profiles": deferred, "pairs_rerun_in_wider_window": int(tot.relaunched),
+            "aln_len": int(tot.aln_len), "msa_md5": md5, "generate_s": gen,
+            "note": "ONE untimed-warm-up-free pass (first touch of every kernel included) over 10 000 x 10 kbp generated with SURVEY.md 8d's parameters, seed 20260501 + 2; the "
+                    "CPU checker's MSA for this family has md5 11284078... (tests/golden/e2e_synthetic_expected.json)"}
 
 
 def main():
@@ -395,30 +435,47 @@ def main():
             out["config"].update(peak)
             kernels, dom = [], None
         traffic = issue = None
+        pmc_ok, pmc_note, pmc_tb_share = None, None, None
         try:
             pmc = json.load(open(PMC))
-            traffic = pmc["hbm_per_pass"]["traffic_bytes"]
-            # what binds this path: instruction issue along the anti-diagonal chain, not HBM; per kernel of the
-            # profiled run: VALU issue slots used (a wave's VALU instruction holds its SIMD for 2 cycles), scalar instructions per cycle
-            # and CU (the scalar unit retires ~1), wave-cycles spent waiting, and the HBM rate the counters saw
-            issue = {"source": "profiles/r03/bench_pmc_summary.json (tools/summarize_pmc.py: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAIT_ANY / SQ_WAVE_CYCLES / "
-                               "FETCH_SIZE / WRITE_SIZE passes and the kernel trace of this command)",
-                     "ceiling": "valu_issue_frac 1.0 = every VALU issue slot of the 1024 SIMDs used; salu_per_cycle_per_cu ~1.0 = scalar unit saturated",
-                     "kernels": [{"kernel": k.replace("void twl::", "").replace("(twl::NArgs)", ""), **{f: round(float(v[f]), 4) for f in
-                                  ("valu_issue_frac", "salu_per_cycle_per_cu", "wait_frac_of_wave_cycles", "active_inst_frac_of_wave_cycles", "hbm_gb_per_s", "seconds_in_run") if f in v}}
-                                 for k, v in sorted(pmc.get("issue_per_kernel", {}).items(), key=lambda kv: -kv[1].get("seconds_in_run", 0.0))]}
-        except Exception:
-            pass
+            lib_hash = (twl.version().split("src ")[-1] if hasattr(twl, "version") else "")
+            pmc_ok = (pmc.get("source_hash") == lib_hash) and args.config == "rnasim10k" and args.workload == "calibrated"
+            if not pmc_ok:
+                pmc_note = (f"counters withheld: profiles/r04/bench_pmc_summary.json was taken on kernel sources {pmc.get('source_hash')} for the default configuration, "
+                            f"this run is {lib_hash} / {args.config} / {args.workload}")
+            else:
+                pmc_note = ("profiles/r04/bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, bytes per pass; "
+                            "FETCH_SIZE doubled per MI355X_MICROARCH.md)")
+                traffic = pmc["hbm_per_pass"]["traffic_bytes"]
+                pmc_tb_share = pmc["hbm_per_pass"]["write_bytes"] / pmc["hbm_per_pass"]["traffic_bytes"]
+                # per kernel of the profiled run: VALU issue slots used (a wave's VALU instruction holds its SIMD-32 for 2 cycles), scalar instructions per
+                # cycle and CU (the scalar unit retires ~1), wave-cycles spent waiting, and the HBM rate the counters saw
+                issue = {"source": "profiles/r04/bench_pmc_summary.json (tools/summarize_pmc.py: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAIT_ANY / SQ_WAVE_CYCLES / "
+                                   "FETCH_SIZE / WRITE_SIZE passes and the kernel trace of this command)",
+                         "ceiling": "valu_issue_frac 1.0 = every VALU issue slot of the 1024 SIMDs used; salu_per_cycle_per_cu ~1.0 = scalar unit saturated",
+                         "kernels": [{"kernel": k.replace("void twl::", "").replace("(twl::NArgs)", ""), **{f: round(float(v[f]), 4) for f in
+                                      ("valu_issue_frac", "salu_per_cycle_per_cu", "wait_frac_of_wave_cycles", "active_inst_frac_of_wave_cycles", "hbm_gb_per_s", "seconds_in_run") if f in v}}
+                                     for k, v in sorted(pmc.get("issue_per_kernel", {}).items(), key=lambda kv: -kv[1].get("seconds_in_run", 0.0))]}
+        except Exception as ex:  # noqa: BLE001
+            pmc_note = f"no counters: {ex}"
+        # compulsory HBM traffic of a pass: every pair reads its two packed profiles once and writes its path once ((R+Q)(4P+8) + (R+Q) bytes)
+        lib_ver = twl.version() if hasattr(twl, "version") else ""
         out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bound": "issue", "contract_bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_live": False,
-            "traffic_source": "profiles/r03/bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per pass; FETCH_SIZE doubled per MI355X_MICROARCH.md)" if traffic else None,
+            "traffic_bytes_per_cell": (traffic / (cells / steps)) if traffic else None,
+            "traffic_frac_of_hbm_peak": (traffic / (kernel_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "traceback_share_of_traffic": pmc_tb_share,
+            "compulsory_bytes_per_cell": 0.07, "compulsory_bytes_frac": (0.07 * (cells / steps) / (kernel_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else None,
+            "traffic_source": pmc_note,
+            "library": lib_ver,
             "issue": issue,
             "algorithmic_bytes_per_cell": bcell, "cells": int(cells // steps), "kernel_ms": kernel_ms / steps,
             "dominant_kernel": dom, "kernels": kernels,
-            "note": "achieved = band cells x algorithmic operand bytes per cell / DP-kernel time over ALL launches of a pass (every level of the family); the operand "
-                    "stream is a notional figure (BASELINE.md section 3): columns are reused from LDS/registers, real HBM traffic is ~1 % of it and the kernel is "
-                    "bound by instruction issue, see DESIGN.md section 3",
+            "note": "what binds this path is instruction issue along the anti-diagonal chain (`issue`: VALU issue slots used, wave-cycles waiting), not HBM: `frac` is the contract "
+                    "figure of BASELINE.md section 3 -- band cells x 64 (192) operand bytes per cell / DP-kernel time over ALL launches of a pass, against 8 TB/s; the operand stream "
+                    "is notional (columns are reused from LDS / registers), so a value above 1 is not a ceiling exceeded.  Real HBM traffic (`traffic`, counters) is ~1.3 B per cell, "
+                    "most of it traceback words written for every window row every 8th anti-diagonal; the compulsory figure is 0.07 B per cell.  DESIGN.md section 3",
         }
         if world == 1 and not args.no_peak and family:
             try:
@@ -435,6 +492,11 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if e2e is not None:
             out["wallclock_to_msa"] = e2e
+        if world == 1 and family and args.config == "rnasim10k" and args.workload == "calibrated" and not args.no_survey8d and not args.leaves and not args.length:
+            try:
+                out["survey8d"] = survey8d_record(cfg, local_rank, base)
+            except Exception as e:  # noqa: BLE001
+                out["survey8d"] = {"note": f"failed: {e}"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if family and not args.keep:

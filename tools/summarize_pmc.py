@@ -69,4 +69,10 @@ if "pass1" in out and dur:
             e["hbm_gb_per_s"] = (2 * p3[name]["sum"].get("FETCH_SIZE", 0.0) + p4[name]["sum"].get("WRITE_SIZE", 0.0)) * 1024 / t / 1e9
         issue[name] = e
     out["issue_per_kernel"] = issue
+try:      # which code these counters belong to: the hash of the kernel sources the profiled library was built from (twl_version carries the same)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as _g
+    out["source_hash"] = _g.source_hash()
+except Exception:
+    out["source_hash"] = None
 print(json.dumps(out, indent=1))

@@ -22,7 +22,8 @@ from .api import (  # noqa: F401
     make_params,
     set_knob,
     shutdown,
+    version,
 )
 from . import api as knobs  # noqa: F401  (KNOB_* constants)
 
-__version__ = "0.1.0"
+__version__ = "0.4.0"

@@ -149,6 +149,11 @@ def set_knob(key: int, value: int):
     _check(load_library().twl_set_knob(C.c_int(key), C.c_int(value)))
 
 
+def version() -> str:
+    """twl_version(): release and the hash of the kernel sources the library was built from (__graft_entry__.source_hash)."""
+    return load_library().twl_version().decode()
+
+
 def get_stats(device=0) -> TwlStats:
     st = TwlStats()
     _check(load_library().twl_get_stats(C.c_int(device), C.byref(st)))

@@ -840,7 +840,10 @@ namespace { extern int g_fail_next_row_allocs; }
 extern "C" {
 
 const char *twl_last_error(void) { return g_err.c_str(); }
-const char *twl_version(void) { return "twilight_amd 0.1 (gfx950)"; }
+#ifndef TWL_SOURCE_HASH
+#define TWL_SOURCE_HASH "unstamped"
+#endif
+const char *twl_version(void) { return "twilight_amd 0.4 (gfx950) src " TWL_SOURCE_HASH; }      // (the hash of the kernel sources: __graft_entry__.source_hash)
 
 int twl_init(const int *device_ids, int n_devices)
 {
