@@ -44,7 +44,7 @@ def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exc
     out = os.path.join(out_dir, f"rank{rank}.aln")
     m = msa.Msa(["-t", tree, "-i", fasta, "-o", out, "--type", typ, "--gpu-index", "0"] + list(flags))
     if device_exchange:
-        # device blocks for every level of the main pass; host blocks for the deferred pass (host-staged level kernel)
+        # device blocks for every level of both passes (the deferred pass runs on the resident rows too); the host callback stays registered for the host-staged kernel
         m.shard(rank, world, tdist.make_exchange(None), exchange_device=tdist.make_device_exchange(torch.device("cuda:0")))
     else:
         m.shard(rank, world, tdist.make_exchange(None))
@@ -60,7 +60,8 @@ def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exc
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("device_exchange", [False, True])
-@pytest.mark.parametrize("name", ["nuc_default", "nuc_r0.7", "nuc_deferrals_cache_compress", "nuc_length_deviation_filter", "prot_cache_and_compress"])
+@pytest.mark.parametrize("name", ["nuc_default", "nuc_r0.7", "nuc_deferrals_cache_compress", "nuc_length_deviation_filter", "prot_cache_and_compress",
+                                  "nuc_10500_leaves_more_than_10000_on_one_side", "nuc_xdrop_failure_retried_in_deferred_pass"])
 def test_two_processes_on_one_gpu_write_the_fixture_msa(built, tmp_path, name, device_exchange):
     import torch.multiprocessing as mp
 

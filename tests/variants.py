@@ -27,6 +27,9 @@ VARIANTS = [
     # with the reference's own thresholds: the host mirror at those branches is checked by the independent replay, not only by itself
     ("nuc_2400_leaves_default_thresholds", dict(leaves=2400, length=600, P=6, seed=31, sub=0.03, indel=0.004), None, [], {}),
     ("prot_2200_leaves_default_thresholds", dict(leaves=2200, length=220, P=22, seed=33, sub=0.03, indel=0.004), None, [], {}),
+    # more than 10 000 sequences on one side of the top pairs (the root splits 10 235 / 265): gapCharScore 0 for those pairs (alignment-cpu.cpp:88) and the
+    # compressed-group bookkeeping (alignment-helper.cpp:479-500) at that size, checked by the independent replay and not only by the self-linked CPU checker
+    ("nuc_10500_leaves_more_than_10000_on_one_side", dict(leaves=10500, length=150, P=6, seed=117, sub=0.03, indel=0.004), None, [], {}),
     ("nuc_xdrop_failure_retried_in_deferred_pass", dict(leaves=8, length=1200, P=6, seed=3, sub=0.03, indel=0.003), (2, 600, 4500), [], {}),
 ]
 
