@@ -333,13 +333,22 @@ def main():
     if family:
         # ---- K + W fresh handles, opened and made resident in HBM before the clock starts ----
         force_shard = bool(os.environ.get("TWL_BENCH_FORCE_SHARD"))      # development: a 1-rank world still goes through the RCCL all-gather
-        exchange = tdist.make_exchange(None if one_gpu else dev) if (world > 1 or force_shard) else None                # host blocks: the deferred pass
-        exchange_dev = tdist.make_device_exchange(dev) if (world > 1 or force_shard) else None      # device blocks: every level of the main pass
+        # the per-level all-gather: the library's own RCCL communicator (one per handle: ncclCommInitRank on ids rank 0 makes and torch.distributed's
+        # store carries); the development switch TWL_BENCH_ONE_GPU (two ranks on one device, which RCCL refuses) keeps the gloo callbacks
+        sharded = world > 1 or force_shard
+        native = sharded and not one_gpu and not os.environ.get("TWL_BENCH_CALLBACK_EXCHANGE")
+        exchange = tdist.make_exchange(None if one_gpu else dev) if (sharded and not native) else None
+        exchange_dev = tdist.make_device_exchange(dev) if (sharded and not native) else None
         handles = []
         t0 = time.perf_counter()
         for i in range(args.warmup + args.steps):
             m = msa.Msa(["-t", tree, "-i", fasta, "-o", os.path.join(base, f"out_r{rank}_{i}.aln"), "--type", cfg["type"], "--gpu-index", str(local_rank)] + (["-v"] if os.environ.get("TWL_BENCH_VERBOSE") else []))
-            if exchange is not None:
+            if native:
+                ids = [msa.rccl_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(ids, src=0)
+                m.shard_rccl(rank, world, ids[0])       # (twl.init above brought the device up; one communicator per process: handles are aligned one after the other)
+            elif exchange is not None:
                 m.shard(rank, world, exchange, exchange_device=exchange_dev)
             m.upload()
             handles.append(m)

@@ -139,6 +139,24 @@ int twl_column_scores(const twl_params *p, int32_t seq_len, const float *freq, c
 int twl_dp_column_scores(const twl_params *p, int32_t seq_len, const float *freq, const float *gap_open, const float *gap_extend,
                          const int32_t *len, const int32_t *num, float *out);
 
+/* ---- RCCL from the library's own C++ (pairs of a level sharded over the GPUs of a node, one process per GPU) ----
+   The collective of a sharded run is ONE all-gather of equal byte blocks per guide-tree level, HBM to HBM over xGMI, on the library's stream of
+   `device`.  librccl is loaded at run time (dlopen "librccl.so.1"; a copy already in the process, e.g. PyTorch's, is reused), so the library
+   has no link-time dependency on it and single-GPU use never touches it.  Replaces the batch dealing of the reference's GPU host code
+   (/root/reference/src/hip/alignment-gpu.hip.cpp:239-254) across processes.
+     twl_comm_unique_id   ncclGetUniqueId: call on ONE rank, hand the 128 bytes to the others by any means (a pipe, a file, a launcher's store)
+     twl_comm_init        ncclCommInitRank for this process's `device` (selected in twl_init); collective: every rank calls it
+     twl_comm_all_gather  d_recv[world][bytes_per_rank] <- every rank's d_send[bytes_per_rank] (device pointers); returns when the blocks are there
+     twl_comm_all_gather_host  the same for host blocks (staged through the library's device buffers)
+     twl_comm_destroy     ncclCommDestroy
+   All return TWL_OK or TWL_ERR_HIP with twl_last_error() set (the RCCL error string). */
+#define TWL_COMM_ID_BYTES 128
+int twl_comm_unique_id(void *id128);
+int twl_comm_init(int device, int rank, int world, const void *id128);
+int twl_comm_all_gather(int device, const void *d_send, void *d_recv, int64_t bytes_per_rank);
+int twl_comm_all_gather_host(int device, const void *send, void *recv, int64_t bytes_per_rank);
+int twl_comm_destroy(int device);
+
 /* Development / test knobs of the launch policy (process-wide; not needed in production).  Returns TWL_ERR_BAD_ARGUMENT for an unknown key.
      TWL_KNOB_MT_PERTURB     n > 0: spoil every n-th predicted tile start of the tile-parallel path, so that its stitch launch has tiles to
                              compute in line (tests of that path); 0 = off (default)

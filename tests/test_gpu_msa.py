@@ -156,6 +156,38 @@ def test_sharded_run_of_world_size_one_sends_device_blocks_through_rccl(built, t
 
 
 @pytest.mark.timeout(600)
+def test_sharded_run_through_the_library_s_own_rccl_communicator(built, tmp_path):
+    """RCCL from the product's own C++ (include/twl_align.h twl_comm_*, include/twl_msa.h twl_msa_shard_rccl): ncclGetUniqueId, ncclCommInitRank and one
+    ncclAllGather per level on the library's stream -- no torch.distributed anywhere in this test.  A 1-rank world (RCCL refuses two ranks on one
+    device) drives the code `twilight-mi355x --gpu-index 0,...,7` and bench.py --gpus 8 drive; a family with deferred pairs, so that the deferred
+    pass goes through the collective too; exchange time is reported per level."""
+    from twilight_amd import msa
+    import twilight_amd as twl
+
+    tmp = str(tmp_path)
+    tree, fasta = _family(tmp, 50, 300, 6, seed=17, sub=0.08, indel=0.03)
+    twl.init([0])
+    uid = msa.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    out = os.path.join(tmp, "sharded.aln")
+    flags = ["--length-deviation", "0.03"]
+    m = msa.Msa(["-t", tree, "-i", fasta, "-o", out] + flags)
+    m.shard_rccl(0, 1, uid)
+    m.upload().align().write()
+    tot, levels = m.report()
+    m.close()
+    assert tot.exchange_ms > 0 and all(lv.exchange_ms > 0 for lv in levels)      # every level, both passes, went through the all-gather
+    assert any(int(lv.task) == 1 for lv in levels)                                # (the deferred pass was there)
+    m2 = msa.Msa(["-t", tree, "-i", fasta, "-o", out + "2"] + flags)             # a second handle of the process shares the communicator
+    m2.shard_rccl(0, 1, uid)
+    m2.upload().align().write()
+    m2.close()
+    ref = os.path.join(tmp, "ref.aln")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "e2e_oracle"), "-t", tree, "-i", fasta, "-o", ref] + flags, capture_output=True, text=True)
+    assert r.returncode == 0 and _md5(out) == _md5(ref) and _md5(out + "2") == _md5(ref)
+
+
+@pytest.mark.timeout(600)
 def test_two_sided_run_too_large_for_the_device_is_restored_on_the_host(built, tmp_path):
     """Two sequences in the two subtrees of the root carry a 150-column insertion at the same place: at the top level both profiles lose
     a 150-column run at the same step, a 151 x 151 alignment that exceeds the per-thread scratch of the device's addGappyColumnsBack

@@ -34,7 +34,8 @@ class TwlStats(C.Structure):
 
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
             "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_dp_column_scores", "twl_host_alloc", "twl_host_free", "twl_set_knob",
-            "twl_copy_to_device", "twl_copy_from_device", "twl_copy_rows_from_device"]
+            "twl_copy_to_device", "twl_copy_from_device", "twl_copy_rows_from_device",
+            "twl_comm_unique_id", "twl_comm_init", "twl_comm_all_gather", "twl_comm_all_gather_host", "twl_comm_destroy"]
 
 
 def exported_symbols():

@@ -81,10 +81,15 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
                    std::vector<int16_t> &errs, LevelRecord &rec)
 {
     const Shard &sh = ctx.shard;
-    if (!sh.exchange) {          // (a 1-rank "world" with an exchange function still goes through it: lets one GPU cover the collective)
+    if (!sh.exchange && !sh.rccl) {          // (a 1-rank "world" with an exchange function still goes through it: lets one GPU cover the collective)
         if (sh.world > 1) { std::cerr << "ERROR: sharded run without an exchange function.\n"; exit(1); }
         return;
     }
+    // the all-gather of host blocks: the caller's callback, or the library's own RCCL communicator (blocks staged through its device buffers)
+    auto gather = [&](const void *send, int64_t bytes, void *recv) -> int {
+        if (sh.rccl) { const int rc = twl_comm_all_gather_host(g_devices[0], send, recv, bytes); if (rc != TWL_OK) std::cerr << "ERROR: " << twl_last_error() << '\n'; return rc; }
+        return sh.exchange(sh.user, send, bytes, recv);
+    };
     static RunCtx::Raw sendStage, recvStage;      // (one run aligns at a time per process)
     constexpr uint64_t kBlockMagic = 0x54574C50ull << 32;      // "TWLP"
     const double t0 = nowMs();
@@ -102,7 +107,7 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
     std::vector<int64_t> sizes((size_t)sh.world, 0);
     {
         const int64_t mineSz = (int64_t)myBytes;
-        const int rc0 = sh.exchange(sh.user, &mineSz, (int64_t)sizeof(int64_t), sizes.data());
+        const int rc0 = gather(&mineSz, (int64_t)sizeof(int64_t), sizes.data());
         if (rc0 != 0) { std::cerr << "ERROR: exchange of the block sizes failed (" << rc0 << ").\n"; exit(1); }
     }
     const size_t blockBytes = (size_t)*std::max_element(sizes.begin(), sizes.end());
@@ -119,7 +124,7 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
             at += rowBytes((size_t)len);
         }
     }
-    const int rc = sh.exchange(sh.user, send, (int64_t)blockBytes, recv);
+    const int rc = gather(send, (int64_t)blockBytes, recv);
     if (rc != 0) { std::cerr << "ERROR: exchange of the level's paths failed (" << rc << ").\n"; exit(1); }
     rec.band_cells = 0; rec.relaunched = 0;
     double kmax = 0;
@@ -188,7 +193,8 @@ void exchangeFinalPaths(RunCtx &ctx, twl_store *store, int device, const twl_par
         if ((rc = twl_copy_to_device(device, send, h.data(), h.size())) != TWL_OK) die("twl_copy_to_device", rc);
         if ((rc = twl_level_paths_to_block(store, (int32_t)prs.size(), prs.data(), lens.data(), where.data(), send, off.data())) != TWL_OK) die("twl_level_paths_to_block", rc);
     }
-    const int xrc = sh.exchangeDev(sh.userDev, send, (int64_t)blockMax, recv);
+    const int xrc = sh.rccl ? twl_comm_all_gather(device, send, recv, (int64_t)blockMax)      // ncclAllGather on the library's stream: HBM to HBM over xGMI
+                            : sh.exchangeDev(sh.userDev, send, (int64_t)blockMax, recv);
     if (xrc != 0) { std::cerr << "ERROR: device exchange of the level's paths failed (" << xrc << ").\n"; exit(1); }
     std::vector<char> hb(hdrMax * (size_t)world);
     if ((rc = twl_copy_rows_from_device(device, hb.data(), hdrMax, recv, blockMax, hdrMax, (uint64_t)world)) != TWL_OK) die("twl_copy_rows_from_device", rc);
@@ -220,6 +226,19 @@ void exchangeFinalPaths(RunCtx &ctx, twl_store *store, int device, const twl_par
 }
 
 const std::vector<int> &selectedDevices() { return g_devices; }
+
+void ensureDevicesUp(Option *option) { ensureInit(option); }
+
+void initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128)
+{
+    ensureInit(option);
+    if (g_devices.size() != 1) { std::cerr << "ERROR: a sharded run takes one device per process.\n"; exit(1); }
+    const int rc = twl_comm_init(g_devices[0], rank, world, id128);
+    if (rc != TWL_OK) { std::cerr << "ERROR: twl_comm_init failed (" << rc << "): " << twl_last_error() << '\n'; exit(1); }
+    Shard sh;
+    sh.rank = rank; sh.world = world; sh.rccl = true;
+    setShard(database, sh);
+}
 
 static std::future<std::pair<int, std::string>> g_initJob;   // (return code, twl_last_error() of the helper thread)
 

@@ -303,8 +303,8 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     const bool procs = ctx.shard.world > 1;
     // ... and so it is with several processes when they can all-gather device blocks (Shard::exchangeDev): each rank restores its own
     // pairs on its device, the final paths travel HBM to HBM (exchangeFinalPaths below), every rank commits all of them from HBM.
-    const bool devX = (nd == 1 && ctx.shard.exchangeDev != nullptr);
-    const bool inPlace = (nd == 1 && ((!procs && !ctx.shard.exchange) || devX));
+    const bool devX = (nd == 1 && (ctx.shard.exchangeDev != nullptr || ctx.shard.rccl));
+    const bool inPlace = (nd == 1 && ((!procs && !ctx.shard.exchange && !ctx.shard.rccl) || devX));
     auto infoOf = [&](const std::vector<int> &which) {      // consensus + removed runs of these pairs, one synchronisation
         uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * which.size() * stride));
         const int rc = twl_level_read_colinfo_many(g_store, (int32_t)which.size(), which.data(), info);

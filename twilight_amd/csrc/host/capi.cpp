@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "../../../include/twl_msa.h"
+#include "../../../include/twl_align.h"
 
 #include "twl_host.hpp"
 
@@ -86,6 +87,23 @@ int twl_msa_shard_device(twl_msa *m, int rank, int world, twl_msa_exchange_fn ex
     msa::progressive::gpu::Shard sh;
     sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user; sh.exchangeDev = exchange_dev; sh.userDev = user_dev;
     msa::progressive::gpu::setShard(m->db, sh);
+    return 0;
+}
+
+int twl_msa_rccl_unique_id(void *id128)
+{
+    const int rc = twl_comm_unique_id(id128);
+    if (rc != TWL_OK) { g_msaErr = twl_last_error(); return -1; }
+    return 0;
+}
+
+int twl_msa_shard_rccl(twl_msa *m, int rank, int world, const void *id128)
+{
+    if (!m || !id128 || world < 1 || rank < 0 || rank >= world) { g_msaErr = "bad argument"; return -2; }
+    if (m->hostStaged) { g_msaErr = "the library's own collective serves the device-resident level kernel"; return -2; }
+    const int rc = twl_msa_shard(m, rank, world, [](void *, const void *, int64_t, void *) { return -1; }, nullptr);      // (validation, thread share; the callback is replaced below)
+    if (rc) return rc;
+    msa::progressive::gpu::initRcclShard(m->db, &m->option, rank, world, id128);
     return 0;
 }
 

@@ -83,7 +83,8 @@ bool parseCommandLine(int argc, char **argv, Option &o)
     return true;
 }
 
-int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput, const std::function<void(SequenceDB *)> &atEnd)
+int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput, const std::function<void(SequenceDB *)> &atEnd,
+                        const std::function<void(SequenceDB *)> &beforeAlign)
 {
     auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = clk();
@@ -95,6 +96,7 @@ int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferred
     const double t1 = clk();
     io::readSequences(option.seqFile, &database, &option, subT);           // :146
     const double t2 = clk();
+    if (beforeAlign) beforeAlign(&database);      // (a sharded run sets its communicator up here: main.cpp)
     progressive::msaOnSubtree(subT, &database, &option, param, kernel, deferredKernel);   // :148
     const double t3 = clk();
     if (option.debug && !database.debug()) std::cerr << "WARNING: --check found an illegal alignment row.\n";

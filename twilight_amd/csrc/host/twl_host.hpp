@@ -262,7 +262,11 @@ struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relau
 using ExchangeFn = int (*)(void *user, const void *send, int64_t bytes_per_rank, void *recv);
 // exchangeDev: the same all-gather on DEVICE buffers (this process's GPU); with it the device-resident level kernel keeps the paths in
 // HBM end to end (align -> gappy columns back -> pack -> all-gather -> unpack -> write-back)
-struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *user = nullptr; ExchangeFn exchangeDev = nullptr; void *userDev = nullptr; };
+struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *user = nullptr; ExchangeFn exchangeDev = nullptr; void *userDev = nullptr;
+               bool rccl = false; };      // rccl: the all-gathers are the library's own (twl_comm_all_gather*, RCCL from C++), no callback
+// Communicator of a sharded run on this process's device (twl_comm_init); the two all-gathers the level kernels use when Shard::rccl is set.
+void initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128);
+void ensureDevicesUp(Option *option);      // joins the twl_init started by beginInit
 // Per-run state of the level kernels; hangs off SequenceDB::gpuCtx so that several runs can live in one process.
 struct RunCtx;
 RunCtx &ctxOf(SequenceDB *database);
@@ -281,7 +285,7 @@ void downloadRows(SequenceDB *database, Tree *T);
 // single partition): tree -> partition -> reroot -> read sequences -> msaOnSubtree -> write MSA.  Returns the MSA length.
 // atEnd (optional) sees the run's SequenceDB after the output was written and before it is destroyed (the CLI reads the run's totals there)
 int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferredKernel, bool writeOutput = true,
-                        const std::function<void(SequenceDB *)> &atEnd = nullptr);
+                        const std::function<void(SequenceDB *)> &atEnd = nullptr, const std::function<void(SequenceDB *)> &beforeAlign = nullptr);
 bool parseCommandLine(int argc, char **argv, Option &option);
 
 }  // namespace msa

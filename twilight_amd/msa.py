@@ -25,8 +25,8 @@ class MsaTotals(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
-_SYMBOLS = ["twl_msa_open", "twl_msa_shard", "twl_msa_shard_device", "twl_msa_upload", "twl_msa_align", "twl_msa_report", "twl_msa_write", "twl_msa_close",
-            "twl_msa_last_error"]
+_SYMBOLS = ["twl_msa_open", "twl_msa_shard", "twl_msa_shard_device", "twl_msa_rccl_unique_id", "twl_msa_shard_rccl", "twl_msa_upload", "twl_msa_align", "twl_msa_report",
+            "twl_msa_write", "twl_msa_close", "twl_msa_last_error"]
 _libs = {}
 
 
@@ -55,6 +55,15 @@ def load_library(path: Optional[str] = None):
         lib.twl_msa_close.argtypes = [C.c_void_p]
         _libs[path] = lib
     return _libs[path]
+
+
+def rccl_unique_id(lib_path: Optional[str] = None) -> bytes:
+    """ncclGetUniqueId through the host library (call on one rank after twl_init, i.e. after a handle was opened and uploaded or api.init ran)."""
+    lib = load_library(lib_path)
+    buf = (C.c_char * 128)()
+    if lib.twl_msa_rccl_unique_id(buf) != 0:
+        raise MsaError(f"twl_msa_rccl_unique_id failed: {lib.twl_msa_last_error().decode()}")
+    return bytes(buf.raw)
 
 
 class Msa:
@@ -97,6 +106,15 @@ class Msa:
         elif world > 1 or exchange is not None:
             self._cb = wrap(exchange)
             self._check(self._lib.twl_msa_shard(self._h, rank, world, self._cb, None), "twl_msa_shard")
+        return self
+
+    def shard_rccl(self, rank: int, world: int, unique_id: bytes):
+        """The same, with the per-level collective made by the library itself (RCCL from its own C++: include/twl_msa.h, twl_msa_shard_rccl):
+        `unique_id` = the 128 bytes `rccl_unique_id()` returned on ONE rank, handed to all of them by the launcher."""
+        if len(unique_id) != 128:
+            raise MsaError("the communicator id has 128 bytes")
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.twl_msa_shard_rccl(self._h, rank, world, buf), "twl_msa_shard_rccl")
         return self
 
     def upload(self):
