@@ -51,6 +51,12 @@ int  twl_store_create(int device, char type, int32_t n_seqs, const char *const *
 void twl_store_destroy(twl_store *s);
 /* Current aligned row of every sequence: rows_out[i] must hold lens_out[i] bytes; call with rows_out == NULL to get the lengths. */
 int  twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out);
+/* The rows of a LIST of sequences, back to back in `out` (row t at the prefix sum of lens_out; out NULL: the lengths only), and the inverse: rows that
+   become the current rows of these sequences.  A sharded run whose ranks aligned their own subtrees alone exchanges them once, where the subtrees
+   meet (twilight_amd/csrc/host/progressive.cpp, ownership).  twl_store_write_cache: a cached profile (float[len][P]) under an id new to this store. */
+int  twl_store_read_rows_of(twl_store *s, int32_t n_ids, const int32_t *ids, char *out, int32_t *lens_out);
+int  twl_store_write_rows(twl_store *s, int32_t n_ids, const int32_t *ids, const char *in, const int32_t *lens);
+int  twl_store_write_cache(twl_store *s, int32_t id, const float *data, int32_t len);
 /* Cached profile `id` as float[len][P]; len_out receives its length; out may be NULL to query the length. */
 int  twl_store_read_cache(twl_store *s, int32_t id, float *out, int32_t *len_out);
 int  twl_store_drop_cache(twl_store *s, int32_t id);

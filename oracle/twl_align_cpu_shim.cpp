@@ -72,5 +72,13 @@ int twl_copy_to_device(int, void *, const void *, uint64_t) { return TWL_ERR_UNS
 int twl_copy_from_device(int, void *, const void *, uint64_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_copy_rows_from_device(int, void *, uint64_t, const void *, uint64_t, uint64_t, uint64_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_set_knob(int, int) { return TWL_ERR_UNSUPPORTED; }
+int twl_store_read_rows_of(twl_store *, int32_t, const int32_t *, char *, int32_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_store_write_rows(twl_store *, int32_t, const int32_t *, const char *, const int32_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_store_write_cache(twl_store *, int32_t, const float *, int32_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_comm_unique_id(void *) { return TWL_ERR_UNSUPPORTED; }
+int twl_comm_init(int, int, int, const void *) { return TWL_ERR_UNSUPPORTED; }
+int twl_comm_all_gather(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_comm_all_gather_host(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_comm_destroy(int) { return TWL_ERR_UNSUPPORTED; }
 
 }  // extern "C"

@@ -6,5 +6,5 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 D=$1; mkdir -p $D
 cp $R/twilight_amd/libtwl_align.so $D/
 cd $R/twilight_amd/csrc/host
-g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -DTWL_DEV -fPIC -shared -o $D/libtwl_host.so phylo.cpp seqdb_io.cpp helpers.cpp progressive.cpp driver.cpp align_gpu.cpp align_resident.cpp capi.cpp $D/libtwl_align.so -Wl,-rpath,'$ORIGIN' -lz
+g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -DTWL_DEV -fPIC -shared -o $D/libtwl_host.so phylo.cpp seqdb_io.cpp helpers.cpp progressive.cpp driver.cpp align_gpu.cpp align_resident.cpp align_owned.cpp capi.cpp $D/libtwl_align.so -Wl,-rpath,'$ORIGIN' -lz
 g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -o $D/twilight-mi355x main.cpp $D/libtwl_host.so $D/libtwl_align.so -Wl,-rpath,'$ORIGIN' -lz

@@ -51,7 +51,13 @@ RunCtx &ctxOf(SequenceDB *database)
     }
     return *static_cast<RunCtx *>(database->gpuCtx);
 }
-void setShard(SequenceDB *database, const Shard &shard) { ctxOf(database).shard = shard; }
+void setShard(SequenceDB *database, const Shard &shard)
+{
+    ctxOf(database).shard = shard;
+    database->ownedPrefix = nullptr;
+    if (shard.world > 1)      // (callers that run the host-staged kernel clear it again: capi.cpp)
+        database->ownedPrefix = [database](Tree *T, std::vector<NodePairVec> &levels, Option *option, Params &param) { return ownedPrefix(T, levels, database, option, param); };
+}
 const std::vector<LevelRecord> &levelRecords(SequenceDB *database) { return ctxOf(database).levels; }
 const LevelTotals &runTotals(SequenceDB *database) { return ctxOf(database).totals; }
 

@@ -76,6 +76,7 @@ int twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange,
     msa::progressive::gpu::Shard sh;
     sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user;
     msa::progressive::gpu::setShard(m->db, sh);
+    if (m->hostStaged) m->db->ownedPrefix = nullptr;      // (subtree ownership is the device-resident kernel's)
     return 0;
 }
 
@@ -87,6 +88,7 @@ int twl_msa_shard_device(twl_msa *m, int rank, int world, twl_msa_exchange_fn ex
     msa::progressive::gpu::Shard sh;
     sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user; sh.exchangeDev = exchange_dev; sh.userDev = user_dev;
     msa::progressive::gpu::setShard(m->db, sh);
+    if (m->hostStaged) m->db->ownedPrefix = nullptr;
     return 0;
 }
 

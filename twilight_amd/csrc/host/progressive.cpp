@@ -146,7 +146,11 @@ void progressiveAlignment(Tree *T, SequenceDB *database, Option *option, std::ve
 {
     int level = 0;
     if (option->printDetail) std::cerr << "Total " << levels.size() << " levels.\n";
+    // a sharded run on the device-resident kernel takes the levels below a cut of the tree by subtree ownership (gpu/align_owned.cpp)
+    size_t done = 0;
+    if (database->ownedPrefix && database->currentTask == 0) done = database->ownedPrefix(T, levels, option, param);
     for (auto m : levels) {                     // serial over levels: tree dependency (progressive.cpp:177)
+        if ((size_t)level < done) { ++level; continue; }
         auto t0 = std::chrono::high_resolution_clock::now();
         updateNode(T, m, database);
         auto t1 = std::chrono::high_resolution_clock::now();

@@ -168,6 +168,8 @@ struct SequenceDB {
     char *rowArena = nullptr;                      // owns the rows of sequences with `borrowed` set
     void *gpuCtx = nullptr;                        // per-run state of the GPU level kernels (progressive::gpu::RunCtx), freed through gpuCtxFree
     void (*gpuCtxFree)(void *) = nullptr;
+    // set for a sharded run on the device-resident level kernel: aligns a prefix of the main pass's levels by subtree ownership (align_owned.cpp), returns how many
+    std::function<size_t(Tree *, std::vector<std::vector<std::pair<Node *, Node *>>> &, Option *, Params &)> ownedPrefix;
     std::function<void(Tree *)> afterMainPass;    // set by the device-resident level kernel: bring rows/caches back to the host
     bool residentDeferred = false;                 // ... and that kernel runs the deferred pass on the resident rows too: they come back after it
     bool lazyRows = false;                         // library use (twl_msa.h): leave the rows in HBM after the main pass until somebody needs them
@@ -267,6 +269,8 @@ struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *use
 // Communicator of a sharded run on this process's device (twl_comm_init); the two all-gathers the level kernels use when Shard::rccl is set.
 void initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128);
 void ensureDevicesUp(Option *option);      // joins the twl_init started by beginInit
+// Subtree ownership of a sharded run (align_owned.cpp): levels [0, returned) of the main pass are done when it returns.
+size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *database, Option *option, Params &param);
 // Per-run state of the level kernels; hangs off SequenceDB::gpuCtx so that several runs can live in one process.
 struct RunCtx;
 RunCtx &ctxOf(SequenceDB *database);

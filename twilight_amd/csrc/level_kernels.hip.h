@@ -455,4 +455,23 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const char *rows0, con
     out[off[s] + c] = (plane[s] ? rows1 : rows0)[(size_t)s * cap + c];
 }
 
+// The same for a list of sequences (ids[t] -> out + off[t]), and its inverse: rows of other ranks' subtrees arriving in this store (twl_store_read_rows_of /
+// twl_store_write_rows: the one exchange of a sharded run whose subtrees were aligned by their owners alone).  grid: (n_ids, n_chunks), 256 threads.
+__global__ void __launch_bounds__(256) gather_rows_of_kernel(const char *rows0, const char *rows1, int64_t cap, const uint8_t *plane, const int32_t *ids,
+                                                             const int32_t *len, const int64_t *off, char *out)
+{
+    const int t = blockIdx.x, s = ids[t];
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= len[t]) return;
+    out[off[t] + c] = (plane[s] ? rows1 : rows0)[(size_t)s * cap + c];
+}
+__global__ void __launch_bounds__(256) scatter_rows_of_kernel(char *rows0, char *rows1, int64_t cap, const uint8_t *plane, const int32_t *ids,
+                                                              const int32_t *len, const int64_t *off, const char *in)
+{
+    const int t = blockIdx.x, s = ids[t];
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= len[t]) return;
+    (plane[s] ? rows1 : rows0)[(size_t)s * cap + c] = in[off[t] + c];
+}
+
 }  // namespace twl

@@ -407,6 +407,93 @@ int twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out)
     return TWL_OK;
 }
 
+// rows of a list of sequences: out = their current rows back to back (row t at the prefix sum of lens_out), lens_out[t] their lengths; out NULL: lengths only
+int twl_store_read_rows_of(twl_store *s, int32_t n_ids, const int32_t *ids, char *out, int32_t *lens_out)
+{
+    if (!s || n_ids < 0 || (n_ids > 0 && (!ids || !lens_out))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    std::vector<int64_t> off((size_t)n_ids);
+    std::vector<int32_t> ln((size_t)n_ids);
+    int64_t total = 0;
+    int32_t maxLen = 1;
+    for (int32_t t = 0; t < n_ids; ++t) {
+        if (ids[t] < 0 || ids[t] >= s->n_seqs) { g_err = "sequence id out of range"; return TWL_ERR_BAD_ARGUMENT; }
+        ln[t] = lens_out[t] = s->len[ids[t]]; off[t] = total; total += ln[t]; maxLen = std::max(maxLen, ln[t]);
+    }
+    if (!out || n_ids == 0 || total == 0) return TWL_OK;
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    int rc;
+    if ((rc = s->d_gather.ensure((size_t)total + (size_t)n_ids * 4 + 64))) return rc;
+    if (s->rows_event) { HIP_TRY(hipStreamWaitEvent(d->stream, s->rows_event, 0)); s->rows_event = nullptr; }
+    if ((rc = upload(s->d_off, off, d->stream))) return rc;
+    if ((rc = upload(s->d_plane, s->plane, d->stream))) return rc;
+    if ((rc = upload(s->d_rowlen, ln, d->stream))) return rc;
+    int32_t *d_ids = reinterpret_cast<int32_t *>((char *)s->d_gather.p + (((size_t)total + 15) & ~(size_t)15));
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(twl::gather_rows_of_kernel, dim3((unsigned)n_ids, (unsigned)((maxLen + 255) / 256)), dim3(256), 0, d->stream,
+                       (const char *)s->rows[0].p, (const char *)s->rows[1].p, s->cap, (const uint8_t *)s->d_plane.p, (const int32_t *)d_ids, (const int32_t *)s->d_rowlen.p,
+                       (const int64_t *)s->d_off.p, (char *)s->d_gather.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, s->d_gather.p, (size_t)total, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return TWL_OK;
+}
+
+// the inverse: rows (back to back in `in`, lengths lens) become the current rows of these sequences
+int twl_store_write_rows(twl_store *s, int32_t n_ids, const int32_t *ids, const char *in, const int32_t *lens)
+{
+    if (!s || n_ids < 0 || (n_ids > 0 && (!ids || !lens || !in))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (n_ids == 0) return TWL_OK;
+    std::vector<int64_t> off((size_t)n_ids);
+    std::vector<int32_t> ln(lens, lens + n_ids);
+    int64_t total = 0;
+    int32_t maxLen = 1;
+    for (int32_t t = 0; t < n_ids; ++t) {
+        if (ids[t] < 0 || ids[t] >= s->n_seqs || lens[t] < 0) { g_err = "sequence id or length out of range"; return TWL_ERR_BAD_ARGUMENT; }
+        off[t] = total; total += lens[t]; maxLen = std::max(maxLen, lens[t]);
+    }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    int rc;
+    if (s->rows_event) { HIP_TRY(hipStreamWaitEvent(d->stream, s->rows_event, 0)); s->rows_event = nullptr; }
+    if ((rc = grow_rows(s, (int64_t)maxLen + 1))) return rc;
+    if ((rc = s->d_gather.ensure((size_t)total + (size_t)n_ids * 4 + 64))) return rc;
+    if ((rc = upload(s->d_off, off, d->stream))) return rc;
+    if ((rc = upload(s->d_plane, s->plane, d->stream))) return rc;
+    if ((rc = upload(s->d_rowlen, ln, d->stream))) return rc;
+    int32_t *d_ids = reinterpret_cast<int32_t *>((char *)s->d_gather.p + (((size_t)total + 15) & ~(size_t)15));
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(s->d_gather.p, in, (size_t)total, hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(twl::scatter_rows_of_kernel, dim3((unsigned)n_ids, (unsigned)((maxLen + 255) / 256)), dim3(256), 0, d->stream,
+                       (char *)s->rows[0].p, (char *)s->rows[1].p, s->cap, (const uint8_t *)s->d_plane.p, (const int32_t *)d_ids, (const int32_t *)s->d_rowlen.p,
+                       (const int64_t *)s->d_off.p, (const char *)s->d_gather.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (int32_t t = 0; t < n_ids; ++t) s->len[ids[t]] = lens[t];
+    return TWL_OK;
+}
+
+// a cached profile arriving from another rank: float[len][P] under a NEW id of this store
+int twl_store_write_cache(twl_store *s, int32_t id, const float *data, int32_t len)
+{
+    if (!s || !data || len < 0 || id < 0) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    if (s->cache.count(id)) { g_err = "cache id in use"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    auto *e = new CacheEntry();
+    const size_t bytes = (size_t)len * s->P * sizeof(float);
+    int rc = cache_buf_get(d, e->buf, std::max<size_t>(bytes, 16));
+    if (rc) { delete e; return rc; }
+    e->len = len;
+    if (bytes) HIP_TRY(hipMemcpyAsync(e->buf.p, data, bytes, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    s->cache[id] = e;
+    return TWL_OK;
+}
+
 int twl_store_read_cache(twl_store *s, int32_t id, float *out, int32_t *len_out)
 {
     if (!s) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
