@@ -54,6 +54,7 @@ def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exc
     m.write()
     m.close()
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([tot.band_cells, tot.pairs, tot.n_levels] + [lv.pairs for lv in levels], dtype=np.int64))
+    np.save(os.path.join(out_dir, f"rank{rank}_x.npy"), np.array([lv.exchange_ms for lv in levels], dtype=np.float64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,3 +76,10 @@ def test_two_processes_on_one_gpu_write_the_fixture_msa(built, tmp_path, name, d
         rep = np.load(os.path.join(d, f"rank{rank}.npy"))
         assert int(rep[0]) == fx["band_cells"], f"rank {rank}: band cells (sum over the ranks of every level)"
         assert list(rep[3:3 + len(fx["pairs_per_level"])]) == fx["pairs_per_level"]
+        # subtree ownership (align_owned.cpp): the levels below the cut are aligned by their owners alone -- no exchange there, ONE where the subtrees meet,
+        # then one per level; both passes of the run
+        x = np.load(os.path.join(d, f"rank{rank}_x.npy"))
+        n_main = len(fx["pairs_per_level"])
+        quiet = [k for k in range(n_main) if x[k] == 0.0]
+        assert quiet == list(range(len(quiet))) and len(quiet) >= 1 and len(quiet) < n_main, (name, x[:n_main].tolist())
+        assert all(v > 0 for v in x[len(quiet):]), (name, x.tolist())
