@@ -81,5 +81,7 @@ def test_two_processes_on_one_gpu_write_the_fixture_msa(built, tmp_path, name, d
         x = np.load(os.path.join(d, f"rank{rank}_x.npy"))
         n_main = len(fx["pairs_per_level"])
         quiet = [k for k in range(n_main) if x[k] == 0.0]
-        assert quiet == list(range(len(quiet))) and len(quiet) >= 1 and len(quiet) < n_main, (name, x[:n_main].tolist())
+        assert quiet == list(range(len(quiet))) and len(quiet) < n_main, (name, x[:n_main].tolist())      # (the level of the cut carries the subtree exchange)
         assert all(v > 0 for v in x[len(quiet):]), (name, x.tolist())
+        if sum(fx["pairs_per_level"]) >= 39:
+            assert len(quiet) >= 1, (name, x[:n_main].tolist())                                           # (8 subtrees per rank fit under a cut above the leaf level)
