@@ -22,12 +22,12 @@ extern "C" {
 
 typedef struct twl_msa twl_msa;
 
-/* Environment variables libtwl_host reads (and the CPU checker with it) -- TEST HOOKS, not options:
-     TWL_TEST_CAL_PROFILE_TH, TWL_TEST_UPDATE_SEQ_TH   the reference's _CAL_PROFILE_TH / _UPDATE_SEQ_TH (msa.hpp:179-180, both 1000): lowered by
-                                tests so that small trees reach the cached-profile and compressed-group branches
-     TWL_TEST_VIRTUAL_DEVICES   n replicas of the store on ONE device: the several-device code path of the resident level kernel on a one-GPU box
-     TWL_OMP_THREADS            host threads of the library (default: what OpenMP picks)
-   TWL_DEBUG traces the launches of libtwl_align on stderr.  Nothing else in the environment changes a result or a launch. */
+/* Development / test switches -- flags of the argv given to twl_msa_open (and of the CLI and the CPU checker, which parse the same way), not options of the product:
+     --test-cal-profile-th n, --test-update-seq-th n   the reference's _CAL_PROFILE_TH / _UPDATE_SEQ_TH (msa.hpp:179-180, both 1000): lowered by tests so
+                                that small trees reach the cached-profile and compressed-group branches
+     --test-virtual-devices n   n replicas of the store on ONE device: the several-replica code path of the resident level kernel on a one-GPU box
+   Environment: TWL_OMP_THREADS (host threads of the library; default: what OpenMP picks) and TWL_DEBUG (traces the launches of libtwl_align on stderr).
+   Nothing in the environment changes a result or a launch. */
 
 /* One level-kernel call (= one line of the reference's per-level report, progressive.cpp:178-189). */
 typedef struct twl_msa_level {

@@ -397,8 +397,8 @@ def main():
     for ign in ("--length-deviation", "--max-ambig", "--max-len", "--min-len", "--type", "--xdrop"):      # already applied in the dump / unused (TALCO ignores --xdrop)
         ap.add_argument(ign, default=None, help="accepted for symmetry with the CLI; the dump already reflects it")
     ap.add_argument("--rooted", action="store_true", help="accepted for symmetry with the CLI")
-    ap.add_argument("--cal-profile-th", type=int, default=int(os.environ.get("TWL_TEST_CAL_PROFILE_TH", "1000")))
-    ap.add_argument("--update-seq-th", type=int, default=int(os.environ.get("TWL_TEST_UPDATE_SEQ_TH", "1000")))
+    ap.add_argument("--cal-profile-th", "--test-cal-profile-th", dest="cal_profile_th", type=int, default=1000)      # (the CLI's development flags, include/twl_msa.h)
+    ap.add_argument("--update-seq-th", "--test-update-seq-th", dest="update_seq_th", type=int, default=1000)
     a = ap.parse_args()
     r = Replay(json.load(open(a.dump)), gappy=a.remove_gappy, wildcard=a.wildcard, match=a.match, mismatch=a.mismatch, transition=a.transition,
                gap_open=a.gap_open, gap_extend=a.gap_extend, blosum=a.blosum, no_filter=not a.filter, cal_profile_th=a.cal_profile_th,

@@ -80,5 +80,6 @@ int twl_comm_init(int, int, int, const void *) { return TWL_ERR_UNSUPPORTED; }
 int twl_comm_all_gather(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_comm_all_gather_host(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_comm_destroy(int) { return TWL_ERR_UNSUPPORTED; }
+int twl_plan_describe(const twl_params *, int32_t, const int32_t *, int32_t, int32_t, int32_t, char *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 
 }  // extern "C"

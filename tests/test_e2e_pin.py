@@ -136,16 +136,14 @@ def test_replicated_resident_path_equals_oracle(built, tmp_path, replicas, kind,
     nwk, seqs = synth.make_family(n, length, P=(6 if kind == "n" else 22), seed=91, sub=0.04, indel=0.004)
     (tmp_path / "t.nwk").write_text(nwk + "\n")
     (tmp_path / "s.fa").write_text("".join(f">{name}\n{seq}\n" for name, seq in seqs))
-    env = dict(os.environ)
     if th:
-        env["TWL_TEST_CAL_PROFILE_TH"] = str(th)
-        env["TWL_TEST_UPDATE_SEQ_TH"] = str(th)
+        flags = flags + ["--test-cal-profile-th", str(th), "--test-update-seq-th", str(th)]
     outs = {}
-    for tag, exe, e in (("oracle", os.path.join(ROOT, "oracle", "e2e_oracle"), env),
-                        ("gpu", os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), dict(env, TWL_TEST_VIRTUAL_DEVICES=str(replicas)))):
+    for tag, exe, extra in (("oracle", os.path.join(ROOT, "oracle", "e2e_oracle"), []),
+                            ("gpu", os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), ["--test-virtual-devices", str(replicas)])):
         out = tmp_path / f"{tag}.aln"
-        r = subprocess.run([exe, "-t", str(tmp_path / "t.nwk"), "-i", str(tmp_path / "s.fa"), "-o", str(out), "--type", kind, "--check", "-v"] + flags,
-                           capture_output=True, text=True, env=e)
+        r = subprocess.run([exe, "-t", str(tmp_path / "t.nwk"), "-i", str(tmp_path / "s.fa"), "-o", str(out), "--type", kind, "--check", "-v"] + flags + extra,
+                           capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = (out, r.stderr)
     assert f"resident on {replicas} device replica(s)" in outs["gpu"][1]

@@ -30,11 +30,9 @@ def _family(tmp, f):
     return t, fa
 
 
-def _run(tree, fasta, out, typ, env=None):
-    e = dict(os.environ)
-    e.update(env or {})
-    r = subprocess.run([os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), "-t", tree, "-i", fasta, "-o", out, "--type", typ, "--check", "-v"],
-                       capture_output=True, text=True, env=e)
+def _run(tree, fasta, out, typ, extra=()):
+    r = subprocess.run([os.path.join(ROOT, "twilight_amd", "twilight-mi355x"), "-t", tree, "-i", fasta, "-o", out, "--type", typ, "--check", "-v"] + list(extra),
+                       capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "illegal alignment" not in r.stderr                      # --check: every row reproduces its input, all rows equally long
     tail = [l for l in r.stderr.splitlines() if l.startswith("Wrote")][-1]
@@ -64,8 +62,8 @@ def test_config4_100k_sequences_one_and_eight_replicas(built, tmp_path):
         pytest.skip("fixture not generated")
     f = EXP["rnasim100k"]
     tree, fasta = _family(str(tmp_path), f)
-    one = _run(tree, fasta, str(tmp_path / "o1.aln"), "n", {"TWL_TEST_VIRTUAL_DEVICES": "1"})
-    eight = _run(tree, fasta, str(tmp_path / "o8.aln"), "n", {"TWL_TEST_VIRTUAL_DEVICES": "8"})
+    one = _run(tree, fasta, str(tmp_path / "o1.aln"), "n", ["--test-virtual-devices", "1"])
+    eight = _run(tree, fasta, str(tmp_path / "o8.aln"), "n", ["--test-virtual-devices", "8"])
     assert one[0] == eight[0] == f["md5"]
     assert one[2] == eight[2] == f["pairs_per_level"]
     assert one[1] == f["band_cells"]          # (virtual replicas share the device's counters; the single-replica run gives the total)

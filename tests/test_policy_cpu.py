@@ -1,0 +1,46 @@
+"""The launch policy of the nucleotide path (twilight_amd/csrc/twl_align.hip: plan_nucleotide, a pure function of a call's facts) through
+twl_plan_describe -- no GPU: which kernel family, matrix mode and window a level of n pairs gets on a 256-CU device."""
+import numpy as np
+import pytest
+
+import twilight_amd as twl
+from twilight_amd import api, synth
+
+M = synth.nucleotide_matrix()
+
+
+def _lens(n, length):
+    return np.full((n, 2), length, dtype=np.int32)
+
+
+@pytest.mark.parametrize("n,length,onehot,expect", [
+    (1, 10000, False, "tile-parallel; mode 2; window 1024"),                       # a lone long pair: every tile at once
+    (128, 10000, False, "tile-parallel; mode 2; window 1024"),                     # up to CUs / 2 pairs: always
+    (200, 10000, False, "tile-parallel; mode 2; window 1024"),                     # a badly filled single round of the throughput kernel
+    (900, 10000, False, "throughput; mode 2; window 768; bulk 900 tail 0"),        # 88 % of one round of 4 x 256 workgroups
+    (1301, 10000, False, "throughput; mode 2; window 768; bulk 1024 tail 277"),    # the remainder through the tile-parallel path
+    (1986, 10000, False, "throughput; mode 2; window 768; bulk 1986 tail 0"),      # 94 % of the second round: stays
+    (3358, 10000, True, "throughput; mode 5; window 768; bulk 3072 tail 286"),     # a leaf level (one-letter query rows)
+    (1301, 1600, False, "throughput; mode 2; window 768; bulk 1301 tail 0"),       # short pairs (3-4 tiles): no tile-parallel remainder
+    (4, 900, False, "speculative teams, 16 waves; mode 2"),                        # too few tiles to spread: two workgroups per pair
+    (200, 900, False, "speculative teams, 8 waves x 2 blocks; mode 2"),
+    (300, 900, False, "throughput; mode 2; window 768; bulk 300 tail 0"),
+])
+def test_plan_of_a_level(built, n, length, onehot, expect):
+    got = api.plan_describe(twl.make_params(M), _lens(n, length), qry_onehot=onehot)
+    assert got.startswith(expect), got
+
+
+def test_plan_depends_on_the_matrix_and_on_the_streak(built):
+    general = M.copy()
+    general[0, 1] = -7.0                                    # no match / transition / transversion structure: mode 1 kernels
+    assert "mode 1" in api.plan_describe(twl.make_params(general), _lens(2000, 5000))
+    wild = synth.nucleotide_matrix()
+    wild[4, :] = wild[:, 4] = 18.0                           # -w: N scores like a match -> the general 5 x 5 mode
+    assert "mode 0" in api.plan_describe(twl.make_params(wild), _lens(2000, 5000))
+    huge = M * 4096.0                                        # outside the hoisted-reciprocal division's range: the IEEE-division kernels
+    assert api.plan_describe(twl.make_params(huge), _lens(10, 5000)).startswith("general (IEEE division)")
+    # a streak of small calls whose pairs all outgrew the fast window starts on the wide one; every 8th call probes the fast window again
+    assert api.plan_describe(twl.make_params(M), _lens(1, 12000), wide_streak=3).startswith("tile-parallel, 3072-row window; mode 2; window 3072")
+    assert api.plan_describe(twl.make_params(M), _lens(1, 12000), wide_streak=7).startswith("tile-parallel; mode 2; window 1024")
+    assert api.plan_describe(twl.make_params(M), _lens(20, 12000), wide_streak=3).startswith("tile-parallel; mode 2; window 1024")

@@ -5,7 +5,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LOW_TH = {"TWL_TEST_CAL_PROFILE_TH": "3", "TWL_TEST_UPDATE_SEQ_TH": "5"}      # small trees reach the cached-profile / compressed-group branches
+LOW_TH = ["--test-cal-profile-th", "3", "--test-update-seq-th", "5"]      # small trees reach the cached-profile / compressed-group branches (development flags, include/twl_msa.h)
 
 VARIANTS = [
     ("nuc_default", dict(leaves=40, length=400, P=6, seed=7, sub=0.08, indel=0.02), None, [], {}),
@@ -19,10 +19,9 @@ VARIANTS = [
     ("prot_blosum45", dict(leaves=24, length=250, P=22, seed=19, sub=0.15, indel=0.02), None, ["-b", "45"], {}),
     ("nuc_length_deviation_deferrals", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, ["--length-deviation", "0.03"], {}),
     ("nuc_length_deviation_filter", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, ["--length-deviation", "0.03", "--filter"], {}),
-    ("nuc_cache_and_compress", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, [], LOW_TH),
-    ("nuc_deferrals_cache_compress", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, ["--length-deviation", "0.05", "-r", "0.8"],
-     {"TWL_TEST_CAL_PROFILE_TH": "2", "TWL_TEST_UPDATE_SEQ_TH": "3"}),
-    ("prot_cache_and_compress", dict(leaves=30, length=200, P=22, seed=9, sub=0.1, indel=0.02), None, [], LOW_TH),
+    ("nuc_cache_and_compress", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, LOW_TH, {}),
+    ("nuc_deferrals_cache_compress", dict(leaves=50, length=300, P=6, seed=17, sub=0.08, indel=0.03), None, ["--length-deviation", "0.05", "-r", "0.8", "--test-cal-profile-th", "2", "--test-update-seq-th", "3"], {}),
+    ("prot_cache_and_compress", dict(leaves=30, length=200, P=22, seed=9, sub=0.1, indel=0.02), None, LOW_TH, {}),
     # families large enough to reach the cached-profile (>= 1000 sequences, msa.hpp:179) and compressed-group (> 1000 members, :180) branches
     # with the reference's own thresholds: the host mirror at those branches is checked by the independent replay, not only by itself
     ("nuc_2400_leaves_default_thresholds", dict(leaves=2400, length=600, P=6, seed=31, sub=0.03, indel=0.004), None, [], {}),

@@ -40,8 +40,7 @@ def one(seed):
     env = dict(os.environ)
     th = int(rng.choice([0, 3, 6, 12]))
     if th:
-        env["TWL_TEST_CAL_PROFILE_TH"] = str(th)
-        env["TWL_TEST_UPDATE_SEQ_TH"] = str(int(rng.choice([th, 2 * th])))
+        flags = flags + ["--test-cal-profile-th", str(th), "--test-update-seq-th", str(int(rng.choice([th, 2 * th])))]
     replicas = int(rng.choice([1, 1, 2, 3]))
     d = tempfile.mkdtemp(prefix="twl_fz_")
     sys.setrecursionlimit(100000)
@@ -51,8 +50,8 @@ def one(seed):
     res = {}
     for tag, exe, extra in (("cpu", CPU, []), ("resident", CLI, []), ("staged", CLI, ["--host-staged"])):
         out = os.path.join(d, tag + ".aln")
-        r = subprocess.run([exe, "-t", os.path.join(d, "t.nwk"), "-i", os.path.join(d, "s.fa"), "-o", out, "--type", kind, "--check"] + flags + extra,
-                           capture_output=True, text=True, env=(dict(env, TWL_TEST_VIRTUAL_DEVICES=str(replicas)) if tag == "resident" else env))
+        r = subprocess.run([exe, "-t", os.path.join(d, "t.nwk"), "-i", os.path.join(d, "s.fa"), "-o", out, "--type", kind, "--check"] + flags + extra +
+                           (["--test-virtual-devices", str(replicas)] if tag == "resident" else []), capture_output=True, text=True, env=env)
         if r.returncode != 0:
             res[tag] = f"rc {r.returncode}: " + (r.stdout + r.stderr)[-300:].replace("\n", " | ")
         else:

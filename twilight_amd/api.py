@@ -35,7 +35,7 @@ class TwlStats(C.Structure):
 _SYMBOLS = ["twl_init", "twl_shutdown", "twl_last_error", "twl_version", "twl_align_batch", "twl_align_batch_device",
             "twl_get_stats", "twl_get_pair_cells", "twl_column_scores", "twl_dp_column_scores", "twl_host_alloc", "twl_host_free", "twl_set_knob",
             "twl_copy_to_device", "twl_copy_from_device", "twl_copy_rows_from_device",
-            "twl_comm_unique_id", "twl_comm_init", "twl_comm_all_gather", "twl_comm_all_gather_host", "twl_comm_destroy"]
+            "twl_comm_unique_id", "twl_comm_init", "twl_comm_all_gather", "twl_comm_all_gather_host", "twl_comm_destroy", "twl_plan_describe"]
 
 
 def exported_symbols():
@@ -141,13 +141,21 @@ def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex
 
 
 KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN, KNOB_MT_ROUNDS, KNOB_MT_THR_JOBS, KNOB_FAIL_ROW_ALLOCS = 1, 2, 3, 4, 5, 6, 7, 8
-KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY, KNOB_MT_TAIL_PCT, KNOB_MT_WIDE = 9, 10, 11, 12
+KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY, KNOB_MT_TAIL_PCT, KNOB_MT_WIDE, KNOB_NO_SPEC = 9, 10, 11, 12, 13
 PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 
 
 def set_knob(key: int, value: int):
     """twl_set_knob: development / test knobs of the launch policy (include/twl_align.h)."""
     _check(load_library().twl_set_knob(C.c_int(key), C.c_int(value)))
+
+
+def plan_describe(params, lens, num_cu=256, qry_onehot=False, wide_streak=0) -> str:
+    """twl_plan_describe: the launch plan of a nucleotide call in words (no device needed)."""
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    buf = C.create_string_buffer(256)
+    _check(load_library().twl_plan_describe(C.byref(params), C.c_int32(lens.shape[0]), _ptr(lens, C.c_int32), C.c_int32(num_cu), C.c_int32(int(qry_onehot)), C.c_int32(wide_streak), buf, C.c_int32(256)))
+    return buf.value.decode()
 
 
 def version() -> str:

@@ -17,7 +17,7 @@
 // write-back are ~1 % of a level's device time, so EVERY device runs them for ALL pairs of the level (the replicas stay identical by
 // construction, cached profiles included); only the DP -- the 99 % -- is sharded: each device aligns its share of the pairs
 // (twl_level_align with a mask, longest-processing-time deal), the paths meet on the host, and every device commits all of them.
-// Per level only paths cross PCIe, nothing crosses xGMI.  TWL_TEST_VIRTUAL_DEVICES=k (tests) runs k replicas on the first device.
+// Per level only paths cross PCIe, nothing crosses xGMI.  --test-virtual-devices k (tests) runs k replicas on the first device.
 #include "align_gpu.hpp"
 
 #include <cstring>
@@ -37,11 +37,7 @@ namespace gpu {
 namespace {
 
 // the per-run state (store replicas, cache ids, totals) lives in RunCtx (align_gpu.hpp), reached through the SequenceDB
-#define g_stores (ctx.stores)
-#define g_storeDev (ctx.storeDev)
-#define g_store (ctx.stores.empty() ? nullptr : ctx.stores[0])
-#define g_finished (ctx.finished)
-#define g_nextCacheId (ctx.nextCacheId)
+inline twl_store *firstStore(RunCtx &ctx) { return ctx.stores.empty() ? nullptr : ctx.stores[0]; }
 
 // Grow-only, never zero-filled staging shared by the runs of a process (one run aligns at a time): a level of 3 000 pairs x 10 kbp
 // moves ~70 MB per array and first-touch page faults cost more than the copies.
@@ -65,14 +61,14 @@ void createStore(RunCtx &ctx, SequenceDB *db, Option *option)
         rows[i] = s->alnStorage[s->storage];
         lens[i] = s->len;
     }
-    g_storeDev = selectedDevices();
-    if (const char *v = getenv("TWL_TEST_VIRTUAL_DEVICES")) g_storeDev.assign(std::max(1, atoi(v)), selectedDevices()[0]);
-    g_stores.assign(g_storeDev.size(), nullptr);
+    ctx.storeDev = selectedDevices();
+    if (option->testVirtualDevices > 0) ctx.storeDev.assign((size_t)option->testVirtualDevices, selectedDevices()[0]);
+    ctx.stores.assign(ctx.storeDev.size(), nullptr);
     std::vector<std::thread> th;
-    std::vector<std::pair<int, std::string>> res(g_storeDev.size(), {TWL_OK, ""});
-    for (size_t d = 0; d < g_storeDev.size(); ++d)
+    std::vector<std::pair<int, std::string>> res(ctx.storeDev.size(), {TWL_OK, ""});
+    for (size_t d = 0; d < ctx.storeDev.size(); ++d)
         th.emplace_back([&, d] {
-            const int rc = twl_store_create(g_storeDev[d], option->type, n, rows.data(), lens.data(), &g_stores[d]);
+            const int rc = twl_store_create(ctx.storeDev[d], option->type, n, rows.data(), lens.data(), &ctx.stores[d]);
             if (rc != TWL_OK) res[d] = {rc, twl_last_error()};
         });
     for (auto &t : th) t.join();
@@ -84,7 +80,7 @@ void createStore(RunCtx &ctx, SequenceDB *db, Option *option)
 template <class F>
 void onAllStores(RunCtx &ctx, const char *what, F fn)
 {
-    const size_t nd = g_stores.size();
+    const size_t nd = ctx.stores.size();
     std::vector<std::pair<int, std::string>> res(nd, {TWL_OK, ""});
     if (nd == 1) { const int rc = fn(0); if (rc != TWL_OK) res[0] = {rc, twl_last_error()}; }
     else {
@@ -102,11 +98,11 @@ void onAllStores(RunCtx &ctx, const char *what, F fn)
 void materialise(Tree *T, SequenceDB *db, Option *option)
 {
     RunCtx &ctx = ctxOf(db);
-    if (!g_store) return;
+    if (!firstStore(ctx)) return;
     const double t0 = nowMs();
     const int n = (int)db->sequences.size();
     std::vector<int32_t> lens(n);
-    int rc = twl_store_read_rows(g_store, nullptr, lens.data());
+    int rc = twl_store_read_rows(firstStore(ctx), nullptr, lens.data());
     if (rc != TWL_OK) die("twl_store_read_rows", rc);
     // One block for all rows, laid out like the device's gathered buffer (row i at the prefix sum of the lengths), so the library
     // copies straight into it; the second half backs the sequences' other buffer (untouched until a later pass writes there).
@@ -127,7 +123,7 @@ void materialise(Tree *T, SequenceDB *db, Option *option)
         rows[i] = s->alnStorage[s->storage];
         at += (size_t)lens[i];
     }
-    rc = twl_store_read_rows(g_store, rows.data(), lens.data());
+    rc = twl_store_read_rows(firstStore(ctx), rows.data(), lens.data());
     if (rc != TWL_OK) die("twl_store_read_rows", rc);
     for (int i = 0; i < n; ++i) db->sequences[i]->len = lens[i];
     const int P = (option->type == 'n') ? 6 : 22;
@@ -136,16 +132,16 @@ void materialise(Tree *T, SequenceDB *db, Option *option)
     for (Node *nd : keep) {
         if (nd->cacheId < 0) continue;
         int32_t len = 0;
-        if ((rc = twl_store_read_cache(g_store, nd->cacheId, nullptr, &len)) != TWL_OK) die("twl_store_read_cache", rc);
+        if ((rc = twl_store_read_cache(firstStore(ctx), nd->cacheId, nullptr, &len)) != TWL_OK) die("twl_store_read_cache", rc);
         std::vector<float> flat((size_t)len * P);
-        if ((rc = twl_store_read_cache(g_store, nd->cacheId, flat.data(), &len)) != TWL_OK) die("twl_store_read_cache", rc);
+        if ((rc = twl_store_read_cache(firstStore(ctx), nd->cacheId, flat.data(), &len)) != TWL_OK) die("twl_store_read_cache", rc);
         nd->msaFreq.assign(len, std::vector<float>(P));
         for (int t = 0; t < len; ++t) std::copy(&flat[(size_t)t * P], &flat[(size_t)t * P] + P, nd->msaFreq[t].begin());
         nd->cacheId = -1;
     }
-    for (twl_store *st : g_stores) twl_store_destroy(st);
-    g_stores.clear();
-    g_finished = true;
+    for (twl_store *st : ctx.stores) twl_store_destroy(st);
+    ctx.stores.clear();
+    ctx.finished = true;
     if (option->printDetail) std::cerr << "Rows back on the host in " << nowMs() - t0 << " ms\n";
 }
 
@@ -175,7 +171,7 @@ void runsAndConsensus(const uint8_t *info, int len, bool removal, const char *le
 void uploadSequences(SequenceDB *database, Option *option)
 {
     RunCtx &ctx = ctxOf(database);
-    if (g_store || g_finished) return;
+    if (firstStore(ctx) || ctx.finished) return;
     ensureInit(option);
     const double t0 = nowMs();
     createStore(ctx, database, option);
@@ -187,7 +183,7 @@ void uploadSequences(SequenceDB *database, Option *option)
         s->borrowed = true;
         s->memLen = 0;
     }
-    if (option->printDetail) std::cerr << "Sequences resident on " << g_stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
+    if (option->printDetail) std::cerr << "Sequences resident on " << ctx.stores.size() << " device replica(s) in " << nowMs() - t0 << " ms\n";
     database->afterMainPass = [database, option](Tree *tree) { materialise(tree, database, option); };
     database->residentDeferred = true;      // the level kernel that set this up also takes the deferred pass with the rows in HBM
 }
@@ -201,15 +197,15 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
 {
     RunCtx &ctx = ctxOf(database);
     const int task = database->currentTask;
-    if ((task != 0 && task != 1) || g_finished) {      // merging sub-alignments, or the rows are on the host already: host-staged kernel
-        if (g_store) materialise(T, database, option);
+    if ((task != 0 && task != 1) || ctx.finished) {      // merging sub-alignments, or the rows are on the host already: host-staged kernel
+        if (firstStore(ctx)) materialise(T, database, option);
         alignmentKernel_GPU(T, nodes, database, option, param);
         return;
     }
     if (option->cpuOnly) { std::cerr << "ERROR: --cpu-only is not available: this build has no CPU alignment path.\n"; exit(1); }
     ensureInit(option);
     uploadSequences(database, option);
-    if (ctx.shard.world > 1 && g_stores.size() > 1) { std::cerr << "ERROR: several processes with several device replicas each are not supported.\n"; exit(1); }
+    if (ctx.shard.world > 1 && ctx.stores.size() > 1) { std::cerr << "ERROR: several processes with several device replicas each are not supported.\n"; exit(1); }
     LevelRecord rec;
     rec.pairs = (int32_t)nodes.size();
     rec.task = task;
@@ -253,7 +249,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         for (int sd = 0; sd < 2; ++sd) {
             twl_side &x = sides[2 * (size_t)i + sd];
             x.member_off = (int32_t)nMembers;
-            if (storeFreq && x.cache_id < 0) x.store_id = nd[sd]->cacheId = g_nextCacheId++;
+            if (storeFreq && x.cache_id < 0) x.store_id = nd[sd]->cacheId = ctx.nextCacheId++;
             nMembers += (size_t)x.n_members;
             stride = std::max(stride, x.len);
         }
@@ -280,11 +276,11 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     // ---- device: profiles, consensus, gappy-column removal, gap penalties ----
     twl_params tp = baseParams(param);
     std::vector<int32_t> lens(2 * (size_t)n);
-    const int nd = (int)g_stores.size();
+    const int nd = (int)ctx.stores.size();
     std::vector<std::vector<int32_t>> lensOf(nd);
     onAllStores(ctx, "twl_level_prepare", [&](int d) {
         lensOf[d].resize(2 * (size_t)n);       // every replica prepares the whole level; column info is fetched from the first only, below
-        return twl_level_prepare(g_stores[d], &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride,
+        return twl_level_prepare(ctx.stores[d], &tp, option->gappyVertical, n, sides.data(), members.data(), weights.data(), stride,
                                  d == 0 ? lens.data() : lensOf[d].data(), nullptr);
     });
     for (int d = 1; d < nd; ++d)
@@ -307,7 +303,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     const bool inPlace = (nd == 1 && ((!procs && !ctx.shard.exchange && !ctx.shard.rccl) || devX));
     auto infoOf = [&](const std::vector<int> &which) {      // consensus + removed runs of these pairs, one synchronisation
         uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * which.size() * stride));
-        const int rc = twl_level_read_colinfo_many(g_store, (int32_t)which.size(), which.data(), info);
+        const int rc = twl_level_read_colinfo_many(firstStore(ctx), (int32_t)which.size(), which.data(), info);
         if (rc != TWL_OK) die("twl_level_read_colinfo_many", rc);
 #pragma omp parallel for schedule(dynamic, 4)
         for (int t = 0; t < (int)which.size(); ++t) {
@@ -319,7 +315,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (inPlace) {}
     else if (needInfo.size() * 8 > (size_t)n) {        // most pairs: one transfer of the level's block
         uint8_t *info = reinterpret_cast<uint8_t *>(g_infoStage.get((size_t)2 * n * stride));
-        const int rc = twl_level_read_colinfo(g_store, -1, 0, info);
+        const int rc = twl_level_read_colinfo(firstStore(ctx), -1, 0, info);
         if (rc != TWL_OK) die("twl_level_read_colinfo", rc);
 #pragma omp parallel for schedule(dynamic, 4)
         for (int t = 0; t < (int)needInfo.size(); ++t) {
@@ -372,13 +368,13 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             for (int i = 0; i < n; ++i) if (all[i] && owner[i] == meBase + d) { mask[i] = 1; ++cnt; }
             if (!cnt) continue;
             const double tCall = nowMs();
-            const int r = twl_level_align(g_stores[d], grp ? &tz : &tp, mask.data(), aln, alnLen.data(), err.data());
+            const int r = twl_level_align(ctx.stores[d], grp ? &tz : &tp, mask.data(), aln, alnLen.data(), err.data());
             if (r != TWL_OK) return r;
             callMs[d] += nowMs() - tCall;
             auto addStats = [&]() {
                 twl_stats st{};
-                if (nd == 1 || g_storeDev[d] != g_storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
-                    if (twl_get_stats(g_storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); } if (d == 0) { rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; } }
+                if (nd == 1 || ctx.storeDev[d] != ctx.storeDev[(d + 1) % nd]) {      // per-device counters (virtual replicas share one device: see below)
+                    if (twl_get_stats(ctx.storeDev[d], &st) == TWL_OK) { cellsOf[d] += st.band_cells; redoOf[d] += (uint64_t)st.n_relaunched; kernMs[d] += st.kernel_ms; totMs[d] += st.total_ms; if (d == 0 && rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); } if (d == 0) { rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; } }
                 }
             };
             addStats();
@@ -398,7 +394,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
                         else { tr.xdrop = static_cast<int32_t>(tr.xdrop * 2); tr.flen = std::min(static_cast<int32_t>(tr.xdrop * 4) << 1, minLen); }
                         if (option->printDetail) std::cout << "Retry pair No. " << i << "\txdrop " << tr.xdrop << " flen " << tr.flen << '\n';
                         const double tRetry = nowMs();
-                        const int rr = twl_level_align(g_stores[d], &tr, one.data(), aln, len1.data(), err1.data());
+                        const int rr = twl_level_align(ctx.stores[d], &tr, one.data(), aln, len1.data(), err1.data());
                         if (rr != TWL_OK) return rr;
                         callMs[d] += nowMs() - tRetry;
                         addStats();
@@ -420,7 +416,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             }
             if (!restore.empty()) {             // gappy columns back on the device: these paths never leave HBM either
                 std::vector<int32_t> fin(restore.size(), -1);
-                const int r3 = twl_level_restore(g_stores[d], grp ? &tz : &tp, (int32_t)restore.size(), restore.data(), pathStride, fin.data());
+                const int r3 = twl_level_restore(ctx.stores[d], grp ? &tz : &tp, (int32_t)restore.size(), restore.data(), pathStride, fin.data());
                 if (r3 != TWL_OK) return r3;
                 for (size_t t = 0; t < restore.size(); ++t) {
                     if (fin[t] > 0) { fromDp[restore[t]] = 2; dpLen[restore[t]] = fin[t]; }
@@ -431,7 +427,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
                 infoOf(std::vector<int>(fetch.begin(), fetch.end()));
                 handedBack.insert(handedBack.end(), fetch.begin(), fetch.end());
                 int8_t *blk = reinterpret_cast<int8_t *>(g_alnStage[d].get(fetch.size() * (size_t)2 * stride));
-                const int r2 = twl_level_read_paths(g_stores[d], (int32_t)fetch.size(), fetch.data(), fetchLen.data(), blk, 2 * stride);
+                const int r2 = twl_level_read_paths(ctx.stores[d], (int32_t)fetch.size(), fetch.data(), fetchLen.data(), blk, 2 * stride);
                 if (r2 != TWL_OK) return r2;
                 for (size_t t = 0; t < fetch.size(); ++t) paths[fetch[t]].assign(&blk[t * (size_t)2 * stride], &blk[t * (size_t)2 * stride] + fetchLen[t]);
             }
@@ -443,7 +439,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (const char *dump = getenv("TWL_DUMP_SCHEDULE")) {
         if (FILE *f = fopen(dump, "a")) {
             std::vector<uint64_t> pc(n, 0);
-            if (nd == 1) (void)twl_get_pair_cells(g_storeDev[0], pc.data(), n);
+            if (nd == 1) (void)twl_get_pair_cells(ctx.storeDev[0], pc.data(), n);
             for (int i = 0; i < n; ++i)
                 fprintf(f, "%d %d %d %d %d %d %d %llu\n", (int)ctx.levels.size(), i, nodes[i].first->seqsIncluded.empty() ? -1 : nodes[i].first->seqsIncluded[0],
                         nodes[i].second->seqsIncluded.empty() ? -1 : nodes[i].second->seqsIncluded[0], ps[i].lens.first, ps[i].lens.second, (int)errs[i], (unsigned long long)pc[i]);
@@ -472,7 +468,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         if (errs[i] != 0 || paths[i].empty()) continue;
         alnPath full;
         restoreOnHost(i, full);
-        const int rc = twl_level_write_final(g_store, i, full.data(), (int32_t)full.size());
+        const int rc = twl_level_write_final(firstStore(ctx), i, full.data(), (int32_t)full.size());
         if (rc != TWL_OK) die("twl_level_write_final", rc);
         fromDp[i] = 2; dpLen[i] = (int32_t)full.size();
         paths[i].clear();
@@ -480,7 +476,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     if (devX) {                               // HBM to HBM
         std::vector<int32_t> bound(n);
         for (int i = 0; i < n; ++i) bound[i] = ps[i].refLen + ps[i].qryLen;
-        exchangeFinalPaths(ctx, g_store, g_storeDev[0], tp, owner, takesPart, bound, pathStride, fromDp, dpLen, errs, rec);
+        exchangeFinalPaths(ctx, firstStore(ctx), ctx.storeDev[0], tp, owner, takesPart, bound, pathStride, fromDp, dpLen, errs, rec);
     }
     else exchangePaths(ctx, owner, takesPart, 2 * stride, paths, errs, rec);             // several processes: everybody gets every path
     std::vector<int> fallbackPairs;
@@ -521,7 +517,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         finalLen[i] = (int32_t)full.size();
     }
     const double tGappy = nowMs() - tFin;
-    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit_from_dp(g_stores[d], finalPaths, finalLen.data(), pathStride, inPlace ? fromDp.data() : nullptr); });
+    onAllStores(ctx, "twl_level_commit", [&](int d) { return twl_level_commit_from_dp(ctx.stores[d], finalPaths, finalLen.data(), pathStride, inPlace ? fromDp.data() : nullptr); });
 #pragma omp parallel for schedule(static) if (n >= 512)
     for (int i = 0; i < n; ++i) {               // Node bookkeeping of updateFrequency / updateAlignment (alignment-helper.cpp:474-478,536-538); the pairs of a level share no node
         if (finalLen[i] == 0) continue;
@@ -535,7 +531,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     }
     ctx.totals.finish_ms += nowMs() - tFin;
     double devPrep = 0, devCommit = 0;
-    if (option->printDetail) twl_level_timing(g_store, &devPrep, &devCommit);      // (waits for the write-back kernels, which the next level would otherwise overlap with)
+    if (option->printDetail) twl_level_timing(firstStore(ctx), &devPrep, &devCommit);      // (waits for the write-back kernels, which the next level would otherwise overlap with)
     ctx.totals.dev_prepare_ms += devPrep;
     ctx.totals.dev_commit_ms += devCommit;
     for (int i = 0; i < n; ++i)

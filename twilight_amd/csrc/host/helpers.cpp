@@ -13,6 +13,8 @@
 
 namespace msa {
 namespace alignment_helper {
+int _CAL_PROFILE_TH = 1000, _UPDATE_SEQ_TH = 1000;      // msa.hpp:179-180
+
 
 static std::mutex g_mapMutex;      // plays database->mapMutex (alignment-helper.cpp:406,420)
 

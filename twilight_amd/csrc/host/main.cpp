@@ -36,7 +36,7 @@ int main(int argc, char **argv)
     auto t0 = std::chrono::high_resolution_clock::now();
     int rank = 0;
     const std::vector<int> allDevices = option.gpuIdx;
-    const int world = (allDevices.size() > 1 && !option.hostStaged && !getenv("TWL_TEST_VIRTUAL_DEVICES")) ? (int)allDevices.size() : 1;
+    const int world = (allDevices.size() > 1 && !option.hostStaged && option.testVirtualDevices == 0) ? (int)allDevices.size() : 1;
     SharedPage *page = nullptr;
     std::vector<pid_t> kids;
     if (world > 1) {

@@ -73,7 +73,7 @@ void getProgressivePairs(std::vector<std::pair<NodePair, int>> &alnOrder, std::s
                 levelOf[node->children[0]] = lvl;
                 alnOrder.push_back({{node, node->children[0]}, lvl});
             }
-            levelOf[node] = levelOf[children[0]];
+            { const int l = levelOf[children[0]]; levelOf[node] = l; }      // (operator[] may grow the table: the value first, then the slot)
         }
     } else if (mode == 1) {
         for (; !postStack.empty(); postStack.pop()) {

@@ -120,6 +120,7 @@ struct Option {
     bool alignGappy = true;
     std::string treeFile, seqFile, outFile;
     bool printDetail = false;    // -v
+    int testVirtualDevices = 0;  // --test-virtual-devices n: n replicas of the store on the first device (the several-replica path of the resident kernel on a one-GPU box)
     bool hostStaged = false;     // --host-staged: build profiles on the host and stage them per level (default: device-resident rows)
     // scoring flags (consumed by Params)
     float match = 18, mismatch = -8, transition = -4, gapOpen = -50, gapExtend = -5, xdrop = 600;
@@ -188,15 +189,9 @@ char detectType(const std::string &seqFile);
 using alnFunction = std::function<void(Tree *, NodePairVec &, SequenceDB *, Option *, Params &)>;
 
 namespace alignment_helper {
-// msa.hpp:179-180.  The two thresholds are 1000 in the reference; the environment variables exist for tests only (they let small
-// trees reach the cached-profile and compressed-group branches) and apply to the product CLI and the CPU checker alike.
-inline int thresholdFromEnv(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && atoi(v) > 0) ? atoi(v) : dflt;
-}
-static const int _CAL_PROFILE_TH = thresholdFromEnv("TWL_TEST_CAL_PROFILE_TH", 1000);
-static const int _UPDATE_SEQ_TH = thresholdFromEnv("TWL_TEST_UPDATE_SEQ_TH", 1000);
+// msa.hpp:179-180.  The two thresholds are 1000 in the reference; tests lower them (--test-cal-profile-th / --test-update-seq-th, parseCommandLine: small
+// trees then reach the cached-profile and compressed-group branches) for the product CLI, the library and the CPU checker alike.  Nothing in the environment touches them.
+extern int _CAL_PROFILE_TH, _UPDATE_SEQ_TH;
 void calculateProfile(float *profile, NodePair &nodes, SequenceDB *database, Option *option, int32_t memLen);
 void removeGappyColumns(float *hostFreq, NodePair &nodes, Option *option, std::pair<IntPairVec, IntPairVec> &gappyColumns, int32_t memLen,
                         IntPair &lens, int currentTask);

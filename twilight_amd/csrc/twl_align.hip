@@ -62,13 +62,6 @@ thread_local std::string g_err;
 std::mutex g_mu;
 
 static bool dbg_on() { static const bool v = getenv("TWL_DEBUG") != nullptr; return v; }
-// Development knobs of the launch policy exist in TWL_DEV builds only (__graft_entry__.build() with TWL_DEV_BUILD=1); what tests
-// need goes through twl_set_knob.
-#ifdef TWL_DEV
-static const char *dev_env(const char *name) { return getenv(name); }
-#else
-static const char *dev_env(const char *) { return nullptr; }
-#endif
 #define TRACE(...) do { if (dbg_on()) { fprintf(stderr, "[twl trace] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 #define HIP_TRY(expr)                                                                                          \
@@ -193,7 +186,6 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
             cached.store(std::max(1, nb));
         }
         blocks_per_cu = cached.load();
-        if (const char *cap = dev_env("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));
     }
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
@@ -247,7 +239,6 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
         cached.store(std::max(1, nb));
     }
     int blocks_per_cu = cached.load();
-    if (const char *cap = dev_env("TWL_MAX_WG_PER_CU")) blocks_per_cu = std::max(1, std::min(blocks_per_cu, atoi(cap)));
     if (window_out) *window_out = CfgT::WINDOW;
     int grid = std::min(n_items, d->num_cu * blocks_per_cu);
     if (grid < 1) grid = 1;
@@ -279,7 +270,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     FILL_TRY(flush_fills(d, st));
     hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
-    if (SPEC && (dbg_on() || dev_env("TWL_SPEC_STATS"))) {      // development: how often the guessed tile start was the true one
+    if (SPEC && dbg_on()) {      // development: how often the guessed tile start was the true one
         std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
         HIP_TRY(hipMemcpyAsync(tw.data(), d->team.p, tw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -325,10 +316,12 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
+int g_no_spec = 0;                   // twl_set_knob(TWL_KNOB_NO_SPEC): no speculative two-workgroup teams (tools that time the plain tile loop)
 int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
 int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
+struct Knobs;
 
 template <int P, int MM, int TRPL, bool WIDE = false, int TW = 8>      // TW x TRPL: waves and 64-row blocks per wave of the throughput geometry (nucleotide 4 x 3: 768 rows, four workgroups per CU; protein 8 x 1: 512 rows, two)
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
@@ -423,6 +416,103 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     return TWL_OK;
 }
 
+
+// ---- launch policy of the nucleotide path: a pure function of the call's facts (unit-tested without a GPU through twl_plan_describe) ----
+struct Knobs { int mt_max_pairs, mt_min_marker, mt_tail_pct, mt_wide, assume_onehot_query, no_spec; };
+struct NucFacts {
+    int n_run = 0, num_cu = 0, marker = 0;
+    const float *M = nullptr;             // 5 x 5 matrix
+    float gap_char = 0;
+    bool qry_onehot = false, dump = false;
+    int wide_streak = 0;
+    const int32_t *h_len = nullptr;       // [pair][2]
+    const int32_t *order = nullptr;       // the pairs that run, longest first
+};
+enum class NucFirst { Dump, WideMt, Mt, SpecShared, Spec16, Few16, Throughput, General };
+struct NucPlan {
+    NucFirst first = NucFirst::General;
+    int mm = 0;                           // matrix mode 0 general / 1 zero N row and column / 2 match-transition-transversion
+    bool mm5 = false;                     // ... in its one-letter-query form (mode 5)
+    bool lean = false;                    // the round-2 kernels (scores within fast_div's range)
+    bool four = false;                    // throughput launch on 4 waves x 3 blocks, four workgroups per CU (768-row window)
+    int bulk = 0, tail = 0;               // throughput: pairs in full rounds / remainder through the tile-parallel path
+};
+NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
+{
+    NucPlan pl;
+    const float *M = f.M;
+    // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
+    bool nz = true, st3 = true;
+    for (int t = 0; t < 5; ++t) nz = nz && M[20 + t] == 0.0f && M[5 * t + 4] == 0.0f;
+    for (int l = 0; l < 4; ++l)
+        for (int m = 0; m < 4; ++m) st3 = st3 && M[5 * l + m] == ((l == m) ? M[0] : (((l ^ m) == 2) ? M[2] : M[1]));
+    pl.mm = nz ? (st3 ? 2 : 1) : 0;
+    // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]; anything else takes the IEEE-division kernel
+    bool divOk = true;
+    auto inRange = [](float x) { const float ax = std::fabs(x); return x == 0.0f || (ax >= 0.0009765625f && ax <= 1024.0f); };
+    for (int t = 0; t < 25; ++t) divOk = divOk && inRange(M[t]);
+    pl.lean = divOk && inRange(f.gap_char);
+    const int mm = pl.mm, n_run = f.n_run;
+    // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step
+    const bool few = n_run <= f.num_cu;
+    int32_t maxLen = 0;
+    long long sumLen = 0;
+    for (int32_t t = 0; t < n_run; ++t) {
+        const int32_t R = f.h_len[2 * f.order[t]], Q = f.h_len[2 * f.order[t] + 1];
+        maxLen = std::max(maxLen, std::max(R, Q)); sumLen += (long long)R + Q;
+    }
+    // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
+    pl.mm5 = pl.lean && mm >= 1 && (f.qry_onehot || k.assume_onehot_query);
+    // very few pairs: two workgroups per pair take the tiles in turn (the mailbox words of that start carry absolute positions in 16 bits each)
+    const bool spec = pl.lean && few && (mm == 2 || pl.mm5) && 2 * n_run <= f.num_cu && maxLen <= 65535 && !k.no_spec;
+    // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the pairs fill the
+    // ONE round of the throughput kernel badly -- tiles spread evenly, at the price of the scouts (~1.2x the work).  Levels of several rounds: the remainder rule below.
+    pl.four = pl.lean && (pl.mm5 || mm == 2);
+    const int perRound = (pl.four ? 4 : 2) * f.num_cu;
+    const double roundsThr = (double)n_run / (double)perRound;
+    const bool mtOk = pl.lean && mm == 2 && !pl.mm5 && !f.dump && n_run <= k.mt_max_pairs && f.marker >= k.mt_min_marker &&
+                      sumLen >= 3ll * f.marker * n_run && (2 * n_run <= f.num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
+    // the last calls' pairs all outgrew the fast window (the deferred pass: one pair per level against the same growing root): no point in finding
+    // that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
+    const bool wideFirst = k.mt_wide && n_run <= 8 && f.wide_streak >= 2 && (f.wide_streak & 7) != 7;
+    if (f.dump) pl.first = NucFirst::Dump;
+    else if (mtOk && wideFirst) pl.first = NucFirst::WideMt;
+    else if (mtOk) pl.first = NucFirst::Mt;
+    // CUs/2 < pairs <= CUs: two workgroups per pair taking the tiles in turn, of the 8-wave geometry, two to a CU (all 2n resident at once, as the teams
+    // wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one 16-wave workgroup per pair
+    else if (pl.lean && mm == 2 && n_run <= f.num_cu && 2 * n_run > f.num_cu && maxLen <= 65535 && !k.no_spec) pl.first = NucFirst::SpecShared;
+    else if (spec) pl.first = NucFirst::Spec16;
+    else if (pl.lean && few) pl.first = NucFirst::Few16;
+    else if (pl.lean) {
+        // Many pairs: persistent workgroups take them in rounds.  A last round that is badly filled costs a whole round: when the remainder is small enough
+        // its pairs (the shortest ones, the order is longest first) go through the tile-parallel path instead, where they spread over all CUs.
+        pl.first = NucFirst::Throughput;
+        int tail = n_run % perRound;
+        long long tailLen = 0;
+        for (int32_t t = n_run - tail; t < n_run; ++t) tailLen += (long long)f.h_len[2 * f.order[t]] + f.h_len[2 * f.order[t] + 1];
+        // (pairs of 8+ tiles: with fewer the scouts and extra launches cost more than the idle workgroups)
+        if (!(n_run > perRound && tail > 0 && tail * 100 <= k.mt_tail_pct * perRound && tail <= k.mt_max_pairs && pl.four && f.marker >= k.mt_min_marker && tailLen >= 8ll * f.marker * tail)) tail = 0;
+        pl.tail = tail; pl.bulk = n_run - tail;
+    }
+    else pl.first = NucFirst::General;
+    return pl;
+}
+const char *nuc_first_name(NucFirst f)
+{
+    switch (f) {
+    case NucFirst::Dump: return "dump";
+    case NucFirst::WideMt: return "tile-parallel, 3072-row window";
+    case NucFirst::Mt: return "tile-parallel";
+    case NucFirst::SpecShared: return "speculative teams, 8 waves x 2 blocks";
+    case NucFirst::Spec16: return "speculative teams, 16 waves";
+    case NucFirst::Few16: return "16 waves x 1 block";
+    case NucFirst::Throughput: return "throughput";
+    default: return "general (IEEE division)";
+    }
+}
+
+Knobs current_knobs() { return Knobs{g_mt_max_pairs, g_mt_min_marker, g_mt_tail_pct, g_mt_wide, g_assume_onehot_query, g_no_spec}; }
+
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
@@ -512,16 +602,12 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
     bool ranMt = false, leanMid = false, startedWide = false, thr768 = false;
-    const bool force_wide = dev_env("TWL_FORCE_WIDE") != nullptr;
-    const char *cfg = dev_env("TWL_FAST_CFG");      // pick the fast-path geometry (nucleotide only)
-    const std::string c = cfg ? cfg : "nuc";
     const int32_t *items = (const int32_t *)d->items.p;
     auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
         return prot ? launch_dp<22, 8, 9, false, false, false>(d, st, a, it, n_it, 1, g, w)
                     : launch_dp<6, 8, 9, false, false, true>(d, st, a, it, n_it, 1, g, w);
     };
     if (n_run == 0) rc = TWL_OK;      // nothing to align in this call
-    else if (force_wide) rc = launch_wide(items, n_run, &grid, &window);
     else if (prot) {
         // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
         // TWL_KNOB_PROT_MODE: auto | dense | sparse | presim | r1 (round-1 kernels) | lean_sparse | lean_presim
@@ -562,8 +648,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             HIP_TRY(hipStreamSynchronize(st));      // m24 goes out of scope
             // CUs/2 < pairs <= CUs: speculative teams of the 512-row geometry, two workgroups per CU, on precomputed scores (as the nucleotide
             // path does with its throughput geometry)
-            const bool sharedSpec = lean && pcs == "auto" && (!few || dev_env("TWL_SPEC_SHARED_ALL")) && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on &&
-                                    !dev_env("TWL_NO_SPEC") && !dev_env("TWL_NO_SPEC_SHARED");
+            const bool sharedSpec = lean && pcs == "auto" && !few && n_run <= d->num_cu && maxLenP <= 65535 && fits && !d->dump_on && !g_no_spec;
             const bool presim = (pcs == "presim" || pcs == "lean_presim" || (pcs == "auto" && few) || sharedSpec) && fits && !d->dump_on;
             statMode = presim ? 4 : 3;
             if (presim) {
@@ -582,20 +667,20 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipGetLastError());
                 a.sim = (const float *)d->sim.p;
                 a.sim_off = (const long long *)d->sim_off.p;
-                statSpec = sharedSpec ? 2 : ((lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !dev_env("TWL_NO_SPEC")) ? 1 : 0);
+                statSpec = sharedSpec ? 2 : ((lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !g_no_spec) ? 1 : 0);
                 long long sumLenP = 0;
                 for (int32_t t = 0; t < n_run; ++t) sumLenP += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
                 // tile-parallel (talco_nuc.hip.h, MT kernels) on the precomputed scores: pairs of 2 kaa have 4-5 tiles each
                 const bool mtOkP = lean && pcs == "auto" && n_run <= g_mt_max_pairs && n_run <= d->num_cu && p->marker >= g_mt_min_marker && sumLenP >= 3ll * p->marker * n_run;
                 if (mtOkP) { rc = launch_mt<22, 4, 1>(d, st, a, items, order, n_run, h_len, &grid, &window); statSpec = 3; ranMt = true; protSmall = false; }
                 else if (sharedSpec) { rc = launch_lean<22, 8, 1, 4, 4, true>(d, st, a, items, n_run, &grid, &window); protSmall = true; }
-                else if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !dev_env("TWL_NO_SPEC")) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
+                else if (lean && 2 * n_run <= d->num_cu && maxLenP <= 65535 && !g_no_spec) rc = launch_lean<22, 16, 1, 4, 1, true>(d, st, a, items, n_run, &grid, &window);
                 else if (lean) rc = launch_lean<22, 16, 1, 4, 1>(d, st, a, items, n_run, &grid, &window);
                 else rc = launch_dp<22, 8, 2, false, true, true, 1, 4>(d, st, a, items, n_run, 0, &grid, &window);
             } else if (d->dump_on) {      // twl_dp_column_scores: the sparse in-kernel score loop, every visited cell written out
                 if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
                 rc = launch_lean<22, 16, 1, 3, 1, false, true>(d, st, a, items, n_run, &grid, &window);
-            } else if (lean && n_run > d->num_cu && !dev_env("TWL_PROT_NO_SMALL")) {
+            } else if (lean && n_run > d->num_cu) {
                 // more pairs than CUs: the 512-row window (8 waves, one block each; protein bands of 2 kaa pairs are ~270 rows wide, ~400
                 // at most) keeps the ring at 61 KB, so two workgroups share a CU like in the nucleotide throughput kernel; a pair
                 // whose band outgrows it goes to the 1024-row kernel below
@@ -608,89 +693,52 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             }
         }
     }
-    else if (c == "w8r2" || c == "nuc" || c == "nuc16" || c == "nuc8") {
-        // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
-        const float *M = a.M;
-        bool nz = true, st3 = true;
-        for (int t = 0; t < 5; ++t) nz = nz && M[20 + t] == 0.0f && M[5 * t + 4] == 0.0f;
-        for (int l = 0; l < 4; ++l)
-            for (int m = 0; m < 4; ++m) st3 = st3 && M[5 * l + m] == ((l == m) ? M[0] : (((l ^ m) == 2) ? M[2] : M[1]));
-        const char *mmEnv = dev_env("TWL_MATRIX_MODE");
-        int mm = nz ? (st3 ? 2 : 1) : 0;
-        if (mmEnv) mm = std::min(mm, atoi(mmEnv));          // development knob: force a more general mode
-        // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]; anything else takes the IEEE-division kernel
-        bool divOk = true;
-        auto inRange = [](float x) { const float ax = std::fabs(x); return x == 0.0f || (ax >= 0.0009765625f && ax <= 1024.0f); };
-        for (int t = 0; t < 25; ++t) divOk = divOk && inRange(M[t]);
-        divOk = divOk && inRange(p->gap_char);
-        const bool lean = (c != "w8r2") && divOk;
-        // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step; many pairs: two blocks per wave, 2+ workgroups per CU
-        const bool few = (c == "nuc16") || (c == "nuc" && n_run <= d->num_cu && !dev_env("TWL_NO_FEW"));
-        // very few pairs: two workgroups per pair take the tiles in turn, the idle one starting its tile early from a guess (talco_nuc.hip.h)
-        int32_t maxLen = 0;
-        for (int32_t t = 0; t < 2 * n_pairs; ++t) maxLen = std::max(maxLen, h_len[t]);
-        // (the mailbox words of the speculative start carry absolute positions in 16 bits each)
-        // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
-        const bool mm5 = lean && mm >= 1 && (qry_onehot || g_assume_onehot_query) && !dev_env("TWL_NO_ONEHOT");
-        const bool spec = lean && few && (mm == 2 || mm5) && 2 * n_run <= d->num_cu && maxLen <= 65535 && !dev_env("TWL_NO_SPEC");
+    else {
+        NucFacts nf;
+        nf.n_run = n_run; nf.num_cu = d->num_cu; nf.marker = p->marker; nf.M = a.M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot; nf.dump = d->dump_on;
+        nf.wide_streak = d->wide_streak; nf.h_len = h_len; nf.order = order.data();
+        const NucPlan pl = plan_nucleotide(nf, current_knobs());
+        const int mm = pl.mm;
+        const bool mm5 = pl.mm5;
         statMode = mm5 ? 5 : mm;
-        statSpec = spec ? 1 : 0;
-        leanMid = lean && mm == 2;
-        long long sumLen = 0;
-        for (int32_t t = 0; t < n_run; ++t) sumLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
-        // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the
-        // pairs fill the ONE round of the throughput kernel badly (2 * CUs persistent workgroups) -- tiles spread evenly, at the price of
-        // the scouts (~1.2x the work).  Levels of several rounds: see the remainder rule at the throughput launch below.
-        const double roundsThr = (double)n_run / (((mm == 2 || mm5) ? 4.0 : 2.0) * d->num_cu);
-        const bool mtOk = lean && mm == 2 && !mm5 && !d->dump_on && n_run <= g_mt_max_pairs && p->marker >= g_mt_min_marker &&
-                          sumLen >= 3ll * p->marker * n_run && (2 * n_run <= d->num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
-        const bool wideFirst = g_mt_wide && n_run <= 8 && d->wide_streak >= 2 && (d->wide_streak & 7) != 7;
-        if (d->dump_on) {      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
-            if (!lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
+        leanMid = pl.lean && mm == 2;
+        TRACE("plan: %s, matrix mode %d%s", nuc_first_name(pl.first), mm, mm5 ? " (one-letter query rows)" : "");
+        switch (pl.first) {
+        case NucFirst::Dump:      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
+            if (!pl.lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
             if (mm5) rc = launch_lean<6, 16, 1, 5, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1, false, true>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1, false, true>(d, st, a, items, n_run, &grid, &window);
-        }
-        else if (mtOk && wideFirst) {
-            // the last calls' pairs all outgrew the fast window (the deferred pass: one pair per level against the same growing root): no point in
-            // finding that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
+            break;
+        case NucFirst::WideMt:
             rc = launch_mt<6, 2, 3, true, 4>(d, st, a, items, order, n_run, h_len, &grid, &window);
             statSpec = 3; ranMt = true; startedWide = true;
-        }
-        else if (mtOk) {
-            // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
+            break;
+        case NucFirst::Mt:        // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
             rc = launch_mt<6, 2, 3, false, 4>(d, st, a, items, order, n_run, h_len, &grid, &window);
             statSpec = 3; ranMt = true;
-        }
-        else if (lean && mm == 2 && n_run <= d->num_cu && (2 * n_run > d->num_cu || dev_env("TWL_SPEC_SHARED_ALL")) && maxLen <= 65535 && !dev_env("TWL_NO_SPEC") && !dev_env("TWL_NO_SPEC_SHARED")) {
-            // CUs/2 < pairs <= CUs: still two workgroups per pair taking the tiles in turn, but of the throughput geometry, two to a CU
-            // (all 2n resident at once, as the teams wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one
-            // 16-wave workgroup per pair; below CUs/2 pairs the 16-wave teams on a CU each are a little faster (16.4 vs 16.9 ms)
+            break;
+        case NucFirst::SpecShared:
             rc = launch_lean<6, 8, 2, 2, 4, true>(d, st, a, items, n_run, &grid, &window);
             statMode = 2; statSpec = 2;
-        }
-        else if (spec && mm5) rc = launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_run, &grid, &window);
-        else if (spec) rc = launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_run, &grid, &window);
-        else if (lean && few) {
+            break;
+        case NucFirst::Spec16:
+            rc = mm5 ? launch_lean<6, 16, 1, 5, 1, true>(d, st, a, items, n_run, &grid, &window) : launch_lean<6, 16, 1, 2, 1, true>(d, st, a, items, n_run, &grid, &window);
+            statSpec = 1;
+            break;
+        case NucFirst::Few16:
             if (mm5) rc = launch_lean<6, 16, 1, 5, 1>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 2) rc = launch_lean<6, 16, 1, 2, 1>(d, st, a, items, n_run, &grid, &window);
             else if (mm == 1) rc = launch_lean<6, 16, 1, 1, 1>(d, st, a, items, n_run, &grid, &window);
             else rc = launch_lean<6, 16, 1, 0, 1>(d, st, a, items, n_run, &grid, &window);
-        } else if (lean) {
-            // Many pairs: persistent workgroups take them in rounds.  Default matrix structure (modes 2 and 5): 4 waves x 3 blocks, a 768-row window,
-            // FOUR workgroups per CU (round 4: the same 16 waves per CU as 8 waves x 2 blocks twice, but four independent anti-diagonal chains per SIMD
-            // instead of two, a barrier of four waves instead of eight, and no first products kept per row -- 2048 pairs of 10 kbp 120 -> 95 ms, a leaf
-            // level 96 -> 66 ms, tools/exp_thr.py); a pair whose band outgrows 640 rows re-runs on 8 waves x 2 blocks (1024 rows) below.
-            // A last round that is badly filled costs a whole round: when the remainder is small enough its pairs (the shortest ones, the order is
-            // longest first) go through the tile-parallel path instead, where they spread over all CUs.
-            const bool four = (mm5 || mm == 2);
-            const int R = (four ? 4 : 2) * d->num_cu;
-            int tail = n_run % R;
-            long long tailLen = 0;
-            for (int32_t t = n_run - tail; t < n_run; ++t) tailLen += (long long)h_len[2 * order[t]] + h_len[2 * order[t] + 1];
-            if (!(n_run > R && tail > 0 && tail * 100 <= g_mt_tail_pct * R && tail <= g_mt_max_pairs && (mm == 2 || mm5) && p->marker >= g_mt_min_marker && tailLen >= 8ll * p->marker * tail)) tail = 0;      // (pairs of 8+ tiles: with fewer the scouts and extra launches cost more than the idle workgroups)
-            const int bulk = n_run - tail;
+            break;
+        case NucFirst::Throughput: {
+            // Default matrix structure (modes 2 and 5): 4 waves x 3 blocks, a 768-row window, FOUR workgroups per CU (round 4: the same 16 waves per CU as
+            // 8 waves x 2 blocks twice, but four independent anti-diagonal chains per SIMD instead of two, a barrier of four waves instead of eight, and no
+            // first products kept per row -- 2048 pairs of 10 kbp 120 -> 95 ms, a leaf level 96 -> 66 ms, tools/exp_thr.py); a pair whose band outgrows 640
+            // rows re-runs on 8 waves x 2 blocks (1024 rows) below.
+            const int bulk = pl.bulk, tail = pl.tail;
 #if defined(TWL_EXP_THR_W)      // geometry experiments (tools/exp_thr.py on cross-compiled variants): waves, blocks per wave, waves per SIMD of the throughput launch
             if (mm5) rc = launch_lean<6, TWL_EXP_THR_W, TWL_EXP_THR_RPL, 5, TWL_EXP_THR_MINW>(d, st, a, items, bulk, &grid, &window);
             else if (mm == 2) rc = launch_lean<6, TWL_EXP_THR_W, TWL_EXP_THR_RPL, 2, TWL_EXP_THR_MINW>(d, st, a, items, bulk, &grid, &window);
@@ -700,7 +748,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
 #endif
             else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, bulk, &grid, &window);
             else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, bulk, &grid, &window);
-            thr768 = four;
+            thr768 = pl.four;
             if (!rc && tail > 0) {
                 const std::vector<int32_t> tailOrder(order.begin() + bulk, order.begin() + n_run);
                 int g2 = 0, w2 = 0;
@@ -709,12 +757,14 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                          : launch_mt<6, 2, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
                 ranMt = true;
             }
+            break;
         }
-        else if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_run, 0, &grid, &window);
-        else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_run, 0, &grid, &window);
-        else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_run, 0, &grid, &window);
+        default:                  // scores outside the fast division's range: the round-1 kernels (IEEE division)
+            if (mm == 2) rc = launch_dp<6, 8, 2, false, true, true, 4, 2>(d, st, a, items, n_run, 0, &grid, &window);
+            else if (mm == 1) rc = launch_dp<6, 8, 2, false, true, true, 4, 1>(d, st, a, items, n_run, 0, &grid, &window);
+            else rc = launch_dp<6, 8, 2, false, true, true, 4, 0>(d, st, a, items, n_run, 0, &grid, &window);
+        }
     }
-    else { g_err = "unknown TWL_FAST_CFG"; return TWL_ERR_BAD_ARGUMENT; }
     if (rc) return rc;
     FILL_TRY(flush_fills(d, st));      // (nothing ran: the outputs are still to be zeroed)
     HIP_TRY(hipEventRecord(d->ev[2], st));
@@ -765,7 +815,6 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (guardRound) --stage;      // (the window stages follow once these are done)
         else for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
         if (redo.empty()) break;
-        if (force_wide) { g_err = "band wider than the wide window"; return TWL_ERR_UNSUPPORTED; }
         const bool mid = (stage == 1) && (!prot || protSmall) && !startedWide;      // (a call that started on the 3072-row geometry goes on to the widest kernel)
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
@@ -1224,6 +1273,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_ASSUME_ONEHOT_QUERY: g_assume_onehot_query = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_MT_TAIL_PCT: g_mt_tail_pct = std::max(0, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }
@@ -1349,6 +1399,24 @@ int twl_comm_destroy(int device)
     const int n = g_rccl.commDestroy(d->comm);
     d->comm = nullptr; d->comm_world = 0;
     return n == 0 ? TWL_OK : rccl_fail("ncclCommDestroy", n);
+}
+
+// The launch plan of a nucleotide call, as run_device would make it, in words: no device is touched (unit tests of the policy on a CPU-only box).
+int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, int32_t num_cu, int32_t qry_onehot, int32_t wide_streak, char *out, int32_t cap)
+{
+    if (!p || p->P != 6 || n_pairs < 0 || (n_pairs > 0 && !len) || num_cu < 1 || !out || cap < 64) { g_err = "bad argument (nucleotide parameters, a buffer of 64+ bytes)"; return TWL_ERR_BAD_ARGUMENT; }
+    std::vector<int32_t> order;
+    for (int32_t n = 0; n < n_pairs; ++n) if (len[2 * n] > 0 && len[2 * n + 1] > 0) order.push_back(n);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return (int64_t)len[2 * x] + len[2 * x + 1] > (int64_t)len[2 * y] + len[2 * y + 1]; });
+    float M[25];
+    for (int t = 0; t < 25; ++t) M[t] = p->matrix[t];
+    NucFacts nf;
+    nf.n_run = (int)order.size(); nf.num_cu = num_cu; nf.marker = p->marker; nf.M = M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot != 0; nf.wide_streak = wide_streak;
+    nf.h_len = len; nf.order = order.data();
+    const NucPlan pl = plan_nucleotide(nf, current_knobs());
+    snprintf(out, (size_t)cap, "%s; mode %d; window %d; bulk %d tail %d", nuc_first_name(pl.first), pl.mm5 ? 5 : pl.mm,
+             pl.first == NucFirst::WideMt ? 3072 : ((pl.first == NucFirst::Throughput && pl.four) ? 768 : 1024), pl.bulk, pl.tail);
+    return TWL_OK;
 }
 
 int twl_get_pair_cells(int device, uint64_t *cells_out, int32_t n)

@@ -932,11 +932,9 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
 {
     if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
     const int32_t n = s->n_pairs;
-    s->prepared = false;
     const int32_t staged = s->staged_stride;
-    s->staged_stride = 0;
-    if (n == 0) return TWL_OK;
-    if ((!paths && !from_dp) || !path_len || path_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    // (the arguments are checked BEFORE the level's state is given up -- a rejected call leaves the level as it was, committable)
+    if (n > 0 && ((!paths && !from_dp) || !path_len || path_stride < 1)) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     if (staged && (!from_dp || staged != path_stride)) { g_err = "commit after twl_level_restore: from_dp and the restore's row pitch are required"; return TWL_ERR_BAD_ARGUMENT; }
     if (from_dp && !staged) for (int32_t i = 0; i < n; ++i) if (from_dp[i] == 2) { g_err = "from_dp == 2 without twl_level_restore"; return TWL_ERR_BAD_ARGUMENT; }
     if (from_dp) {
@@ -945,18 +943,20 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
             if (!from_dp[i] && path_len[i] > 0 && !paths) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
         }
     }
-    Device *d = s->d;
-    std::lock_guard<std::mutex> lk(d->mu);
-    struct GiveBack { twl_store *s; ~GiveBack() { release_level(s->lv); } } giveBack{s};      // the level's buffers return to the device's pool
-    HIP_TRY(hipSetDevice(d->id));
-    hipStream_t st = d->stream;
-    const size_t P = (size_t)s->P;
     int32_t maxPath = 0;
     for (int32_t i = 0; i < n; ++i) {
         if (path_len[i] < 0 || path_len[i] > path_stride) { g_err = "path_len outside [0, path_stride]"; return TWL_ERR_BAD_ARGUMENT; }
         maxPath = std::max(maxPath, path_len[i]);
     }
-    if (maxPath == 0) return TWL_OK;
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    s->prepared = false;                       // the commit goes ahead: the level is over whatever happens from here on
+    s->staged_stride = 0;
+    struct GiveBack { twl_store *s; ~GiveBack() { release_level(s->lv); } } giveBack{s};      // the level's buffers return to the device's pool
+    if (n == 0 || maxPath == 0) return TWL_OK;
+    HIP_TRY(hipSetDevice(d->id));
+    hipStream_t st = d->stream;
+    const size_t P = (size_t)s->P;
     int rc;
     if ((rc = grow_rows(s, maxPath))) return rc;
     const int32_t nChunks = (maxPath + 255) / 256;
