@@ -797,26 +797,43 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     if ((rc = lv->d_paths.ensure((size_t)n * (size_t)out_stride))) return rc;
     s->staged_stride = out_stride;
     if (n_sel == 0) return TWL_OK;
+    //  at most 4096 pairs per batch: the work arrays cost ~32 * (2 * seq_len + 1) bytes per pair plus the scratch of the small alignments
+    // (~458 KB per pair once 4096 / n_sel floors at one workgroup); a wide level of a 100 000-leaf tree with a low -r would otherwise ask for tens of GB at
+    // once.  A batch whose arrays cannot be had is handed back (-1: the caller restores those pairs on the host, a path that still exists).
+    constexpr int32_t kBatch = 4096;
+    if (n_sel > kBatch) {
+        d->mu.unlock();
+        int rcAll = TWL_OK;
+        for (int32_t at = 0; at < n_sel && rcAll == TWL_OK; at += kBatch) rcAll = twl_level_restore(s, p, std::min(kBatch, n_sel - at), pairs + at, out_stride, final_len_out + at);
+        d->mu.lock();
+        return rcAll;
+    }
     const size_t ns = (size_t)n_sel;
+    auto handBack = [&](int rcAlloc) {          // out of device memory for this batch: its pairs go back to the host path
+        (void)hipGetLastError();
+        for (int32_t t = 0; t < n_sel; ++t) final_len_out[t] = -1;
+        (void)rcAlloc;
+        return (int)TWL_OK;
+    };
     {
         Arena &A = lv->up_restore;
         if ((rc = A.begin(ns * sizeof(int32_t), 1))) return rc;
         A.put(lv->r_sel, pairs, ns);
         if ((rc = A.flush(st))) return rc;
     }
-    if ((rc = lv->r_oidx.ensure(2 * ns * (sl + 1) * sizeof(int32_t)))) return rc;
-    if ((rc = lv->r_run.ensure(ns * 4 * bstride * sizeof(int32_t)))) return rc;
-    if ((rc = lv->r_seg.ensure(ns * bstride * sizeof(int32_t)))) return rc;
-    if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return rc;
-    if ((rc = lv->r_blist.ensure(ns * bstride * sizeof(int32_t)))) return rc;
+    if ((rc = lv->r_oidx.ensure(2 * ns * (sl + 1) * sizeof(int32_t)))) return handBack(rc);
+    if ((rc = lv->r_run.ensure(ns * 4 * bstride * sizeof(int32_t)))) return handBack(rc);
+    if ((rc = lv->r_seg.ensure(ns * bstride * sizeof(int32_t)))) return handBack(rc);
+    if ((rc = lv->r_aoff.ensure(ns * bstride * sizeof(int32_t)))) return handBack(rc);
+    if ((rc = lv->r_blist.ensure(ns * bstride * sizeof(int32_t)))) return handBack(rc);
     if ((rc = lv->r_nboth.ensure(ns * sizeof(int32_t)))) return rc;
     const unsigned nWch = (unsigned)((bstride + (size_t)twl::kRsThreads * twl::kWrItems - 1) / ((size_t)twl::kRsThreads * twl::kWrItems));      // chunks of boundaries of the longest possible path
-    if ((rc = lv->r_wtot.ensure(ns * nWch * sizeof(int32_t)))) return rc;
-    if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return rc;
+    if ((rc = lv->r_wtot.ensure(ns * nWch * sizeof(int32_t)))) return handBack(rc);
+    if ((rc = lv->r_arena.ensure(ns * (size_t)out_stride))) return handBack(rc);
     if ((rc = lv->r_outlen.ensure((size_t)n * sizeof(int32_t)))) return rc;
     const unsigned nb = (unsigned)std::max(1, std::min(128, 4096 / n_sel));     // one-wave workgroups per pair of the small alignments (<= ~1.8 GB of scratch for the rare large ones)
-    if ((rc = lv->r_tb.ensure(ns * nb * twl::kNwThreads * (size_t)twl::kNwCells))) return rc;
-    if ((rc = lv->r_rows.ensure(ns * nb * twl::kNwThreads * 6 * (size_t)twl::kNwRow * sizeof(float)))) return rc;
+    if ((rc = lv->r_tb.ensure(ns * nb * twl::kNwThreads * (size_t)twl::kNwCells))) return handBack(rc);
+    if ((rc = lv->r_rows.ensure(ns * nb * twl::kNwThreads * 6 * (size_t)twl::kNwRow * sizeof(float)))) return handBack(rc);
     twl::RestoreArgs a{};
     a.aln = (const int8_t *)lv->d_aln.p; a.aln_len = (const int32_t *)lv->d_alnlen.p; a.aln_stride = (int32_t)(2 * sl);
     a.colinfo = (const uint8_t *)lv->d_colinfo.p; a.stride = s->seq_len;
