@@ -299,6 +299,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     const float xdropf = (float)a.xdrop;
     const float gc = a.gap_char;
     const bool gcNZ = (gc != 0.0f);
+    const unsigned long long gcMask = gcNZ ? ~0ull : 0ull;
     if constexpr (SPARSE) {
         for (int t = threadIdx.x; t < 21 * 6; t += C::THREADS) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
     }
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             qM[r][m] = qv[r][m] * a.M[20 + m];
                         }
                     }
-                    q5any[r] = __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
+                    q5any[r] = gcNZ && __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
                     bool bad = false;
 #pragma unroll
                     for (int t = 0; t < P; ++t) bad = bad | div_guard_bad(cb[t]);
@@ -732,15 +733,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             }
                             // the gap-letter terms, :394-395.  With gapCharScore 0 (the deferred pass, groups of > 10 000 sequences: alignment-cpu.cpp:88)
                             // every one of them is +-0 and the running sum keeps its value (up to the sign of a zero, which nothing downstream sees)
-                            if (gcNZ) {
-                                if (q5any[r]) {
+                            // (the test of gapCharScore sits in q5any and in the mask below: as a branch of its own around the two blocks it cost the wide level 2.5 %)
+                            if (q5any[r]) {
 #pragma unroll
-                                    for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
-                                }
-                                if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f)) != 0ull) {
+                                for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
+                            }
+                            if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f) & gcMask) != 0ull) {
 #pragma unroll
-                                    for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
-                                }
+                                for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
                             }
                         } else if constexpr (SPARSE) {
                             // protein column score, :409-433, over the NON-ZERO letters of the reference column only: a skipped letter has r[l] == 0,
