@@ -290,6 +290,9 @@ def random_mt_case(seed):
         batch.len[k, int(rng.integers(0, 2))] = max(1, int(batch.len[k].min() * rng.uniform(0.1, 0.7)))
     marker = int(rng.choice([200, 512, 1024]))
     pk = dict(marker=marker, xdrop=int(rng.choice([600, 2000, 5000])), flen=int(rng.choice([200, 700, 4096])))
+    if not prot and rng.random() < 0.12:      # bands that outgrow the fast window: the 768 -> 1024 -> 3072 -> 4608 row stages, pair scouts (round 4)
+        pk["xdrop"] = int(rng.choice([9000, 14000, 26000, 40000]))
+        pk["flen"] = 4096
     if rng.random() < 0.25:
         pk["gap_char"] = 0.0
     knobs = {api.KNOB_MT_MIN_MARKER: 64, api.KNOB_MT_PERTURB: int(rng.choice([0, 0, 1, 2, 5])), api.KNOB_MT_ROUNDS: int(rng.choice([1, 2, 3])),
