@@ -44,3 +44,8 @@ def test_plan_depends_on_the_matrix_and_on_the_streak(built):
     assert api.plan_describe(twl.make_params(M), _lens(1, 12000), wide_streak=3).startswith("tile-parallel, 3072-row window; mode 2; window 3072")
     assert api.plan_describe(twl.make_params(M), _lens(1, 12000), wide_streak=7).startswith("tile-parallel; mode 2; window 1024")
     assert api.plan_describe(twl.make_params(M), _lens(20, 12000), wide_streak=3).startswith("tile-parallel; mode 2; window 1024")
+    # ... and a level of up to CUs pairs starts wide when three quarters of the previous narrow-first level went on to the wide window; every 6th such call probes
+    assert api.plan_describe(twl.make_params(M), _lens(100, 12000), wide_streak=1001).startswith("tile-parallel, 3072-row window")
+    assert api.plan_describe(twl.make_params(M), _lens(100, 12000), wide_streak=1000).startswith("tile-parallel; mode 2; window 1024")
+    assert api.plan_describe(twl.make_params(M), _lens(100, 12000), wide_streak=1051).startswith("tile-parallel; mode 2; window 1024")
+    assert api.plan_describe(twl.make_params(M), _lens(300, 12000), wide_streak=1001).startswith("tile-parallel; mode 2; window 1024")      # (more pairs than CUs: the fast window first)

@@ -114,6 +114,7 @@ struct Device {
     int comm_world = 0, comm_rank = 0;
     Buf comm_send, comm_recv;                                                    // staging of twl_comm_all_gather_host
     int wide_streak = 0;                                                         // consecutive small calls whose pairs all outgrew the fast window (run_device: wideFirst)
+    int last_wide_pct = 0, wide_calls = 0;                                       // share of the last narrow-first call's pairs that went on to the wide window; calls started wide since
     int mt_launch = 0;                                                           // launches of the tile-parallel level in flight (work counter index)
     char kname[160] = {0};                                                       // the kernel of the first DP launch of the call in flight
     Buf h2d_freq, h2d_gop, h2d_gex, h2d_len, h2d_num, d_aln, d_alnlen, d_err;   // staging for the host form
@@ -316,6 +317,7 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
+int g_scout_xdrop_pct = 100;         // twl_set_knob(TWL_KNOB_SCOUT_XDROP_PCT): X-drop of the pair scouts in percent of the call's (they only predict: a narrower band is a cheaper scout)
 int g_no_spec = 0;                   // twl_set_knob(TWL_KNOB_NO_SPEC): no speculative two-workgroup teams (tools that time the plain tile loop)
 int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
 int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
@@ -393,7 +395,11 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         // global path's crossing of every anti-diagonal; its suffixes are what the tiles' own paths follow.
         int maxRQ = 0;
         for (int t = 0; t < n_run; ++t) maxRQ = std::max(maxRQ, h_len[2 * order[t]] + h_len[2 * order[t] + 1]);
-        if constexpr (P == 6) { if ((rc = launch_mt_kernel<P, SW, SR, MM, 1, 4>(d, st, a, n_run, nullptr, (size_t)(maxRQ >> 3) + 2))) return rc; }
+        if constexpr (P == 6) {
+            twl::NArgs as = a;
+            as.xdrop = (int32_t)((long long)a.xdrop * g_scout_xdrop_pct / 100);
+            if ((rc = launch_mt_kernel<P, SW, SR, MM, 1, 4>(d, st, as, n_run, nullptr, (size_t)(maxRQ >> 3) + 2))) return rc;
+        }
     } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
@@ -424,7 +430,7 @@ struct NucFacts {
     const float *M = nullptr;             // 5 x 5 matrix
     float gap_char = 0;
     bool qry_onehot = false, dump = false;
-    int wide_streak = 0;
+    int wide_streak = 0, last_wide_pct = 0, wide_calls = 0;
     const int32_t *h_len = nullptr;       // [pair][2]
     const int32_t *order = nullptr;       // the pairs that run, longest first
 };
@@ -474,7 +480,10 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
                       sumLen >= 3ll * f.marker * n_run && (2 * n_run <= f.num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
     // the last calls' pairs all outgrew the fast window (the deferred pass: one pair per level against the same growing root): no point in finding
     // that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
-    const bool wideFirst = k.mt_wide && n_run <= 8 && f.wide_streak >= 2 && (f.wide_streak & 7) != 7;
+    // ... and so for a level of up to CUs pairs when three quarters of the previous narrow-first level's pairs went on to the wide window (the upper levels
+    // of a family whose pairs outgrow the fast window: their narrow attempts cost 40-80 ms each in tiles computed in line up to the overflow); every 6th probes
+    const bool wideFirst = k.mt_wide && ((n_run <= 8 && f.wide_streak >= 2 && (f.wide_streak & 7) != 7) ||
+                                         (n_run <= f.num_cu && f.last_wide_pct >= 75 && (f.wide_calls % 6) != 5));
     if (f.dump) pl.first = NucFirst::Dump;
     else if (mtOk && wideFirst) pl.first = NucFirst::WideMt;
     else if (mtOk) pl.first = NucFirst::Mt;
@@ -696,7 +705,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else {
         NucFacts nf;
         nf.n_run = n_run; nf.num_cu = d->num_cu; nf.marker = p->marker; nf.M = a.M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot; nf.dump = d->dump_on;
-        nf.wide_streak = d->wide_streak; nf.h_len = h_len; nf.order = order.data();
+        nf.wide_streak = d->wide_streak; nf.last_wide_pct = d->last_wide_pct; nf.wide_calls = d->wide_calls; nf.h_len = h_len; nf.order = order.data();
         const NucPlan pl = plan_nucleotide(nf, current_knobs());
         const int mm = pl.mm;
         const bool mm5 = pl.mm5;
@@ -782,6 +791,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     std::vector<unsigned long long> cells((size_t)n_pairs);
     unsigned long long mtStat[4] = {0, 0, 0, 0};
     bool redoMt = false;      // a re-run went through the tile-parallel path (launch_mt, WIDE)
+    int widePairs = 0;        // pairs that went on to the wide window
     // (one small kernel writes them into a pinned host block: three device-to-host copies into pageable memory before)
     const size_t resBytes = 4 * sizeof(unsigned long long) + (size_t)n_pairs * (sizeof(unsigned long long) + sizeof(int32_t) + sizeof(int16_t));
     if (resBytes > d->res_cap) {
@@ -834,6 +844,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             long long redoLen = 0;
             for (int32_t n : redo) redoLen += (long long)h_len[2 * n] + h_len[2 * n + 1];
             const bool wideMt = g_mt_wide && (int)redo.size() <= g_mt_max_pairs && p->marker >= g_mt_min_marker && redoLen >= 3ll * p->marker * (long long)redo.size();
+            widePairs += (int)redo.size();
             if (wideMt) { rc = launch_mt<6, 2, 3, true, 4>(d, st, a, (const int32_t *)d->items.p, redo, (int)redo.size(), h_len, &grid2, &w2); redoMt = true; }
             else rc = launch_lean<6, 8, 4, 2, 2>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
         }
@@ -852,6 +863,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     // how the fast window fared (see wideFirst): every pair of a small call outgrew it / the call started wide -> the streak goes on
     if (!prot && leanMid && n_run > 0 && n_run <= 8) d->wide_streak = (startedWide || (redoMt && d->stats.n_relaunched >= n_run)) ? d->wide_streak + 1 : 0;
+    if (!prot && leanMid && n_run > 0) {
+        if (startedWide) d->wide_calls += 1;
+        else { d->last_wide_pct = (int)(100ll * widePairs / n_run); d->wide_calls = 0; }
+    }
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     if (reran) {
         const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
@@ -1274,6 +1289,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_TAIL_PCT: g_mt_tail_pct = std::max(0, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }
@@ -1404,6 +1420,7 @@ int twl_comm_destroy(int device)
 // The launch plan of a nucleotide call, as run_device would make it, in words: no device is touched (unit tests of the policy on a CPU-only box).
 int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, int32_t num_cu, int32_t qry_onehot, int32_t wide_streak, char *out, int32_t cap)
 {
+    // (wide_streak >= 1000 encodes the other memory of the device: 1000 + 10 * calls started wide + (1 if three quarters of the last narrow-first call went wide))
     if (!p || p->P != 6 || n_pairs < 0 || (n_pairs > 0 && !len) || num_cu < 1 || !out || cap < 64) { g_err = "bad argument (nucleotide parameters, a buffer of 64+ bytes)"; return TWL_ERR_BAD_ARGUMENT; }
     std::vector<int32_t> order;
     for (int32_t n = 0; n < n_pairs; ++n) if (len[2 * n] > 0 && len[2 * n + 1] > 0) order.push_back(n);
@@ -1411,7 +1428,8 @@ int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, 
     float M[25];
     for (int t = 0; t < 25; ++t) M[t] = p->matrix[t];
     NucFacts nf;
-    nf.n_run = (int)order.size(); nf.num_cu = num_cu; nf.marker = p->marker; nf.M = M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot != 0; nf.wide_streak = wide_streak;
+    nf.n_run = (int)order.size(); nf.num_cu = num_cu; nf.marker = p->marker; nf.M = M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot != 0; nf.wide_streak = wide_streak < 1000 ? wide_streak : 0;
+    if (wide_streak >= 1000) { nf.last_wide_pct = ((wide_streak - 1000) % 10) ? 100 : 0; nf.wide_calls = (wide_streak - 1000) / 10; }
     nf.h_len = len; nf.order = order.data();
     const NucPlan pl = plan_nucleotide(nf, current_knobs());
     snprintf(out, (size_t)cap, "%s; mode %d; window %d; bulk %d tail %d", nuc_first_name(pl.first), pl.mm5 ? 5 : pl.mm,
