@@ -482,8 +482,8 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
     // that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
     // ... and so for a level of up to CUs pairs when three quarters of the previous narrow-first level's pairs went on to the wide window (the upper levels
     // of a family whose pairs outgrow the fast window: their narrow attempts cost 40-80 ms each in tiles computed in line up to the overflow); every 6th probes
-    const bool wideFirst = k.mt_wide && ((n_run <= 8 && f.wide_streak >= 2 && (f.wide_streak & 7) != 7) ||
-                                         (n_run <= f.num_cu && f.last_wide_pct >= 75 && (f.wide_calls % 6) != 5));
+    const bool wideFirst = k.mt_wide && (n_run <= 8 ? (f.wide_streak >= 2 && (f.wide_streak & 7) != 7)
+                                                    : (n_run <= f.num_cu && f.last_wide_pct >= 75 && (f.wide_calls % 6) != 5));
     if (f.dump) pl.first = NucFirst::Dump;
     else if (mtOk && wideFirst) pl.first = NucFirst::WideMt;
     else if (mtOk) pl.first = NucFirst::Mt;
