@@ -57,6 +57,12 @@ int  twl_store_read_rows(twl_store *s, char *const *rows_out, int32_t *lens_out)
 int  twl_store_read_rows_of(twl_store *s, int32_t n_ids, const int32_t *ids, char *out, int32_t *lens_out);
 int  twl_store_write_rows(twl_store *s, int32_t n_ids, const int32_t *ids, const char *in, const int32_t *lens);
 int  twl_store_write_cache(twl_store *s, int32_t id, const float *data, int32_t len);
+/* The same two on DEVICE blocks, for collectives that move device memory (RCCL over xGMI): rows_to_block packs the current rows of `ids` back to back at
+   dev_block (lens_out their lengths), rows_from_block makes the rows found at dev_block the current rows of `ids`; exchange_buffers hands out two device
+   buffers of the store (send, recv) of at least the given sizes. */
+int  twl_store_rows_to_block(twl_store *s, int32_t n_ids, const int32_t *ids, void *dev_block, int32_t *lens_out);
+int  twl_store_rows_from_block(twl_store *s, int32_t n_ids, const int32_t *ids, const int32_t *lens, const void *dev_block);
+int  twl_store_exchange_buffers(twl_store *s, int64_t send_bytes, int64_t recv_bytes, void **send_dev, void **recv_dev);
 /* Cached profile `id` as float[len][P]; len_out receives its length; out may be NULL to query the length. */
 int  twl_store_read_cache(twl_store *s, int32_t id, float *out, int32_t *len_out);
 int  twl_store_drop_cache(twl_store *s, int32_t id);

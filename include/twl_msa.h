@@ -26,6 +26,7 @@ typedef struct twl_msa twl_msa;
      --test-cal-profile-th n, --test-update-seq-th n   the reference's _CAL_PROFILE_TH / _UPDATE_SEQ_TH (msa.hpp:179-180, both 1000): lowered by tests so
                                 that small trees reach the cached-profile and compressed-group branches
      --test-virtual-devices n   n replicas of the store on ONE device: the several-replica code path of the resident level kernel on a one-GPU box
+     --test-no-ownership        a sharded run deals and exchanges every level (the design before subtree ownership; tests hold the two to each other)
    Environment: TWL_OMP_THREADS (host threads of the library; default: what OpenMP picks) and TWL_DEBUG (traces the launches of libtwl_align on stderr).
    Nothing in the environment changes a result or a launch. */
 

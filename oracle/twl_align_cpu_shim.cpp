@@ -75,6 +75,9 @@ int twl_set_knob(int, int) { return TWL_ERR_UNSUPPORTED; }
 int twl_store_read_rows_of(twl_store *, int32_t, const int32_t *, char *, int32_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_store_write_rows(twl_store *, int32_t, const int32_t *, const char *, const int32_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_store_write_cache(twl_store *, int32_t, const float *, int32_t) { return TWL_ERR_UNSUPPORTED; }
+int twl_store_rows_to_block(twl_store *, int32_t, const int32_t *, void *, int32_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_store_rows_from_block(twl_store *, int32_t, const int32_t *, const int32_t *, const void *) { return TWL_ERR_UNSUPPORTED; }
+int twl_store_exchange_buffers(twl_store *, int64_t, int64_t, void **, void **) { return TWL_ERR_UNSUPPORTED; }
 int twl_comm_unique_id(void *) { return TWL_ERR_UNSUPPORTED; }
 int twl_comm_init(int, int, int, const void *) { return TWL_ERR_UNSUPPORTED; }
 int twl_comm_all_gather(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }

@@ -60,6 +60,22 @@ def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exc
 
 
 @pytest.mark.timeout(900)
+def test_two_processes_without_subtree_ownership(built, tmp_path):
+    """--test-no-ownership: every level dealt and exchanged (the design of round 3) -- the same MSA, and an exchange on every level."""
+    import torch.multiprocessing as mp
+
+    name = "nuc_deferrals_cache_compress"
+    _, fam, ins, flags, env = [v for v in VARIANTS if v[0] == name][0]
+    d = str(tmp_path)
+    t, f, typ = write_family(d, fam, ins)
+    mp.start_processes(_worker, args=(2, _free_port(), t, f, d, typ, list(flags) + ["--test-no-ownership"], env, True), nprocs=2, join=True, start_method="spawn")
+    fx = FIX[name]
+    for rank in range(2):
+        assert hashlib.md5(open(os.path.join(d, f"rank{rank}.aln"), "rb").read()).hexdigest() == fx["md5"], f"rank {rank}"
+        assert all(v > 0 for v in np.load(os.path.join(d, f"rank{rank}_x.npy")))
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("device_exchange", [False, True])
 @pytest.mark.parametrize("name", ["nuc_default", "nuc_r0.7", "nuc_deferrals_cache_compress", "nuc_length_deviation_filter", "prot_cache_and_compress",
                                   "nuc_10500_leaves_more_than_10000_on_one_side", "nuc_xdrop_failure_retried_in_deferred_pass"])

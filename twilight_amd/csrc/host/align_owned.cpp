@@ -87,7 +87,7 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
     RunCtx &ctx = ctxOf(database);
     const Shard sh = ctx.shard;
     if (sh.world <= 1 || database->currentTask != 0 || !(sh.rccl || sh.exchange) || ctx.finished) return 0;
-    if (getenv("TWL_NO_OWNERSHIP")) return 0;      // (development: the round-3 behaviour, every level dealt and exchanged)
+    if (option->testNoOwnership) return 0;         // (--test-no-ownership: the round-3 behaviour, every level dealt and exchanged)
     const int nLevels = (int)levels.size();
     // ---- the cut: the highest level that leaves >= 8 subtrees per rank; none such -> every level is dealt as before ----
     const long long want = 8ll * sh.world;
@@ -200,25 +200,55 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
         w.put<int32_t>(r.mt_predicted); w.put<int32_t>(r.mt_inline); w.put<int32_t>(r.matrix_mode); w.put<int32_t>(r.speculative);
         w.bytes(r.kernel, sizeof r.kernel);
     }
+    // The rows travel HBM to HBM when the run has a device collective (the library's RCCL communicator, or the caller's device callback): packed into one
+    // device block per rank, all-gathered, unpacked by a kernel -- 10 000 x 10 kbp at 8 ranks is ~140 MB of rows at the cut, which would otherwise cross
+    // PCIe twice.  Without one (host callback only) they ride in the host block.
+    const bool rowsOnDevice = sh.rccl || sh.exchangeDev != nullptr;
+    std::vector<int32_t> myLens;
+    size_t myRowBytes = 0;
     {   // rows (and the low-quality flags fallback2cpu may have cleared) of the sequences in my subtrees
         std::sort(mySeqs.begin(), mySeqs.end());
         mySeqs.erase(std::unique(mySeqs.begin(), mySeqs.end()), mySeqs.end());
-        std::vector<int32_t> lens(mySeqs.size());
-        int rc = twl_store_read_rows_of(store, (int32_t)mySeqs.size(), mySeqs.data(), nullptr, lens.data());
+        myLens.resize(mySeqs.size());
+        int rc = twl_store_read_rows_of(store, (int32_t)mySeqs.size(), mySeqs.data(), nullptr, myLens.data());
         if (rc != TWL_OK) die("twl_store_read_rows_of", rc);
-        size_t total = 0;
-        for (int32_t x : lens) total += (size_t)x;
+        for (int32_t x : myLens) myRowBytes += (size_t)x;
         w.put<int32_t>((int32_t)mySeqs.size());
         w.bytes(mySeqs.data(), mySeqs.size() * sizeof(int32_t));
-        w.bytes(lens.data(), lens.size() * sizeof(int32_t));
+        w.bytes(myLens.data(), myLens.size() * sizeof(int32_t));
         for (int32_t s : mySeqs) w.put<uint8_t>(database->sequences[s]->lowQuality ? 1 : 0);
         w.align8();
-        w.put<uint64_t>((uint64_t)total);
-        const size_t at = w.b.size();
-        w.b.resize(at + total);
-        if ((rc = twl_store_read_rows_of(store, (int32_t)mySeqs.size(), mySeqs.data(), w.b.data() + at, lens.data())) != TWL_OK) die("twl_store_read_rows_of", rc);
+        w.put<uint64_t>((uint64_t)myRowBytes);
+        w.put<uint64_t>(rowsOnDevice ? 1 : 0);
+        if (!rowsOnDevice) {
+            const size_t at = w.b.size();
+            w.b.resize(at + myRowBytes);
+            if ((rc = twl_store_read_rows_of(store, (int32_t)mySeqs.size(), mySeqs.data(), w.b.data() + at, myLens.data())) != TWL_OK) die("twl_store_read_rows_of", rc);
+        }
     }
     std::vector<std::vector<char>> blobs = allGatherBlobs(ctx, w.b);
+    // ... then the device blocks: every rank knows every rank's row bytes from the host blocks
+    void *rowsRecv = nullptr;
+    size_t rowsBlk = 0;
+    if (rowsOnDevice) {
+        for (int r = 0; r < sh.world; ++r) {
+            Reader probe{blobs[r].data(), blobs[r].size()};
+            // (the row-bytes field sits right in front of the flag at the end of the block)
+            if (blobs[r].size() < 16) { std::cerr << "ERROR: malformed subtree block from rank " << r << ".\n"; exit(1); }
+            uint64_t rb; memcpy(&rb, blobs[r].data() + blobs[r].size() - 16, 8);
+            rowsBlk = std::max(rowsBlk, (size_t)rb);
+            (void)probe;
+        }
+        rowsBlk = (rowsBlk + 255) & ~(size_t)255;
+        if (rowsBlk > 0) {
+            void *rowsSend = nullptr;
+            int rc = twl_store_exchange_buffers(store, (int64_t)rowsBlk, (int64_t)(rowsBlk * (size_t)sh.world), &rowsSend, &rowsRecv);
+            if (rc != TWL_OK) die("twl_store_exchange_buffers", rc);
+            if ((rc = twl_store_rows_to_block(store, (int32_t)mySeqs.size(), mySeqs.data(), rowsSend, myLens.data())) != TWL_OK) die("twl_store_rows_to_block", rc);
+            const int xrc = sh.rccl ? twl_comm_all_gather(selectedDevices()[0], rowsSend, rowsRecv, (int64_t)rowsBlk) : sh.exchangeDev(sh.userDev, rowsSend, (int64_t)rowsBlk, rowsRecv);
+            if (xrc != 0) { std::cerr << "ERROR: device exchange of the subtrees' rows failed (" << xrc << "): " << twl_last_error() << '\n'; exit(1); }
+        }
+    }
 
     // ---- import the others' subtrees; merge the deferred lists and the level records ----
     struct Tagged { int level, idx; Node *node; };
@@ -273,7 +303,9 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
         const char *lowq = rd.bytes((size_t)nSeqs);
         rd.align8();
         const uint64_t total = rd.get<uint64_t>();
-        const char *rows = rd.bytes((size_t)total);
+        const bool onDev = rd.get<uint64_t>() != 0;
+        const char *rows = onDev ? nullptr : rd.bytes((size_t)total);
+        if (onDev != rowsOnDevice) { std::cerr << "ERROR: the ranks disagree on how the subtrees' rows travel.\n"; exit(1); }
         if (r == sh.rank || nSeqs == 0) continue;
         std::vector<int32_t> idv((size_t)nSeqs), lenv((size_t)nSeqs);
         memcpy(idv.data(), ids, idv.size() * sizeof(int32_t));
@@ -282,8 +314,9 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
             if (idv[t] < 0 || idv[t] >= (int)database->sequences.size()) { std::cerr << "ERROR: malformed subtree block from rank " << r << ".\n"; exit(1); }
             database->sequences[idv[t]]->lowQuality = lowq[t] != 0;
         }
-        const int rc = twl_store_write_rows(store, nSeqs, idv.data(), rows, lenv.data());
-        if (rc != TWL_OK) die("twl_store_write_rows", rc);
+        const int rc = onDev ? twl_store_rows_from_block(store, nSeqs, idv.data(), lenv.data(), static_cast<const char *>(rowsRecv) + rowsBlk * (size_t)r)
+                             : twl_store_write_rows(store, nSeqs, idv.data(), rows, lenv.data());
+        if (rc != TWL_OK) die(onDev ? "twl_store_rows_from_block" : "twl_store_write_rows", rc);
     }
     std::stable_sort(deferredAll.begin(), deferredAll.end(), [](const Tagged &a, const Tagged &b) { return a.level != b.level ? a.level < b.level : a.idx < b.idx; });
     database->fallback_nodes.clear();

@@ -120,6 +120,7 @@ struct Option {
     bool alignGappy = true;
     std::string treeFile, seqFile, outFile;
     bool printDetail = false;    // -v
+    bool testNoOwnership = false; // --test-no-ownership: a sharded run deals and exchanges every level (no subtree ownership below a cut)
     int testVirtualDevices = 0;  // --test-virtual-devices n: n replicas of the store on the first device (the several-replica path of the resident kernel on a one-GPU box)
     bool hostStaged = false;     // --host-staged: build profiles on the host and stage them per level (default: device-resident rows)
     // scoring flags (consumed by Params)

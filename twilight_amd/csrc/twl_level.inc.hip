@@ -208,6 +208,7 @@ struct twl_store {
     LevelBufs *lv = nullptr;     // the level's device buffers, held from prepare to commit (from the device's pool, see LevelBufs)
     int32_t staged_stride = 0;   // > 0: twl_level_restore put this level's DP paths (and the restored ones) into lv->d_paths at this row pitch
     Buf d_gather, d_off, d_plane, d_rowlen;
+    Buf x_send, x_recv;          // device blocks of the subtree exchange of a sharded run (twl_store_exchange_buffers)
     double prepare_ms = 0, commit_ms = 0;
 };
 
@@ -294,7 +295,7 @@ void store_destroy_locked(twl_store *s)
     (void)hipStreamSynchronize(s->d->stream2);
     for (auto &kv : s->cache) { cache_buf_put(s->d, kv.second->buf); delete kv.second; }
     release_level(s->lv);
-    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen})
+    for (Buf *b : {&s->rows[0], &s->rows[1], &s->lut, &s->d_gather, &s->d_off, &s->d_plane, &s->d_rowlen, &s->x_send, &s->x_recv})
         b->release();
     s->d->live_stores -= 1;
     delete s;
@@ -472,6 +473,69 @@ int twl_store_write_rows(twl_store *s, int32_t n_ids, const int32_t *ids, const 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(d->stream));
     for (int32_t t = 0; t < n_ids; ++t) s->len[ids[t]] = lens[t];
+    return TWL_OK;
+}
+
+// The same two on DEVICE blocks (the rows of a sharded run's subtrees travel HBM to HBM): rows_to_block packs the current rows of `ids` back to back at
+// dev_block (lens_out their lengths), rows_from_block makes the rows found there the current rows.  twl_store_exchange_buffers: two device buffers of the store.
+static int rows_block(twl_store *s, bool toBlock, int32_t n_ids, const int32_t *ids, const int32_t *lens, void *dev_block)
+{
+    std::vector<int64_t> off((size_t)n_ids);
+    std::vector<int32_t> ln(lens, lens + n_ids);
+    int64_t total = 0;
+    int32_t maxLen = 1;
+    for (int32_t t = 0; t < n_ids; ++t) { off[t] = total; total += lens[t]; maxLen = std::max(maxLen, lens[t]); }
+    Device *d = s->d;
+    int rc;
+    if (s->rows_event) { HIP_TRY(hipStreamWaitEvent(d->stream, s->rows_event, 0)); s->rows_event = nullptr; }
+    if (!toBlock && (rc = grow_rows(s, (int64_t)maxLen + 1))) return rc;
+    if ((rc = s->d_gather.ensure((size_t)n_ids * 4 + 64))) return rc;
+    if ((rc = upload(s->d_off, off, d->stream))) return rc;
+    if ((rc = upload(s->d_plane, s->plane, d->stream))) return rc;
+    if ((rc = upload(s->d_rowlen, ln, d->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_gather.p, ids, (size_t)n_ids * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
+    const dim3 grid((unsigned)n_ids, (unsigned)((maxLen + 255) / 256));
+    if (toBlock)
+        hipLaunchKernelGGL(twl::gather_rows_of_kernel, grid, dim3(256), 0, d->stream, (const char *)s->rows[0].p, (const char *)s->rows[1].p, s->cap, (const uint8_t *)s->d_plane.p,
+                           (const int32_t *)s->d_gather.p, (const int32_t *)s->d_rowlen.p, (const int64_t *)s->d_off.p, (char *)dev_block);
+    else
+        hipLaunchKernelGGL(twl::scatter_rows_of_kernel, grid, dim3(256), 0, d->stream, (char *)s->rows[0].p, (char *)s->rows[1].p, s->cap, (const uint8_t *)s->d_plane.p,
+                           (const int32_t *)s->d_gather.p, (const int32_t *)s->d_rowlen.p, (const int64_t *)s->d_off.p, (const char *)dev_block);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (!toBlock) for (int32_t t = 0; t < n_ids; ++t) s->len[ids[t]] = lens[t];
+    return TWL_OK;
+}
+int twl_store_rows_to_block(twl_store *s, int32_t n_ids, const int32_t *ids, void *dev_block, int32_t *lens_out)
+{
+    if (!s || n_ids < 0 || (n_ids > 0 && (!ids || !lens_out || !dev_block))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    for (int32_t t = 0; t < n_ids; ++t) {
+        if (ids[t] < 0 || ids[t] >= s->n_seqs) { g_err = "sequence id out of range"; return TWL_ERR_BAD_ARGUMENT; }
+        lens_out[t] = s->len[ids[t]];
+    }
+    if (n_ids == 0) return TWL_OK;
+    std::lock_guard<std::mutex> lk(s->d->mu);
+    HIP_TRY(hipSetDevice(s->d->id));
+    return rows_block(s, true, n_ids, ids, lens_out, dev_block);
+}
+int twl_store_rows_from_block(twl_store *s, int32_t n_ids, const int32_t *ids, const int32_t *lens, const void *dev_block)
+{
+    if (!s || n_ids < 0 || (n_ids > 0 && (!ids || !lens || !dev_block))) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    for (int32_t t = 0; t < n_ids; ++t) if (ids[t] < 0 || ids[t] >= s->n_seqs || lens[t] < 0) { g_err = "sequence id or length out of range"; return TWL_ERR_BAD_ARGUMENT; }
+    if (n_ids == 0) return TWL_OK;
+    std::lock_guard<std::mutex> lk(s->d->mu);
+    HIP_TRY(hipSetDevice(s->d->id));
+    return rows_block(s, false, n_ids, ids, lens, const_cast<void *>(dev_block));
+}
+int twl_store_exchange_buffers(twl_store *s, int64_t send_bytes, int64_t recv_bytes, void **send_dev, void **recv_dev)
+{
+    if (!s || send_bytes < 0 || recv_bytes < 0 || !send_dev || !recv_dev) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    std::lock_guard<std::mutex> lk(s->d->mu);
+    HIP_TRY(hipSetDevice(s->d->id));
+    int rc;
+    if ((rc = s->x_send.ensure((size_t)std::max<int64_t>(send_bytes, 16)))) return rc;
+    if ((rc = s->x_recv.ensure((size_t)std::max<int64_t>(recv_bytes, 16)))) return rc;
+    *send_dev = s->x_send.p; *recv_dev = s->x_recv.p;
     return TWL_OK;
 }
 

@@ -16,7 +16,7 @@ class TwlSide(C.Structure):
                 ("cache_id", C.c_int32), ("store_id", C.c_int32), ("reserved", C.c_int32)]
 
 
-_SYMBOLS = ["twl_store_create", "twl_store_destroy", "twl_store_read_rows", "twl_store_read_rows_of", "twl_store_write_rows", "twl_store_write_cache", "twl_store_read_cache", "twl_store_drop_cache",
+_SYMBOLS = ["twl_store_create", "twl_store_destroy", "twl_store_read_rows", "twl_store_read_rows_of", "twl_store_write_rows", "twl_store_write_cache", "twl_store_rows_to_block", "twl_store_rows_from_block", "twl_store_exchange_buffers", "twl_store_read_cache", "twl_store_drop_cache",
             "twl_level_prepare", "twl_level_read_colinfo", "twl_level_read_colinfo_many", "twl_level_align", "twl_level_read_path", "twl_level_read_paths", "twl_level_commit", "twl_level_commit_from_dp", "twl_level_read_columns", "twl_level_timing",
             "twl_level_restore", "twl_level_read_final", "twl_level_exchange_buffers", "twl_level_paths_to_block", "twl_level_paths_from_block",
             "twl_level_write_final"]
