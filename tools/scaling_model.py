@@ -6,7 +6,8 @@ Assumptions, all from the single-GPU level table:
   * below the cut a rank runs 1/N of every level's DP time, but never less per level than the level floor (one tile's latency + scouts: the smallest
     level time of the run), and only for levels in which an average subtree still has a pair (pairs_at_level >= subtrees);
   * the non-DP time of the pass divides by N below the cut and is replicated above it (in proportion to the pairs);
-  * the exchange at the cut moves every rank's rows through PCIe twice (25 GB/s) + 2 ms; above the cut one all-gather per level (0.15 ms);
+  * the exchange at the cut all-gathers the subtrees' rows HBM to HBM (rows ~1.5 x the sequence length at the cut; 100 GB/s effective per rank over xGMI)
+    + 3 ms for the host blocks (node state, cached profiles) and the pack / unpack kernels; above the cut one all-gather per level (0.15 ms);
   * above the cut a level costs max(t / N, floor)."""
 import json, sys
 
@@ -19,7 +20,7 @@ kms = [l["kernel_ms"] for l in main]
 floor = min(kms)
 t1 = d["ms_per_step"]
 nondp = t1 - sum(kms)
-rows_bytes = d["config"]["n_sequences"] * d["config"]["aln_len"] * 0.5      # rows are on average half their final length at the cut
+rows_bytes = d["config"]["n_sequences"] * d["config"]["seq_length"] * 1.5
 print(f"single GPU: {t1:.1f} ms per pass, DP {sum(kms):.1f} ms over {len(kms)} levels, level floor {floor:.2f} ms, non-DP {nondp:.1f} ms")
 for n in ranks:
     if n == 1:
@@ -46,7 +47,7 @@ for n in ranks:
     n_pairs = sum(pairs)
     nd_below = nondp * sum(pairs[:cut + 1]) / n_pairs / n
     nd_top = nondp * sum(pairs[cut + 1:]) / n_pairs
-    exch = 2.0 + 2 * rows_bytes / 25e9 * 1e3 + 0.15 * (len(kms) - cut - 1)
+    exch = 3.0 + rows_bytes * (n - 1) / n / 100e9 * 1e3 + 0.15 * (len(kms) - cut - 1)
     t = below + top + nd_below + nd_top + exch
     print(f"N = {n}: cut after level {cut + 1} ({subtrees} subtrees, {sum(pairs[cut + 1:])} pairs above); below {below:.1f} + above {top:.1f} + non-DP {nd_below + nd_top:.1f} + exchange {exch:.1f} "
           f"= {t:.1f} ms -> {t1 / t:.2f}x")
