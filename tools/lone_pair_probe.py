@@ -1,5 +1,5 @@
 """Development aid: a lone pair / a few pairs through the tile-parallel path on either geometry of its tile launches (TWL_KNOB_MT_THR_JOBS).
-   python tools/lone_pair_probe.py <pairs> <length> <thr_jobs>"""
+   python tools/lone_pair_probe.py <pairs> <length> <thr_jobs> [library.so]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +8,8 @@ from twilight_amd import synth, api
 import torch
 import twilight_amd as twl
 n = int(sys.argv[1]); length = int(sys.argv[2]); thr = int(sys.argv[3])
+if len(sys.argv) > 4 and sys.argv[4] != "base":
+    api.LIB_PATH = os.path.abspath(sys.argv[4])
 b = synth.make_level_batch(min(n, 8), length, members=((1, 8), (1, 8)), seed=5)
 twl.init([0])
 twl.set_knob(api.KNOB_MT_THR_JOBS, thr)
@@ -24,4 +26,4 @@ for r in range(5):
     torch.cuda.synchronize()
     st = twl.get_stats(0)
     if r: best = min(best, st.kernel_ms)
-print(f"pairs {n} len {length} thr_jobs {thr}: kernel {best:.3f} ms, tiles {st.mt_tiles_predicted}/{st.mt_tiles_inline}, {st.kernel.decode()[:70]}", flush=True)
+print(f"{os.path.basename(sys.argv[4]) if len(sys.argv) > 4 else 'base':20s} pairs {n} len {length} thr_jobs {thr}: kernel {best:.3f} ms, tiles {st.mt_tiles_predicted}/{st.mt_tiles_inline}, {st.kernel.decode()[:70]}", flush=True)

@@ -333,7 +333,11 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     // 1024-row window of the fast geometries.  Until round 4 those ran their ~20 tiles one after the other on the 2048- and 4608-row kernels
     // (0.2-0.6 s per 10 kbp pair); their tiles are as independent as anybody's.  The scouts keep the narrow geometry: a scout's band opens
     // from one cell by a row per diagonal over the ~400 diagonals it runs.
+#if defined(TWL_EXP_LAT_W)      // geometry experiments of the latency launches (tools/lone_pair_probe.py on cross-compiled variants)
+    constexpr int SW = WIDE ? 16 : TWL_EXP_LAT_W, SR = WIDE ? 3 : TWL_EXP_LAT_RPL;
+#else
     constexpr int SW = 16, SR = WIDE ? 3 : 1;       // geometry of the stitch launch and of tiles while they fit the device at once
+#endif
     if (window_out) *window_out = twl::NCfg<SW, SR>::WINDOW;
     const int marker = base.marker;
     const int slots = (2 * base.seq_len) / (marker - 1) + 2;
@@ -403,7 +407,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
-        rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, 16, 1, MM, 1, 2>(d, st, a, nScout);
+        rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, WIDE ? 16 : SW, WIDE ? 1 : SR, MM, 1, 2>(d, st, a, nScout);
         if (rc) return rc;
     }
     for (int r = 0; r < rounds; ++r) {
