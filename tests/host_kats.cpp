@@ -3,6 +3,8 @@
 #include "../twilight_amd/csrc/host/twl_host.hpp"
 
 #include <random>
+#include <functional>
+#include <unordered_map>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -263,6 +265,54 @@ int main(int argc, char **argv)
         progressive::scheduling(sub->root, levels, 0);
         size_t pairs = 0; for (auto &l : levels) pairs += l.size();
         CHECK("schedule_has_n_minus_1_pairs", pairs == 4 && !levels.empty() && !levels[0].empty());
+        delete sub;
+    }
+    // ---- subtree ownership of a sharded run (progressive::planOwnership; used by gpu/align_owned.cpp) ----
+    {
+        // a random binary tree of 600 leaves with uniform splits (as twilight_amd/synth.py makes them: unbalanced on purpose)
+        std::mt19937 rng(12345);
+        int leafNo = 0;
+        std::function<std::string(int)> grow = [&](int n) -> std::string {
+            if (n == 1) return "s" + std::to_string(leafNo++) + ":0.01";
+            const int left = 1 + (int)(rng() % (unsigned)(n - 1));
+            return "(" + grow(left) + "," + grow(n - left) + "):0.01";
+        };
+        const std::string f = tmp + "/own.nwk";
+        { std::ofstream o(f); o << grow(600) << ";\n"; }
+        Tree T(f);
+        phylogeny::assignSinglePartition(T.root);
+        Tree *sub = new Tree(T.root, true);
+        std::vector<NodePairVec> levels;
+        progressive::scheduling(sub->root, levels, 0);
+        for (int world : {2, 4, 8}) {
+            const progressive::OwnershipPlan plan = progressive::planOwnership(sub, levels, world);
+            bool ok = plan.cut >= 0 && plan.cut + 1 < (int)levels.size() && (int)plan.owner.size() == plan.cut + 1 && (int)plan.load.size() == world;
+            long long below = 0, aboveP = 0;
+            for (int l = 0; l < (int)levels.size(); ++l) (l <= plan.cut ? below : aboveP) += (long long)levels[l].size();
+            ok = ok && aboveP + 1 >= 8 * world;                                   // the cut leaves 8 subtrees per rank ...
+            long long aboveNext = aboveP - (long long)levels[plan.cut + 1].size();
+            ok = ok && (plan.cut + 2 >= (int)levels.size() || aboveNext + 1 < 8 * world);   // ... and is the highest level that does
+            long long sum = 0, mx = 0;
+            for (long long x : plan.load) { sum += x; mx = std::max(mx, x); }
+            ok = ok && sum == below && plan.subtrees >= 4 * world;                  // (leaves that only take part above the cut are subtrees without a pair: not counted)
+            ok = ok && mx * world <= (world <= 4 ? 2 : 3) * sum + 8 * world;      // the longest-first deal of >= 8 subtrees per rank keeps the loads together (a 10 000-leaf tree: within 0.3 %)
+            // data flow stays inside an owner: whoever produced an operand (or the child an internal operand adopts from) owns the pair that consumes it
+            std::unordered_map<const Node *, int> producer;
+            for (int l = 0; l <= plan.cut && ok; ++l)
+                for (size_t i = 0; i < levels[l].size() && ok; ++i) {
+                    const int me = plan.owner[l][i];
+                    ok = ok && me >= 0 && me < world;
+                    for (const Node *x : {levels[l][i].first, levels[l][i].second}) {
+                        if (producer.count(x)) ok = ok && producer[x] == me;
+                        if (!x->is_leaf()) for (const Node *c : x->children) if (producer.count(c)) ok = ok && producer[c] == me;
+                    }
+                    producer[levels[l][i].first] = me; producer[levels[l][i].second] = me;
+                }
+            CHECK(("ownership_plan_world_" + std::to_string(world)).c_str(), ok);
+        }
+        const progressive::OwnershipPlan none = progressive::planOwnership(sub, levels, 200);      // 8 x 200 subtrees do not exist in a 600-leaf tree
+        CHECK("ownership_plan_none_for_too_many_ranks", none.cut == -1 && none.owner.empty());
+        CHECK("ownership_plan_none_for_one_rank", progressive::planOwnership(sub, levels, 1).cut == -1);
         delete sub;
     }
     return g_fail ? 1 : 0;

@@ -71,12 +71,6 @@ std::vector<std::vector<char>> allGatherBlobs(RunCtx &ctx, const std::vector<cha
     return out;
 }
 
-struct UnionFind {
-    std::vector<int> p;
-    int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
-    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
-};
-
 constexpr uint64_t kMagic = 0x54574C4F574E4544ull;      // "TWLOWNED"
 
 }  // namespace
@@ -88,53 +82,17 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
     const Shard sh = ctx.shard;
     if (sh.world <= 1 || database->currentTask != 0 || !(sh.rccl || sh.exchange) || ctx.finished) return 0;
     if (option->testNoOwnership) return 0;         // (--test-no-ownership: the round-3 behaviour, every level dealt and exchanged)
-    const int nLevels = (int)levels.size();
-    // ---- the cut: the highest level that leaves >= 8 subtrees per rank; none such -> every level is dealt as before ----
-    const long long want = 8ll * sh.world;
-    std::vector<long long> above((size_t)nLevels + 1, 0);
-    for (int l = nLevels - 1; l >= 0; --l) above[l] = above[l + 1] + (long long)levels[l].size();      // pairs at levels >= l
-    int cut = -1;                                                                                        // last level of the owned prefix
-    for (int l = nLevels - 2; l >= 0; --l)
-        if (above[l + 1] + 1 >= want) { cut = l; break; }
+    const OwnershipPlan plan = planOwnership(T, levels, sh.world);
+    const int cut = plan.cut;
     if (cut < 0) return 0;
-
-    // ---- subtrees below the cut: classes of the nodes the pairs of levels <= cut connect ----
-    std::unordered_map<Node *, int> idOf;
+    std::unordered_map<Node *, int> idOf;      // a number for every node of the schedule, the same on every rank
     std::vector<Node *> nodeOf;
-    auto id = [&](Node *n) { auto it = idOf.find(n); if (it != idOf.end()) return it->second; const int k = (int)nodeOf.size(); idOf.emplace(n, k); nodeOf.push_back(n); return k; };
-    for (auto &lv : levels) for (auto &pr : lv) { id(pr.first); id(pr.second); }      // (every rank numbers the nodes alike: the schedule is the same everywhere)
-    const int grp = T->root->grpID;
-    UnionFind uf;
-    for (int l = 0; l <= cut; ++l)
-        for (auto &pr : levels[l])
-            for (Node *x : {pr.first, pr.second})
-                if (!x->is_leaf())
-                    for (Node *c : x->children) if (c->grpID == -1 || c->grpID == grp) id(c);      // (children an operand adopts from, progressive.cpp:126-172)
-    uf.p.resize(nodeOf.size());
-    std::iota(uf.p.begin(), uf.p.end(), 0);
-    for (int l = 0; l <= cut; ++l)
-        for (auto &pr : levels[l]) {
-            uf.unite(idOf[pr.first], idOf[pr.second]);
-            for (Node *x : {pr.first, pr.second})
-                if (!x->is_leaf())
-                    for (Node *c : x->children) if (c->grpID == -1 || c->grpID == grp) uf.unite(idOf[x], idOf[c]);
-        }
-    std::unordered_map<int, long long> cost;      // class -> pairs in it
-    for (int l = 0; l <= cut; ++l) for (auto &pr : levels[l]) cost[uf.find(idOf[pr.first])] += 1;
-    std::vector<std::pair<long long, int>> order;
-    for (auto &kv : cost) order.push_back({kv.second, kv.first});
-    std::sort(order.begin(), order.end(), [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
-    std::unordered_map<int, int> ownerOf;
-    std::vector<long long> load((size_t)sh.world, 0);
-    for (auto &c : order) {
-        const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        ownerOf[c.second] = r;
-        load[r] += c.first;
-    }
-    auto mineP = [&](const NodePair &pr) { return ownerOf[uf.find(idOf[pr.first])] == sh.rank; };
+    for (auto &lv : levels) for (auto &pr : lv) for (Node *x : {pr.first, pr.second}) if (!idOf.count(x)) { idOf.emplace(x, (int)nodeOf.size()); nodeOf.push_back(x); }
+    long long pairsBelow = 0, pairsAbove = 0;
+    for (int l = 0; l < (int)levels.size(); ++l) (l <= cut ? pairsBelow : pairsAbove) += (long long)levels[l].size();
     if (option->printDetail)
-        std::cerr << "Sharded run, rank " << sh.rank << " of " << sh.world << ": levels 1-" << cut + 1 << " by subtree ownership (" << order.size() << " subtrees, " << load[sh.rank]
-                  << " of " << above[0] - above[cut + 1] << " pairs here), " << above[cut + 1] << " pairs above dealt per level\n";
+        std::cerr << "Sharded run, rank " << sh.rank << " of " << sh.world << ": levels 1-" << cut + 1 << " by subtree ownership (" << plan.subtrees << " subtrees, " << plan.load[sh.rank]
+                  << " of " << pairsBelow << " pairs here), " << pairsAbove << " pairs above dealt per level\n";
 
     // ---- phase 1: my subtrees, alone ----
     struct Deferred { int level, idx, node; };
@@ -148,7 +106,7 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
         NodePairVec mine;
         std::unordered_map<Node *, int> origIdx;
         for (int i = 0; i < (int)levels[l].size(); ++i)
-            if (mineP(levels[l][i])) { mine.push_back(levels[l][i]); origIdx[levels[l][i].second] = i; }
+            if (plan.owner[l][i] == sh.rank) { mine.push_back(levels[l][i]); origIdx[levels[l][i].second] = i; }
         const size_t fb0 = database->fallback_nodes.size();
         if (!mine.empty()) {
             for (auto &pr : mine) for (Node *x : {pr.first, pr.second}) { const int k = idOf[x]; if (!seen[k]) { seen[k] = 1; touched.push_back(k); } }

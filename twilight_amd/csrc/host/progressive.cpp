@@ -188,6 +188,73 @@ void updateAlignment(Node *node, SequenceDB *database)
     node->seqsIncluded = members;
 }
 
+// ---- subtree ownership of a sharded run (gpu/align_owned.cpp uses it; pure: unit-tested in tests/host_kats.cpp) ----
+// The cut is the highest level of the schedule that still leaves 8 subtrees per rank; the subtrees below it are the classes of the nodes the pairs of
+// levels <= cut connect (a pair connects its two operands; an internal operand is connected to the children it adopts its content from,
+// progressive.cpp:126-172), dealt longest-first by their number of pairs.  No cut (cut = -1) when the tree is too small for that.
+namespace {
+struct UnionFind {
+    std::vector<int> p;
+    int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) p[std::max(a, b)] = std::min(a, b); }
+};
+}
+OwnershipPlan planOwnership(Tree *T, const std::vector<NodePairVec> &levels, int world)
+{
+    OwnershipPlan plan;
+    const int nLevels = (int)levels.size();
+    if (world <= 1 || nLevels < 2) return plan;
+    const long long want = 8ll * world;
+    std::vector<long long> above((size_t)nLevels + 1, 0);
+    for (int l = nLevels - 1; l >= 0; --l) above[l] = above[l + 1] + (long long)levels[l].size();      // pairs at levels >= l
+    int cut = -1;
+    for (int l = nLevels - 2; l >= 0; --l)
+        if (above[l + 1] + 1 >= want) { cut = l; break; }
+    if (cut < 0) return plan;
+    std::unordered_map<const Node *, int> idOf;
+    auto id = [&](const Node *n) { auto it = idOf.find(n); if (it != idOf.end()) return it->second; const int k = (int)idOf.size(); idOf.emplace(n, k); return k; };
+    const int grp = T->root->grpID;
+    auto adopts = [&](const Node *c) { return c->grpID == -1 || c->grpID == grp; };
+    for (int l = 0; l <= cut; ++l)
+        for (auto &pr : levels[l])
+            for (const Node *x : {pr.first, pr.second}) {
+                id(x);
+                if (!x->is_leaf()) for (const Node *c : x->children) if (adopts(c)) id(c);
+            }
+    UnionFind uf;
+    uf.p.resize(idOf.size());
+    for (size_t k = 0; k < uf.p.size(); ++k) uf.p[k] = (int)k;
+    for (int l = 0; l <= cut; ++l)
+        for (auto &pr : levels[l]) {
+            uf.unite(idOf[pr.first], idOf[pr.second]);
+            for (const Node *x : {pr.first, pr.second})
+                if (!x->is_leaf()) for (const Node *c : x->children) if (adopts(c)) uf.unite(idOf[x], idOf[c]);
+        }
+    // (numbering by first appearance in the schedule: the same on every rank)
+    std::unordered_map<int, long long> cost;
+    std::vector<int> firstSeen;
+    for (int l = 0; l <= cut; ++l)
+        for (auto &pr : levels[l]) { const int c = uf.find(idOf[pr.first]); if (!cost.count(c)) firstSeen.push_back(c); cost[c] += 1; }
+    std::vector<std::pair<long long, int>> order;      // (pairs, rank of first appearance)
+    for (size_t k = 0; k < firstSeen.size(); ++k) order.push_back({cost[firstSeen[k]], (int)k});
+    std::sort(order.begin(), order.end(), [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    std::unordered_map<int, int> ownerOf;
+    plan.load.assign((size_t)world, 0);
+    for (auto &c : order) {
+        const int r = (int)(std::min_element(plan.load.begin(), plan.load.end()) - plan.load.begin());
+        ownerOf[firstSeen[(size_t)c.second]] = r;
+        plan.load[r] += c.first;
+    }
+    plan.cut = cut;
+    plan.subtrees = (int)order.size();
+    plan.owner.resize((size_t)cut + 1);
+    for (int l = 0; l <= cut; ++l) {
+        plan.owner[l].resize(levels[l].size());
+        for (size_t i = 0; i < levels[l].size(); ++i) plan.owner[l][i] = ownerOf[uf.find(idOf[levels[l][i].first])];
+    }
+    return plan;
+}
+
 // progressive.cpp:232-299
 void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, alnFunction kernel, alnFunction deferredKernel)
 {

@@ -212,6 +212,9 @@ void getProgressivePairs(std::vector<std::pair<NodePair, int>> &alnOrder, std::s
 void scheduling(Node *root, std::vector<NodePairVec> &levels, int mode);
 void updateNode(Tree *tree, NodePairVec &nodes, SequenceDB *database);
 void progressiveAlignment(Tree *T, SequenceDB *database, Option *option, std::vector<NodePairVec> &levels, Params &param, alnFunction kernel);
+// Subtree ownership of a sharded run: levels [0, cut] are aligned by the owner of each pair's subtree alone (owner[level][pair]), the rest dealt per level.
+struct OwnershipPlan { int cut = -1; int subtrees = 0; std::vector<std::vector<int>> owner; std::vector<long long> load; };
+OwnershipPlan planOwnership(Tree *T, const std::vector<NodePairVec> &levels, int world);
 // `deferredKernel` aligns the deferred sequences against the root in the second pass; the reference hard-wires
 // cpu::alignmentKernel_CPU there (progressive.cpp:291).
 void msaOnSubtree(Tree *T, SequenceDB *database, Option *option, Params &param, alnFunction kernel, alnFunction deferredKernel);
