@@ -345,3 +345,31 @@ def test_gappy_columns_back_on_the_device(gpu, seq_type):
         for sid, want in zip(ids[i][0] + ids[i][1], e["rows_after"]):
             assert rows[sid] == want, f"pair {i}: row {sid} after write-back"
     st.close()
+
+
+def test_rows_and_cached_profiles_of_a_subtree_move_between_stores(gpu):
+    """What a sharded run exchanges where its subtrees meet (host/align_owned.cpp): the current rows of a list of sequences out of one store (host block and
+    device block) and into another (both ways), and a cached profile under an id new to the receiving store."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    rng = np.random.default_rng(5)
+    seqs = [bytes(rng.choice(list(b"ACGT-"), size=int(rng.integers(40, 400))).astype(np.uint8)) for _ in range(23)]
+    a, b = L.Store(seqs, "n"), L.Store([s[:7] for s in seqs], "n")          # b holds stubs: the rows arrive from a
+    ids = [3, 22, 0, 11, 7]
+    got = a.rows_of(ids)
+    assert got == [seqs[i] for i in ids] and a.rows_to_block(ids) == got
+    longer = [s + b"-" * 1500 for s in got]                                   # longer than b's row pitch: the planes grow
+    b.write_rows(ids[:3], longer[:3])
+    b.write_rows(ids[3:], longer[3:], via_device_block=True)
+    rows = b.rows()
+    for k, i in enumerate(ids):
+        assert rows[i] == longer[k]
+    for i in set(range(23)) - set(ids):
+        assert rows[i] == seqs[i][:7]
+    prof = rng.random((321, 6)).astype(np.float32)
+    b.write_cache(40, prof)
+    assert np.array_equal(b.cache(40), prof)
+    with pytest.raises(Exception):
+        b.write_cache(40, prof)                                               # the id is taken
+    a.close(); b.close()

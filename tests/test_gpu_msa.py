@@ -187,6 +187,38 @@ def test_sharded_run_through_the_library_s_own_rccl_communicator(built, tmp_path
     assert r.returncode == 0 and _md5(out) == _md5(ref) and _md5(out + "2") == _md5(ref)
 
 
+def test_the_library_s_all_gathers_in_a_one_rank_world(built):
+    """twl_comm_all_gather (device blocks) and twl_comm_all_gather_host (host blocks staged through the library's device buffers) on raw buffers: with one
+    rank the gathered block is the sent one -- the plumbing (dlopen, communicator, stream order, staging) an N-rank run relies on."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import twilight_amd as twl
+    from twilight_amd import api
+
+    twl.init([0])
+    lib = api.load_library()
+    uid = (C.c_char * 128)()
+    assert lib.twl_comm_unique_id(uid) == 0
+    rc = lib.twl_comm_init(0, 0, 1, uid)
+    assert rc == 0, lib.twl_last_error()
+    assert lib.twl_comm_init(0, 0, 1, uid) == 0                       # the process's communicator is shared by later runs of the same shape
+    assert lib.twl_comm_init(0, 0, 2, uid) != 0                       # ... and refused for another
+    src = np.random.default_rng(3).integers(0, 255, size=1 << 20, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    lib.twl_comm_all_gather_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    assert lib.twl_comm_all_gather_host(0, src.ctypes.data, dst.ctypes.data, src.size) == 0, lib.twl_last_error()
+    assert np.array_equal(src, dst)
+    d_src = torch.from_numpy(src).to("cuda:0")
+    d_dst = torch.zeros_like(d_src)
+    torch.cuda.synchronize()
+    lib.twl_comm_all_gather.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    assert lib.twl_comm_all_gather(0, d_src.data_ptr(), d_dst.data_ptr(), src.size) == 0, lib.twl_last_error()
+    assert torch.equal(d_src, d_dst)
+
+
 @pytest.mark.timeout(600)
 def test_two_sided_run_too_large_for_the_device_is_restored_on_the_host(built, tmp_path):
     """Two sequences in the two subtrees of the root carry a 150-column insertion at the same place: at the top level both profiles lose

@@ -80,6 +80,60 @@ class Store:
         api._check(lib.twl_store_read_rows(self._h, ptrs, lens))
         return [bufs[i].raw[: lens[i]] for i in range(self.n)]
 
+    def rows_of(self, ids: Sequence[int]) -> List[bytes]:
+        """twl_store_read_rows_of: the current rows of a list of sequences."""
+        lib = _lib()
+        n = len(ids)
+        idv = (C.c_int32 * n)(*ids)
+        lens = (C.c_int32 * n)()
+        api._check(lib.twl_store_read_rows_of(self._h, C.c_int32(n), idv, None, lens))
+        buf = C.create_string_buffer(max(1, sum(lens)))
+        api._check(lib.twl_store_read_rows_of(self._h, C.c_int32(n), idv, buf, lens))
+        out, at = [], 0
+        for k in range(n):
+            out.append(buf.raw[at: at + lens[k]])
+            at += lens[k]
+        return out
+
+    def write_rows(self, ids: Sequence[int], rows: Sequence[bytes], via_device_block: bool = False):
+        """twl_store_write_rows (host block) or twl_store_rows_from_block (device block of the store's exchange buffers): rows of other ranks' subtrees arriving."""
+        lib = _lib()
+        n = len(ids)
+        idv = (C.c_int32 * n)(*ids)
+        lens = (C.c_int32 * n)(*[len(r) for r in rows])
+        blob = b"".join(rows)
+        if not via_device_block:
+            api._check(lib.twl_store_write_rows(self._h, C.c_int32(n), idv, blob, lens))
+            return
+        send, recv = C.c_void_p(), C.c_void_p()
+        api._check(lib.twl_store_exchange_buffers(self._h, C.c_int64(len(blob)), C.c_int64(len(blob)), C.byref(send), C.byref(recv)))
+        api._check(lib.twl_copy_to_device(C.c_int(0), recv, blob, C.c_uint64(len(blob))))
+        api._check(lib.twl_store_rows_from_block(self._h, C.c_int32(n), idv, lens, recv))
+
+    def rows_to_block(self, ids: Sequence[int]) -> List[bytes]:
+        """twl_store_rows_to_block into the store's send buffer, read back: what a rank sends of its subtrees."""
+        lib = _lib()
+        n = len(ids)
+        idv = (C.c_int32 * n)(*ids)
+        lens = (C.c_int32 * n)()
+        api._check(lib.twl_store_read_rows_of(self._h, C.c_int32(n), idv, None, lens))
+        total = max(1, sum(lens))
+        send, recv = C.c_void_p(), C.c_void_p()
+        api._check(lib.twl_store_exchange_buffers(self._h, C.c_int64(total), C.c_int64(total), C.byref(send), C.byref(recv)))
+        api._check(lib.twl_store_rows_to_block(self._h, C.c_int32(n), idv, send, lens))
+        buf = C.create_string_buffer(total)
+        api._check(lib.twl_copy_from_device(C.c_int(0), buf, send, C.c_uint64(total)))
+        out, at = [], 0
+        for k in range(n):
+            out.append(buf.raw[at: at + lens[k]])
+            at += lens[k]
+        return out
+
+    def write_cache(self, cache_id: int, profile: np.ndarray):
+        """twl_store_write_cache: a cached profile float[len][P] under an id new to this store."""
+        prof = np.ascontiguousarray(profile, dtype=np.float32)
+        api._check(_lib().twl_store_write_cache(self._h, C.c_int32(cache_id), prof.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(prof.shape[0])))
+
     def cache(self, cache_id: int) -> np.ndarray:
         lib = _lib()
         n = C.c_int32(0)
