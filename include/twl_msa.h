@@ -59,15 +59,17 @@ typedef int (*twl_msa_exchange_fn)(void *user, const void *send, int64_t bytes_p
 /* argv: the flags of the CLI (-t tree -i sequences -o output [-r ...] [--type n|p] [--gpu-index k] ...; argv[0] is ignored).
    Parses the options, reads the tree and the sequences, builds nothing on the device yet. */
 int  twl_msa_open(int argc, const char *const *argv, twl_msa **out);
-/* Several processes, one GPU each, align this family together: every process opens the same inputs, aligns the pairs dealt to
-   `rank` and gets the others' paths through `exchange` once per level (twilight_amd/dist.py: torch.distributed all_gather, backend
-   nccl = RCCL over xGMI on GPUs, gloo in CPU tests).  Call before twl_msa_align; world == 1 is the default. */
+/* Several processes, one GPU each, align this family together: every process opens the same inputs.  Below a cut of the guide tree a rank aligns
+   the subtrees it owns alone (device-resident kernel: no exchange there, one exchange of rows / cached profiles / node bookkeeping where the subtrees
+   meet; twilight_amd/csrc/host/align_owned.cpp); above it -- and on every level with the host-staged kernel -- it aligns the pairs dealt to `rank`
+   and gets the others' paths through `exchange` once per level (twilight_amd/dist.py: torch.distributed all_gather, backend nccl = RCCL over xGMI on
+   GPUs, gloo in CPU tests).  Call before twl_msa_align; world == 1 is the default. */
 int  twl_msa_shard(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange, void *user);
 /* The same with an all-gather of DEVICE blocks (send_dev / recv_dev live in the HBM of this process's GPU; same signature): the
    device-resident level kernel then keeps every path in HBM from the DP to the write-back -- one collective per level and no host
    staging (twilight_amd/dist.py: make_device_exchange, RCCL over xGMI).  The library has synchronised its stream before the call; the
    collective must have completed when the function returns.  `exchange` (host blocks) may be given too: the host-staged level kernel
-   (--host-staged, and the deferred pass) uses it. */
+   (--host-staged) and the bookkeeping of the subtree exchange use it. */
 int  twl_msa_shard_device(twl_msa *m, int rank, int world, twl_msa_exchange_fn exchange_dev, void *user_dev, twl_msa_exchange_fn exchange, void *user);
 /* The same sharded run with the collective made by the library itself: RCCL from C++ (include/twl_align.h, twl_comm_*), one ncclAllGather per
    level on the library's stream, no callback into the caller's runtime.  id128 = the 128 bytes twl_msa_rccl_unique_id gave ONE rank, handed to
