@@ -25,6 +25,12 @@
 #pragma once
 #include "talco_kernel.hip.h"
 
+#if defined(TWL_EXP_NOPRIO)      // experiment builds: no wave priorities
+#define TWL_SETPRIO(x) do {} while (0)
+#else
+#define TWL_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+
 namespace twl {
 
 struct NArgs {
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         // in front of it: an active wave started its step up to 1100 cycles after the first wave of its SIMD); back to 0
                         // in front of the barrier, where the idle waves must not be held up -- keeping the priority across the barrier
                         // gave the gain away again.  Wide level 130 -> 121 ms, 100 pairs in tiles 8.2 -> 7.6 ms (tools/exp_step_cost.py).
-                        __builtin_amdgcn_s_setprio(2);
+                        TWL_SETPRIO(2);
                         const int i = b + lane;
                         // ---- loads: mailbox of the previous block, reference column of this cell ----
                         float eS, eI; int eCS = 0, eCI = 0;
@@ -917,14 +923,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
                 }
                 TWL_STAMP(t_slots);
-                __builtin_amdgcn_s_setprio(0);
+                TWL_SETPRIO(0);
                 wg_barrier_lds();
                 if constexpr (W == 16) {   // one workgroup per CU (latency geometry): a wave that had cells on this diagonal also runs the band bookkeeping behind
                                            // the barrier ahead of the idle ones (lone pair 1.72 -> 1.67 ms); with two workgroups per CU the same cost 6 %
                     bool anyBlk = false;
 #pragma unroll
                     for (int r = 0; r < RPL; ++r) anyBlk |= ((unsigned)(64 * blk[r] - lkm63) <= wlim);
-                    if (anyBlk) __builtin_amdgcn_s_setprio(2);
+                    if (anyBlk) TWL_SETPRIO(2);
                 }
                 TWL_STAMP(t_bar);
 
