@@ -681,6 +681,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 const unsigned vTrashRed = vcur + relTrashRed;
                 const int lkm63 = Lk - 63;
                 const unsigned wlim = (unsigned)(width1 + 64);
+                int nActSlots = 0;
 
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
@@ -692,7 +693,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         // in front of it: an active wave started its step up to 1100 cycles after the first wave of its SIMD); back to 0
                         // in front of the barrier, where the idle waves must not be held up -- keeping the priority across the barrier
                         // gave the gain away again.  Wide level 130 -> 121 ms, 100 pairs in tiles 8.2 -> 7.6 ms (tools/exp_step_cost.py).
-                        TWL_SETPRIO(2);
+                        // ... and a wave that enters a SECOND block of the same diagonal is the one its workgroup will wait for: top priority from there on
+                        // (round 4, throughput launches: 2048 pairs of 10 kbp 95.8 -> 93.0 ms; in the tile jobs of the tile-parallel path the same cost 8 %: not there)
+                        if constexpr (MT == 0 && RPL >= 2) { if (nActSlots++ == 0) TWL_SETPRIO(2); else TWL_SETPRIO(3); }
+                        else TWL_SETPRIO(2);
                         const int i = b + lane;
                         // ---- loads: mailbox of the previous block, reference column of this cell ----
                         float eS, eI; int eCS = 0, eCI = 0;
