@@ -96,6 +96,10 @@ int twl_level_read_colinfo_many(twl_store *s, int32_t n_sel, const int32_t *pair
  * fetches the few it has to edit with twl_level_read_path and commits the others in place with twl_level_commit_from_dp.
  */
 int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out);
+/* The same with the gap-character score chosen per pair, as the reference chooses it (src/alignment-cpu.cpp:88: gapCharScore is 0 for a pair with
+   more than 10 000 sequences on a side, gapExtend otherwise): zero_gap[i] != 0 gives pair i the score 0, the others p->gap_char (NULL = all
+   p->gap_char).  One launch instead of one per group: the top levels of a 100 000-leaf tree hold a few pairs of each kind. */
+int twl_level_align_mixed(twl_store *s, const twl_params *p, const uint8_t *run_mask, const uint8_t *zero_gap, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out);
 
 /* The first `len` path codes of pair `pair` as the level's last DP run over that pair left them. */
 int twl_level_read_path(twl_store *s, int32_t pair, int8_t *out, int32_t len);

@@ -55,6 +55,7 @@ int twl_store_drop_cache(twl_store *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_prepare(twl_store *, const twl_params *, float, int32_t, const twl_side *, const int32_t *, const float *, int32_t, int32_t *, uint8_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_read_colinfo(twl_store *, int32_t, int32_t, uint8_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_align(twl_store *, const twl_params *, const uint8_t *, int8_t *, int32_t *, int16_t *) { return TWL_ERR_UNSUPPORTED; }
+int twl_level_align_mixed(twl_store *, const twl_params *, const uint8_t *, const uint8_t *, int8_t *, int32_t *, int16_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_commit(twl_store *, const int8_t *, const int32_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_commit_from_dp(twl_store *, const int8_t *, const int32_t *, int32_t, const uint8_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_level_read_path(twl_store *, int32_t, int8_t *, int32_t) { return TWL_ERR_UNSUPPORTED; }

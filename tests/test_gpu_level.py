@@ -373,3 +373,47 @@ def test_rows_and_cached_profiles_of_a_subtree_move_between_stores(gpu):
     with pytest.raises(Exception):
         b.write_cache(40, prof)                                               # the id is taken
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("regime", ["throughput", "few", "tile_parallel", "protein_few", "protein_many"])
+def test_one_launch_takes_pairs_of_both_gap_character_kinds(gpu, regime):
+    """The reference decides gapCharScore per pair (alignment-cpu.cpp:88: 0 when a side holds more than 10 000 sequences).  twl_level_align_mixed
+    takes the pairs of both kinds in ONE launch; every pair must come out as in the call of its own kind, on each kernel family the level can take."""
+    import twilight_amd as twl
+    from twilight_amd import level as L
+
+    seq_type = "p" if regime.startswith("protein") else "n"
+    if regime == "throughput":
+        cases = [LC.make_case("n", seed, cached=0, length=90 + (seed % 11) * 7) for seed in range(1100)]
+    elif regime == "few":
+        cases = [LC.make_case("n", seed, cached=0, length=200 + 13 * seed) for seed in range(10)]
+    elif regime == "tile_parallel":
+        cases = [LC.make_case("n", seed, cached=0, length=1700 + 40 * seed) for seed in range(6)]
+    elif regime == "protein_few":
+        cases = [LC.make_case("p", seed, cached=0, length=150 + 20 * seed) for seed in range(8)]
+    else:
+        cases = [LC.make_case("p", seed, cached=0, length=80 + (seed % 9) * 6) for seed in range(300)]
+    seqs, pairs, ids = _level(cases)
+    p = twl.make_params(LC.matrix_of(seq_type), marker=512 if regime == "tile_parallel" else 1024)
+    p0 = twl.make_params(LC.matrix_of(seq_type), marker=p.marker, gap_char=0.0)
+    st = L.Store(seqs, seq_type)
+    st.prepare(p, pairs, gappy_threshold=0.95)
+    n = len(cases)
+    zero = (np.arange(n) % 3 == 1).astype(np.uint8)
+    aln_p, n_p, err_p = st.align(p, run_mask=1 - zero)
+    aln_z, n_z, err_z = st.align(p0, run_mask=zero)
+    aln_a, n_a, err_a = st.align(p0)              # every pair with score 0: how many pairs the score matters for
+    aln_m, n_m, err_m = st.align(p, zero_gap=zero)
+    if regime == "tile_parallel":
+        assert twl.get_stats(0).speculative == 3
+    differ = 0
+    for i in range(n):
+        want_a, want_n, want_e = (aln_z, n_z, err_z) if zero[i] else (aln_p, n_p, err_p)
+        assert err_m[i] == want_e[i] and n_m[i] == want_n[i] and np.array_equal(aln_m[i, : n_m[i]], want_a[i, : want_n[i]]), f"pair {i} (zero_gap {zero[i]})"
+        if not zero[i]:
+            differ += int(n_a[i] != n_p[i] or not np.array_equal(aln_a[i, : n_a[i]], aln_p[i, : n_p[i]]))
+    assert differ > 0, "the gap-character score changes no path of this level: the test does not discriminate"
+    # a mask of zeros is the plain call; all ones is the call with gap_char 0
+    aln_1, n_1, err_1 = st.align(p, zero_gap=np.ones(n, dtype=np.uint8))
+    assert np.array_equal(n_1, n_a) and np.array_equal(err_1, err_a) and all(np.array_equal(aln_1[i, : n_1[i]], aln_a[i, : n_a[i]]) for i in range(n))
+    st.close()

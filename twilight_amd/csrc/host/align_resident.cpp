@@ -361,14 +361,16 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
         int8_t *aln = inPlace ? nullptr : reinterpret_cast<int8_t *>(g_alnStage[d].get((size_t)n * 2 * stride));
         std::vector<int32_t> alnLen(n);
         std::vector<int16_t> err(n);
-        for (int grp = 0; grp < 2; ++grp) {
-            const std::vector<uint8_t> &all = grp ? maskZero : maskPlain;
+        {
+            // ONE launch for the pairs of both gap-character kinds (alignment-cpu.cpp:88 decides per pair; until round 4 one call per kind, which
+            // doubled the latency of the top levels of a 100 000-leaf tree, where a few pairs of each kind meet)
             std::vector<uint8_t> mask(n, 0);
-            int cnt = 0;
-            for (int i = 0; i < n; ++i) if (all[i] && owner[i] == meBase + d) { mask[i] = 1; ++cnt; }
-            if (!cnt) continue;
+            int cnt = 0, cntZero = 0;
+            for (int i = 0; i < n; ++i) if ((maskPlain[i] || maskZero[i]) && owner[i] == meBase + d) { mask[i] = 1; ++cnt; cntZero += maskZero[i]; }
+            if (!cnt) return (int)TWL_OK;
             const double tCall = nowMs();
-            const int r = twl_level_align(ctx.stores[d], grp ? &tz : &tp, mask.data(), aln, alnLen.data(), err.data());
+            const int r = (cntZero == cnt) ? twl_level_align(ctx.stores[d], &tz, mask.data(), aln, alnLen.data(), err.data())
+                                           : twl_level_align_mixed(ctx.stores[d], &tp, mask.data(), cntZero ? maskZero.data() : nullptr, aln, alnLen.data(), err.data());
             if (r != TWL_OK) return r;
             callMs[d] += nowMs() - tCall;
             auto addStats = [&]() {
@@ -382,7 +384,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             if (task == 1) {
                 for (int i = 0; i < n; ++i) {
                     if (!mask[i] || err[i] == 0) continue;
-                    twl_params tr = grp ? tz : tp;
+                    twl_params tr = maskZero[i] ? tz : tp;
                     const int minLen = std::min(ps[i].lens.first, ps[i].lens.second);
                     std::vector<uint8_t> one(n, 0);
                     one[i] = 1;
@@ -416,7 +418,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             }
             if (!restore.empty()) {             // gappy columns back on the device: these paths never leave HBM either
                 std::vector<int32_t> fin(restore.size(), -1);
-                const int r3 = twl_level_restore(ctx.stores[d], grp ? &tz : &tp, (int32_t)restore.size(), restore.data(), pathStride, fin.data());
+                const int r3 = twl_level_restore(ctx.stores[d], &tp, (int32_t)restore.size(), restore.data(), pathStride, fin.data());
                 if (r3 != TWL_OK) return r3;
                 for (size_t t = 0; t < restore.size(); ++t) {
                     if (fin[t] > 0) { fromDp[restore[t]] = 2; dpLen[restore[t]] = fin[t]; }

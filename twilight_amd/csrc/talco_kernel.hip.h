@@ -51,6 +51,7 @@ struct KArgs {
     int32_t *hb;              // optional host-mapped heartbeat [16] written by workgroup 0 (debug only)
     int32_t step_slack;       // watchdog: a pair may run at most 32*(R+Q) + step_slack diagonals in total
     float gap_open, gap_extend, gap_char;
+    const uint8_t *gc_zero;   // optional [pair]: 1 = this pair's gapCharScore is 0 whatever gap_char says (alignment-cpu.cpp:88 decides per pair)
     int32_t xdrop, flen, marker;
     float M[441];             // scoreMatrix[l][m] row-major, (P-1)x(P-1): 5x5 or 21x21
     // matrix mode 4 (protein, few pairs): column scores precomputed by score_matrix_kernel, diagonal-major per pair:
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *tb = a.tb + (size_t)blockIdx.x * (size_t)a.tb_words;
-    const float gapOpen = a.gap_open, gapExtend = a.gap_extend, gc = a.gap_char;
+    const float gapOpen = a.gap_open, gapExtend = a.gap_extend;
     const int marker = a.marker;
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_kernel(KArgs a)
         if (item >= a.n_items) break;
         const int pair = __builtin_amdgcn_readfirstlane(a.items[item]);
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
+        const float gc = (a.gc_zero && a.gc_zero[pair]) ? 0.0f : a.gap_char;
         const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
         const bool denomOne = (denom == 1.0f);
         const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * CW);
@@ -788,6 +790,7 @@ struct ScoreArgs {
     const int32_t *blk_off;        // [n_items + 1] first workgroup of each item
     int32_t n_items, seq_len;
     float gap_char;
+    const uint8_t *gc_zero;        // optional [pair], as in KArgs
     const float *M24;              // P = 22: [21][24] matrix rows padded to 24 floats; P = 6: the 5x5 matrix row-major, padded to 28 floats
     float *sim;
     const long long *sim_off;
@@ -838,7 +841,7 @@ __global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
     __syncthreads();
     const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];
     const bool denomOne = (denom == 1.0f);
-    const float gc = a.gap_char;
+    const float gc = (a.gc_zero && a.gc_zero[pair]) ? 0.0f : a.gap_char;
     const int pitch = (Q + 63) & ~63;
     float *out = a.sim + a.sim_off[pair];
     const float *rf = reinterpret_cast<const float *>(s_r);

@@ -51,6 +51,7 @@ struct NArgs {
     int32_t n_pairs_total;
     int32_t step_slack;       // watchdog: a pair may run at most (R+Q+2)*((R+Q)/(marker-1)+4) + step_slack diagonals in total
     float gap_open, gap_extend, gap_char;
+    const uint8_t *gc_zero;   // optional [pair]: 1 = this pair's gapCharScore is 0 whatever gap_char says (alignment-cpu.cpp:88 decides per pair)
     int32_t xdrop, flen, marker;
     float M[25];              // nucleotide scoreMatrix[l][m] row-major 5x5 (the protein matrix comes through M24)
     const float *M24;         // protein: [21][24] matrix rows padded to 24 floats (device memory)
@@ -303,9 +304,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     uint32_t *tb = a.tb + (size_t)blockIdx.x * (size_t)a.tb_words;
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
     const float xdropf = (float)a.xdrop;
-    const float gc = a.gap_char;
-    const bool gcNZ = (gc != 0.0f);
-    const unsigned long long gcMask = gcNZ ? ~0ull : 0ull;
     if constexpr (SPARSE) {
         for (int t = threadIdx.x; t < 21 * 6; t += C::THREADS) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
     }
@@ -327,6 +325,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         const int slot = (MT == 1 || MT == 2) ? __builtin_amdgcn_readfirstlane(a.mt_jobs[3 * item + 1]) : 0;
         const int mtx = (MT == 1 || MT == 2) ? __builtin_amdgcn_readfirstlane(a.mt_jobs[3 * item + 2]) : item;      // row of this pair in the mt_* tables: its position in the stitch launch
         const int R = a.len[2 * pair], Q = a.len[2 * pair + 1];
+        const float gc = (a.gc_zero && __builtin_amdgcn_readfirstlane((int)a.gc_zero[pair])) ? 0.0f : a.gap_char;
+        const bool gcNZ = (gc != 0.0f);
+        const unsigned long long gcMask = gcNZ ? ~0ull : 0ull;
         // MT 2 (scout of tile boundary `slot`): the anti-diagonals it reports and its own marker behind them
         const int spLo = (a.marker - 1) * slot - 1, spHi = a.marker * slot + 1;
         const int scoutD0 = max(spLo - a.mt_lead, 0);

@@ -108,6 +108,8 @@ struct Device {
     bool dump_on = false;
     std::vector<int32_t> dbg_host;
     std::vector<int32_t> mt_jobs_host;
+    Buf gc_zero;                          // [pair] flags of a call with pairs of both gap-character kinds (run_device)
+    std::vector<uint8_t> gc_zero_host;
     std::vector<int16_t> last_err;                                               // error codes of the last run_device call, as read back by it
     int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
     void *comm = nullptr;                                                        // ncclComm_t of a sharded run (twl_comm_init)
@@ -254,7 +256,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
     a.cells = base.cells; a.tb = (uint32_t *)d->tb.p; a.queue = base.queue; a.items = d_items; a.n_items = n_items;
     a.seq_len = base.seq_len; a.tb_words = (int32_t)tbw; a.dbg = base.dbg; a.n_pairs_total = base.n_pairs_total;
-    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char;
+    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char; a.gc_zero = base.gc_zero;
     a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
     for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
     a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
@@ -378,7 +380,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
     a.cells = base.cells; a.queue = base.queue; a.items = d_items;
     a.seq_len = base.seq_len; a.dbg = nullptr; a.n_pairs_total = base.n_pairs_total;
-    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char;
+    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char; a.gc_zero = base.gc_zero;
     a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
     for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
     a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
@@ -529,8 +531,11 @@ Knobs current_knobs() { return Knobs{g_mt_max_pairs, g_mt_min_marker, g_mt_tail_
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
-               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len, const float *d_packed = nullptr, bool qry_onehot = false)
+               int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len, const float *d_packed = nullptr, bool qry_onehot = false,
+               const uint8_t *h_gc_zero = nullptr)
 {
+    // h_gc_zero: optional [n_pairs], 1 = the pair's gapCharScore is 0 whatever p->gap_char says (the reference decides it per pair,
+    // alignment-cpu.cpp:88; one launch then takes the pairs of both kinds -- the top levels of a 100 000-leaf tree hold a few of each)
     // qry_onehot: every query row of every pair of this call has at most one non-zero letter (single sequences: the device-resident
     // level path knows, it built the profiles) -- the nucleotide kernels then take the four-product form of the column score
     // d_packed: the level's columns already in the packed [P+2] layout (device-resident level path); no packing pass then
@@ -595,9 +600,16 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     a.seq_len = seq_len;
     a.n_pairs_total = n_pairs;
     a.gap_open = p->gap_open; a.gap_extend = p->gap_extend; a.gap_char = p->gap_char;
+    a.gc_zero = nullptr;
+    if (h_gc_zero && p->gap_char != 0.0f && std::any_of(h_gc_zero, h_gc_zero + n_pairs, [](uint8_t z) { return z != 0; })) {
+        if ((rc = d->gc_zero.ensure((size_t)n_pairs))) return rc;
+        d->gc_zero_host.assign(h_gc_zero, h_gc_zero + n_pairs);       // (kept with the device: the upload is asynchronous)
+        HIP_TRY(hipMemcpyAsync(d->gc_zero.p, d->gc_zero_host.data(), (size_t)n_pairs, hipMemcpyHostToDevice, st));
+        a.gc_zero = (const uint8_t *)d->gc_zero.p;
+    }
     a.xdrop = p->xdrop; a.flen = p->flen; a.marker = p->marker;
     a.step_slack = 1 << 16;
-    const bool want_dbg = getenv("TWL_DEBUG") != nullptr;
+    const bool want_dbg = dbg_on();
     a.dbg = nullptr;
     if (want_dbg) {
         if ((rc = d->dbg.ensure((size_t)n_pairs * 16 * sizeof(int32_t) + 2048 + 16 * 192 * 32))) return rc;     // per-pair records, then the stamp build's sums and timeline
@@ -673,7 +685,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipStreamSynchronize(st));      // the host vectors above go out of scope
                 twl::ScoreArgs sa{};
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
-                sa.n_items = n_run; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.M24 = (const float *)d->m24.p;
+                sa.n_items = n_run; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.gc_zero = a.gc_zero; sa.M24 = (const float *)d->m24.p;
                 sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
                 FILL_TRY(flush_fills(d, st));
                 hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_run]), dim3(256), 0, st, sa);
@@ -979,7 +991,7 @@ void twl_shutdown(void)
         twl_level_pool_release(d);
         if (d->comm) { comm_destroy_raw(d->comm); d->comm = nullptr; }
         d->comm_send.release(); d->comm_recv.release();
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs,
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs, &d->gc_zero,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);

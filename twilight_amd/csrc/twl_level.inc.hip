@@ -740,6 +740,13 @@ int twl_level_read_colinfo(twl_store *s, int32_t pair, int32_t side, uint8_t *ou
 
 int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out)
 {
+    return twl_level_align_mixed(s, p, run_mask, nullptr, aln_out, aln_len_out, err_out);
+}
+
+// One call for the pairs of both gap-character kinds of a level (alignment-cpu.cpp:88 decides gapCharScore per pair): zero_gap[i] = 1 gives
+// pair i gapCharScore 0, the others p->gap_char.
+int twl_level_align_mixed(twl_store *s, const twl_params *p, const uint8_t *run_mask, const uint8_t *zero_gap, int8_t *aln_out, int32_t *aln_len_out, int16_t *err_out)
+{
     if (!s || !s->prepared) { g_err = "twl_level_prepare has not been called"; return TWL_ERR_BAD_ARGUMENT; }
     int rc = check_params(p);
     if (rc) return rc;
@@ -770,7 +777,7 @@ int twl_level_align(twl_store *s, const twl_params *p, const uint8_t *run_mask, 
     for (int32_t i = 0; i < n && qryOneHot; ++i)
         if (lm[2 * i] > 0 && lm[2 * i + 1] > 0) qryOneHot = s->sides[2 * (size_t)i + 1].n_members == 1 && s->sides[2 * (size_t)i + 1].cache_id < 0;
     rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->lv->d_lenmask.p, (const int32_t *)s->lv->d_num.p, (int8_t *)s->lv->d_aln.p,
-                    (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot);
+                    (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot, zero_gap);
     if (rc) return rc;
     if ((int32_t)d->last_err.size() == n && (int32_t)d->last_alnlen.size() == n) {      // (run_device read them back already, in its one synchronisation)
         std::copy(d->last_err.begin(), d->last_err.end(), err_out);
@@ -838,40 +845,15 @@ int twl_level_read_paths(twl_store *s, int32_t n_sel, const int32_t *pairs, cons
     return TWL_OK;
 }
 
-// addGappyColumnsBack for the pairs `pairs` of the prepared and aligned level, on the device (restore_kernels.hip.h): their final paths go
-// into the level's path buffer (row pitch out_stride, the pitch the commit must then be given), final_len_out[t] = the final length of
-// pairs[t], or -1 when that pair holds a two-sided run too large for the device (the caller restores it on the host, as before).
-int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out)
+// One batch of twl_level_restore (the caller holds the device's lock and has sized the path buffer).
+static int restore_batch(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out)
 {
-    if (!s || !s->prepared || !s->lv || (n_sel > 0 && !s->lv->d_aln.p)) { g_err = "twl_level_align has not been called"; return TWL_ERR_BAD_ARGUMENT; }
-    int rc = check_params(p);
-    if (rc) return rc;
+    int rc;
     const int32_t n = s->n_pairs;
-    if (n_sel < 0 || (n_sel > 0 && (!pairs || !final_len_out)) || out_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
-    for (int32_t t = 0; t < n_sel; ++t) if (pairs[t] < 0 || pairs[t] >= n) { g_err = "pair index out of range"; return TWL_ERR_BAD_ARGUMENT; }
     Device *d = s->d;
-    std::lock_guard<std::mutex> lk(d->mu);
-    HIP_TRY(hipSetDevice(d->id));
     hipStream_t st = d->stream;
     LevelBufs *lv = s->lv;
     const size_t sl = (size_t)s->seq_len, bstride = 2 * sl + 1;
-    // the restored paths go straight into the rows of the level's path buffer (the commit leaves those rows alone); several calls per
-    // level (one per gap-character group, after that group's twl_level_align) share the buffer and must agree on its pitch
-    if (s->staged_stride && s->staged_stride != out_stride) { g_err = "twl_level_restore: one row pitch per level"; return TWL_ERR_BAD_ARGUMENT; }
-    if ((rc = lv->d_paths.ensure((size_t)n * (size_t)out_stride))) return rc;
-    s->staged_stride = out_stride;
-    if (n_sel == 0) return TWL_OK;
-    // (ADVICE round 3) at most 4096 pairs per batch: the work arrays cost ~32 * (2 * seq_len + 1) bytes per pair plus the scratch of the small alignments
-    // (~458 KB per pair once 4096 / n_sel floors at one workgroup); a wide level of a 100 000-leaf tree with a low -r would otherwise ask for tens of GB at
-    // once.  A batch whose arrays cannot be had is handed back (-1: the caller restores those pairs on the host, a path that still exists).
-    constexpr int32_t kBatch = 4096;
-    if (n_sel > kBatch) {
-        d->mu.unlock();
-        int rcAll = TWL_OK;
-        for (int32_t at = 0; at < n_sel && rcAll == TWL_OK; at += kBatch) rcAll = twl_level_restore(s, p, std::min(kBatch, n_sel - at), pairs + at, out_stride, final_len_out + at);
-        d->mu.lock();
-        return rcAll;
-    }
     const size_t ns = (size_t)n_sel;
     auto handBack = [&](int rcAlloc) {          // out of device memory for this batch: its pairs go back to the host path
         (void)hipGetLastError();
@@ -923,6 +905,34 @@ int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const in
     HIP_TRY(hipStreamSynchronize(st));
     const int32_t *all = (const int32_t *)lv->back.p;
     for (int32_t t = 0; t < n_sel; ++t) final_len_out[t] = all[pairs[t]];
+    return TWL_OK;
+}
+
+// addGappyColumnsBack for the pairs `pairs` of the prepared and aligned level, on the device (restore_kernels.hip.h): their final paths go
+// into the level's path buffer (row pitch out_stride, the pitch the commit must then be given), final_len_out[t] = the final length of
+// pairs[t], or -1 when that pair holds a two-sided run too large for the device (the caller restores it on the host, as before).
+int twl_level_restore(twl_store *s, const twl_params *p, int32_t n_sel, const int32_t *pairs, int32_t out_stride, int32_t *final_len_out)
+{
+    if (!s || !s->prepared || !s->lv || (n_sel > 0 && !s->lv->d_aln.p)) { g_err = "twl_level_align has not been called"; return TWL_ERR_BAD_ARGUMENT; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    const int32_t n = s->n_pairs;
+    if (n_sel < 0 || (n_sel > 0 && (!pairs || !final_len_out)) || out_stride < 1) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    for (int32_t t = 0; t < n_sel; ++t) if (pairs[t] < 0 || pairs[t] >= n) { g_err = "pair index out of range"; return TWL_ERR_BAD_ARGUMENT; }
+    Device *d = s->d;
+    std::lock_guard<std::mutex> lk(d->mu);
+    HIP_TRY(hipSetDevice(d->id));
+    // the restored paths go straight into the rows of the level's path buffer (the commit leaves those rows alone); several calls per
+    // level share the buffer and must agree on its pitch
+    if (s->staged_stride && s->staged_stride != out_stride) { g_err = "twl_level_restore: one row pitch per level"; return TWL_ERR_BAD_ARGUMENT; }
+    if ((rc = s->lv->d_paths.ensure((size_t)n * (size_t)out_stride))) return rc;
+    s->staged_stride = out_stride;
+    // (ADVICE round 3) at most 4096 pairs per batch: the work arrays cost ~32 * (2 * seq_len + 1) bytes per pair plus the scratch of the small alignments
+    // (~458 KB per pair once 4096 / n_sel floors at one workgroup); a wide level of a 100 000-leaf tree with a low -r would otherwise ask for tens of GB at
+    // once.  A batch whose arrays cannot be had is handed back (-1: the caller restores those pairs on the host, a path that still exists).
+    constexpr int32_t kBatch = 4096;
+    for (int32_t at = 0; at < n_sel; at += kBatch)
+        if ((rc = restore_batch(s, p, std::min(kBatch, n_sel - at), pairs + at, out_stride, final_len_out + at))) return rc;
     return TWL_OK;
 }
 

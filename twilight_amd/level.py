@@ -17,7 +17,7 @@ class TwlSide(C.Structure):
 
 
 _SYMBOLS = ["twl_store_create", "twl_store_destroy", "twl_store_read_rows", "twl_store_read_rows_of", "twl_store_write_rows", "twl_store_write_cache", "twl_store_rows_to_block", "twl_store_rows_from_block", "twl_store_exchange_buffers", "twl_store_read_cache", "twl_store_drop_cache",
-            "twl_level_prepare", "twl_level_read_colinfo", "twl_level_read_colinfo_many", "twl_level_align", "twl_level_read_path", "twl_level_read_paths", "twl_level_commit", "twl_level_commit_from_dp", "twl_level_read_columns", "twl_level_timing",
+            "twl_level_prepare", "twl_level_read_colinfo", "twl_level_read_colinfo_many", "twl_level_align", "twl_level_align_mixed", "twl_level_read_path", "twl_level_read_paths", "twl_level_commit", "twl_level_commit_from_dp", "twl_level_read_columns", "twl_level_timing",
             "twl_level_restore", "twl_level_read_final", "twl_level_exchange_buffers", "twl_level_paths_to_block", "twl_level_paths_from_block",
             "twl_level_write_final"]
 
@@ -174,7 +174,8 @@ class Store:
         api._check(_lib().twl_level_read_columns(self._h, C.c_int32(pair), C.c_int32(side), out.ctypes.data_as(C.POINTER(C.c_float)), C.c_int32(n)))
         return out
 
-    def align(self, params: api.TwlParams, run_mask: Optional[np.ndarray] = None):
+    def align(self, params: api.TwlParams, run_mask: Optional[np.ndarray] = None, zero_gap: Optional[np.ndarray] = None):
+        """twl_level_align; with zero_gap (one flag per pair) twl_level_align_mixed: those pairs take gapCharScore 0, the others params.gap_char."""
         n, sl = self._n_pairs, self._seq_len
         aln = np.zeros((n, 2 * sl), dtype=np.int8)
         aln_len = np.zeros(n, dtype=np.int32)
@@ -183,6 +184,12 @@ class Store:
         if run_mask is not None:
             m = np.ascontiguousarray(run_mask, dtype=np.uint8)
             mask = m.ctypes.data_as(C.POINTER(C.c_uint8))
+        if zero_gap is not None:
+            z = np.ascontiguousarray(zero_gap, dtype=np.uint8)
+            assert z.shape == (n,)
+            api._check(_lib().twl_level_align_mixed(self._h, C.byref(params), mask, z.ctypes.data_as(C.POINTER(C.c_uint8)), aln.ctypes.data_as(C.POINTER(C.c_int8)),
+                                                    aln_len.ctypes.data_as(C.POINTER(C.c_int32)), err.ctypes.data_as(C.POINTER(C.c_int16))))
+            return aln, aln_len, err
         api._check(_lib().twl_level_align(self._h, C.byref(params), mask, aln.ctypes.data_as(C.POINTER(C.c_int8)),
                                           aln_len.ctypes.data_as(C.POINTER(C.c_int32)), err.ctypes.data_as(C.POINTER(C.c_int16))))
         return aln, aln_len, err
