@@ -300,7 +300,16 @@ struct CommitArgs {
     float *const *cache;
     const int32_t *merge;         // [n_merge][4]  pair, ref slot, query slot, destination slot
     const float *merge_w;         // [n_merge][2]  refWeight, qryWeight
+    // pairs whose DP path IS the final path (no gappy column was removed) are read where the DP kernel left them
+    const uint8_t *from_dp;       // optional [n_pairs]: 1 = the pair's path is row `pair` of paths_dp
+    const int8_t *paths_dp;       // [n_pairs][dp_stride]
+    int32_t dp_stride;
 };
+
+__device__ __forceinline__ const int8_t *path_row(const CommitArgs &a, int pair)
+{
+    return (a.from_dp && a.from_dp[pair] == 1) ? a.paths_dp + (size_t)pair * (size_t)a.dp_stride : a.paths + (size_t)pair * (size_t)a.path_stride;
+}
 
 // grid: n_pairs workgroups of 256 threads: chunk_base[pair][ch] = reference / query columns the path consumes before its 256-element chunk ch.
 // Thread t counts chunk g * 256 + t (sixteen 16-byte loads; rows of the path buffer start at multiples of path_stride, hence the byte
@@ -310,8 +319,8 @@ __global__ void __launch_bounds__(256) path_scan_kernel(CommitArgs a)
     __shared__ int s_wave[4];
     const int pair = blockIdx.x;
     const int n = a.path_len[pair];
-    const int8_t *path = a.paths + (size_t)pair * a.path_stride;
-    const bool aligned = (((size_t)pair * (size_t)a.path_stride) & 15u) == 0 && ((size_t)a.paths & 15u) == 0;
+    const int8_t *path = path_row(a, pair);
+    const bool aligned = ((size_t)path & 15u) == 0;
     const int nch = (n + 255) >> 8;
     int baseR = 0, baseQ = 0;
     for (int g0 = 0; g0 < nch; g0 += 256) {
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(256) apply_path_kernel(CommitArgs a)
     if (c0 >= n) return;
     const int c = c0 + 4 * threadIdx.x;
     const int own = isQ ? 1 : 2;
-    const int8_t *path = a.paths + (size_t)pair * a.path_stride;
+    const int8_t *path = path_row(a, pair);
     bool keep[4];
     int cnt = 0;
 #pragma unroll
@@ -422,7 +431,7 @@ __global__ void __launch_bounds__(256) merge_cache_kernel(CommitArgs a)
     const int c0 = blockIdx.y * 256;
     if (c0 >= n) return;
     const int j = c0 + threadIdx.x;
-    const int code = (j < n) ? a.paths[(size_t)pair * a.path_stride + j] : 3;
+    const int code = (j < n) ? path_row(a, pair)[j] : 3;
     int tot;
     const int r = a.chunk_base[((size_t)pair * a.n_chunks + blockIdx.y) * 2] + block_scan_256(code == 0 || code == 2, &tot, s_wave);
     const int q = a.chunk_base[((size_t)pair * a.n_chunks + blockIdx.y) * 2 + 1] + block_scan_256(code == 0 || code == 1, &tot, s_wave);

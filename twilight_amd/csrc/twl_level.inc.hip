@@ -80,7 +80,7 @@ struct LevelBufs {
     Ref d_sides, d_mseq, d_mw, d_mplane, d_tab, d_num;       // up_prepare (d_mplane, d_tab: up_commit after the commit's upload)
     Ref d_lenmask;                                           // up_align
     Ref r_sel;                                               // up_restore
-    Ref d_pathlen, d_work, d_merge, d_mergew;                // up_commit
+    Ref d_pathlen, d_work, d_merge, d_mergew, d_fromdp;      // up_commit
     Buf d_raw, d_colinfo, d_cols, d_len, d_aln, d_alnlen, d_err;
     Buf d_paths, d_chunk, d_ccnt;
     Buf r_oidx, r_run, r_seg, r_aoff, r_blist, r_nboth, r_wtot, r_arena, r_outlen, r_tb, r_rows;      // twl_level_restore (restore_kernels.hip.h)
@@ -1090,17 +1090,10 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if ((rc = s->lv->d_paths.ensure((size_t)n * (size_t)path_stride))) return rc;
     if (!from_dp) HIP_TRY(hipMemcpyAsync(s->lv->d_paths.p, paths, (size_t)n * (size_t)path_stride, hipMemcpyHostToDevice, st));
     else {
-        // the DP output of this level, row by row, inside HBM; then the (few) rows the caller brought
+        // the DP output of this level stays where the DP kernel left it (the commit kernels read row i of that buffer for from_dp[i] == 1; until
+        // round 4 every run of such rows was copied into the path buffer: ~1700 small 2-D copies per pass of a 100 000-leaf tree); only the (few)
+        // rows the caller brought are uploaded
         // (from_dp[i] == 2: twl_level_restore has put pair i's final path into its row already)
-        const size_t width = std::min((size_t)path_stride, 2 * (size_t)s->seq_len);
-        for (int32_t i = 0; i < n;) {
-            if (from_dp[i] != 1) { ++i; continue; }
-            int32_t j = i;
-            while (j < n && from_dp[j] == 1) ++j;
-            HIP_TRY(hipMemcpy2DAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, (size_t)path_stride, (const int8_t *)s->lv->d_aln.p + (size_t)i * 2 * (size_t)s->seq_len,
-                                     2 * (size_t)s->seq_len, width, (size_t)(j - i), hipMemcpyDeviceToDevice, st));
-            i = j;
-        }
         for (int32_t i = 0; i < n; ++i)
             if (!from_dp[i] && path_len[i] > 0 && (hostRows = true))
                 HIP_TRY(hipMemcpyAsync((int8_t *)s->lv->d_paths.p + (size_t)i * (size_t)path_stride, paths + (size_t)i * (size_t)path_stride, (size_t)path_len[i], hipMemcpyHostToDevice, st));
@@ -1108,18 +1101,20 @@ int twl_level_commit_from_dp(twl_store *s, const int8_t *paths, const int32_t *p
     if ((rc = s->lv->d_chunk.ensure((size_t)n * nChunks * 2 * sizeof(int32_t)))) return rc;
     {
         Arena &A = s->lv->up_commit;
-        if ((rc = A.begin(((size_t)n + work.size() + merge.size()) * sizeof(int32_t) + mergew.size() * sizeof(float) + tab.size() * sizeof(float *) + mplane.size(), 6))) return rc;
+        if ((rc = A.begin(((size_t)n + work.size() + merge.size()) * sizeof(int32_t) + mergew.size() * sizeof(float) + tab.size() * sizeof(float *) + mplane.size() + (from_dp ? (size_t)n : 0), 7))) return rc;
         A.put(s->lv->d_pathlen, path_len, (size_t)n);
         A.put(s->lv->d_work, work);
         A.put(s->lv->d_merge, merge);
         A.put(s->lv->d_mergew, mergew);
         A.put(s->lv->d_tab, tab);
         A.put(s->lv->d_mplane, mplane);
+        if (from_dp) A.put(s->lv->d_fromdp, from_dp, (size_t)n);
         if ((rc = A.flush(st))) return rc;
     }
 
     twl::CommitArgs a{};
     a.paths = (const int8_t *)s->lv->d_paths.p;
+    if (from_dp) { a.from_dp = (const uint8_t *)s->lv->d_fromdp.p; a.paths_dp = (const int8_t *)s->lv->d_aln.p; a.dp_stride = (int32_t)(2 * (size_t)s->seq_len); }
     a.path_len = (const int32_t *)s->lv->d_pathlen.p;
     a.path_stride = path_stride;
     a.chunk_base = (int32_t *)s->lv->d_chunk.p;
