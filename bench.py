@@ -338,9 +338,10 @@ def main():
         # the per-level all-gather: the library's own RCCL communicator (one per handle: ncclCommInitRank on ids rank 0 makes and torch.distributed's
         # store carries); the development switch TWL_BENCH_ONE_GPU (two ranks on one device, which RCCL refuses) keeps the gloo callbacks
         sharded = world > 1 or force_shard
-        native = sharded and not one_gpu and not os.environ.get("TWL_BENCH_CALLBACK_EXCHANGE")
+        native = sharded and (not one_gpu or bool(os.environ.get("TWL_BENCH_TRY_NATIVE"))) and not os.environ.get("TWL_BENCH_CALLBACK_EXCHANGE")      # (TRY_NATIVE on one GPU: RCCL refuses two ranks on a device -- the way out below, exercised)
         exchange = tdist.make_exchange(None if one_gpu else dev) if (sharded and not native) else None
         exchange_dev = tdist.make_device_exchange(dev) if (sharded and not native) else None
+        native_note = None
         handles = []
         t0 = time.perf_counter()
         for i in range(args.warmup + args.steps):
@@ -349,7 +350,23 @@ def main():
                 ids = [msa.rccl_unique_id() if rank == 0 else None]
                 if world > 1:
                     dist.broadcast_object_list(ids, src=0)
-                m.shard_rccl(rank, world, ids[0])       # (twl.init above brought the device up; one communicator per process: handles are aligned one after the other)
+                ok, why = 1, ""
+                try:
+                    m.shard_rccl(rank, world, ids[0])   # (twl.init above brought the device up; one communicator per process: handles are aligned one after the other)
+                except Exception as e:                  # no communicator on this rank: every rank must take the same way out
+                    ok, why = 0, str(e)
+                if world > 1:
+                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = int(flag.item())
+                if not ok:
+                    # the library's own communicator could not be made: the same all-gather through torch.distributed's RCCL (device blocks, callbacks)
+                    native = False
+                    native_note = f"twl_msa_shard_rccl failed ({why or 'on another rank'}): per-level all-gather through torch.distributed callbacks"
+                    sys.stderr.write(f"[bench rank {rank}] {native_note}\n")
+                    exchange = tdist.make_exchange(None if one_gpu else dev)
+                    exchange_dev = tdist.make_device_exchange(dev)
+                    m.shard(rank, world, exchange, exchange_device=exchange_dev)      # (replaces the handle's shard description, also where the communicator came up)
             elif exchange is not None:
                 m.shard(rank, world, exchange, exchange_device=exchange_dev)
             m.upload()
@@ -424,7 +441,10 @@ def main():
             out["config"].update({"n_sequences": int(tot.n_sequences), "seq_length": cfg["length"], "levels": int(tot.n_levels), "pairs": int(tot.pairs),
                                   "band_cells_per_pass": int(cells // steps), "aln_len": int(tot.aln_len), "pairs_rerun_in_wider_window": int(tot.relaunched),
                                   "msa_md5": md5, "generate_s": gen_s, "open_and_upload_s_per_handle": open_s / max(1, args.warmup + args.steps),
-                                  "parallelism": f"pairs of each level dealt to {world} rank(s); final paths all-gathered per level HBM to HBM over RCCL (one collective per level)" if world > 1 else "1 GPU"})
+                                  "parallelism": (f"{world} rank(s), one GPU each: subtrees below a cut of the guide tree owned by one rank (no exchange there), one exchange at the cut, "
+                                                  f"above it the pairs of each level dealt to the ranks and the final paths all-gathered HBM to HBM over RCCL (one collective per level)") if world > 1 else "1 GPU"})
+            if sharded:
+                out["config"]["collective"] = native_note or ("the library's own RCCL communicator (twl_msa_shard_rccl)" if native else "torch.distributed callbacks")
             out["dp_kernel"] = {"cells_per_s": cells / (kernel_ms * 1e-3), "kernel_ms_per_pass": kernel_ms / steps, "exchange_ms_per_pass": exch_ms / steps,
                                 "share_of_step_time": (kernel_ms / steps) / (dt_max * 1e3 / steps),
                                 "note": "all DP launches of a pass (HIP events on the library's stream; with several ranks the slowest rank of each level)"}

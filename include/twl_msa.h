@@ -74,7 +74,9 @@ int  twl_msa_shard_device(twl_msa *m, int rank, int world, twl_msa_exchange_fn e
 /* The same sharded run with the collective made by the library itself: RCCL from C++ (include/twl_align.h, twl_comm_*), one ncclAllGather per
    level on the library's stream, no callback into the caller's runtime.  id128 = the 128 bytes twl_msa_rccl_unique_id gave ONE rank, handed to
    all ranks by the launcher (bench.py: torch.distributed's store; twilight-mi355x --gpu-index a,b,...: a shared page of the processes it forks).
-   Collective: every rank calls it, after twl_msa_open.  This is how `twilight-mi355x --gpu-index 0,1,...,7` runs: one process per GPU. */
+   Collective: every rank calls it, after twl_msa_open.  This is how `twilight-mi355x --gpu-index 0,1,...,7` runs: one process per GPU.
+   -3: RCCL could not make the communicator (twl_msa_last_error says why); the handle is unsharded again and may be sharded through the caller's own
+   collective (twl_msa_shard_device) -- every rank has to take the same way, which is the caller's to agree on (bench.py does, with one all-reduce). */
 int  twl_msa_rccl_unique_id(void *id128);
 int  twl_msa_shard_rccl(twl_msa *m, int rank, int world, const void *id128);
 /* Device-resident path: put the sequences into HBM now (otherwise the first level does it). */

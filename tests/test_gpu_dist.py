@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exchange):
+def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exchange, try_native=False):
     sys.path.insert(0, ROOT)
     os.environ.update(env)                      # (the thresholds are read when the host library loads)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,6 +43,16 @@ def _worker(rank, world, port, tree, fasta, out_dir, typ, flags, env, device_exc
 
     out = os.path.join(out_dir, f"rank{rank}.aln")
     m = msa.Msa(["-t", tree, "-i", fasta, "-o", out, "--type", typ, "--gpu-index", "0"] + list(flags))
+    if try_native:
+        # the library's own communicator cannot be made here (RCCL refuses two ranks on one device): twl_msa_shard_rccl must say so on every rank
+        # -- an error code, not the end of the process -- and leave the handle usable for a caller's own collective
+        ids = [msa.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            m.shard_rccl(rank, world, ids[0])
+            raise SystemExit("twl_msa_shard_rccl succeeded with two ranks on one device")
+        except msa.MsaError as e:
+            assert "twl_comm_init failed" in str(e), str(e)
     if device_exchange:
         # device blocks for every level of both passes (the deferred pass runs on the resident rows too); the host callback stays registered for the host-staged kernel
         m.shard(rank, world, tdist.make_exchange(None), exchange_device=tdist.make_device_exchange(torch.device("cuda:0")))
@@ -101,3 +111,18 @@ def test_two_processes_on_one_gpu_write_the_fixture_msa(built, tmp_path, name, d
         assert all(v > 0 for v in x[len(quiet):]), (name, x.tolist())
         if sum(fx["pairs_per_level"]) >= 39:
             assert len(quiet) >= 1, (name, x[:n_main].tolist())                                           # (8 subtrees per rank fit under a cut above the leaf level)
+
+
+@pytest.mark.timeout(900)
+def test_no_communicator_is_an_error_code_and_the_handle_stays_usable(built, tmp_path):
+    """twl_msa_shard_rccl where RCCL cannot make a communicator: both ranks get an error (bench.py then agrees on torch.distributed's callbacks), shard the
+    same handles through callbacks and write the fixture's MSA."""
+    import torch.multiprocessing as mp
+
+    name = "nuc_default"
+    _, fam, ins, flags, env = [v for v in VARIANTS if v[0] == name][0]
+    d = str(tmp_path)
+    t, f, typ = write_family(d, fam, ins)
+    mp.start_processes(_worker, args=(2, _free_port(), t, f, d, typ, flags, env, True, True), nprocs=2, join=True, start_method="spawn")
+    for rank in range(2):
+        assert hashlib.md5(open(os.path.join(d, f"rank{rank}.aln"), "rb").read()).hexdigest() == FIX[name]["md5"], f"rank {rank}"

@@ -235,15 +235,16 @@ const std::vector<int> &selectedDevices() { return g_devices; }
 
 void ensureDevicesUp(Option *option) { ensureInit(option); }
 
-void initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128)
+int initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128)
 {
     ensureInit(option);
     if (g_devices.size() != 1) { std::cerr << "ERROR: a sharded run takes one device per process.\n"; exit(1); }
     const int rc = twl_comm_init(g_devices[0], rank, world, id128);
-    if (rc != TWL_OK) { std::cerr << "ERROR: twl_comm_init failed (" << rc << "): " << twl_last_error() << '\n'; exit(1); }
+    if (rc != TWL_OK) return rc;            // (twl_last_error() says why; the CLI ends the run, a caller of the C ABI may shard through its own collective instead)
     Shard sh;
     sh.rank = rank; sh.world = world; sh.rccl = true;
     setShard(database, sh);
+    return TWL_OK;
 }
 
 static std::future<std::pair<int, std::string>> g_initJob;   // (return code, twl_last_error() of the helper thread)

@@ -105,7 +105,12 @@ int twl_msa_shard_rccl(twl_msa *m, int rank, int world, const void *id128)
     if (m->hostStaged) { g_msaErr = "the library's own collective serves the device-resident level kernel"; return -2; }
     const int rc = twl_msa_shard(m, rank, world, [](void *, const void *, int64_t, void *) { return -1; }, nullptr);      // (validation, thread share; the callback is replaced below)
     if (rc) return rc;
-    msa::progressive::gpu::initRcclShard(m->db, &m->option, rank, world, id128);
+    const int rcComm = msa::progressive::gpu::initRcclShard(m->db, &m->option, rank, world, id128);
+    if (rcComm) {                           // no communicator: the handle is as it was before the call (the caller may shard it through its own collective)
+        g_msaErr = std::string("twl_comm_init failed: ") + twl_last_error();
+        twl_msa_shard(m, 0, 1, nullptr, nullptr);
+        return -3;
+    }
     return 0;
 }
 

@@ -71,7 +71,8 @@ int main(int argc, char **argv)
             while (!page->ready.load() && !page->failed.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
             if (page->failed.load()) exit(1);
         }
-        msa::progressive::gpu::initRcclShard(db, &option, rank, world, page->id);
+        const int rcComm = msa::progressive::gpu::initRcclShard(db, &option, rank, world, page->id);
+        if (rcComm != TWL_OK) { std::cerr << "ERROR: twl_comm_init failed (" << rcComm << "): " << twl_last_error() << '\n'; exit(1); }
     };
     const int alnLen = msa::runDefaultAlignment(option, kernel, kernel, rank == 0, [&](msa::SequenceDB *db) { g = msa::progressive::gpu::runTotals(db); }, beforeAlign);
     if (rank != 0) _exit(0);

@@ -266,7 +266,7 @@ using ExchangeFn = int (*)(void *user, const void *send, int64_t bytes_per_rank,
 struct Shard { int rank = 0, world = 1; ExchangeFn exchange = nullptr; void *user = nullptr; ExchangeFn exchangeDev = nullptr; void *userDev = nullptr;
                bool rccl = false; };      // rccl: the all-gathers are the library's own (twl_comm_all_gather*, RCCL from C++), no callback
 // Communicator of a sharded run on this process's device (twl_comm_init); the two all-gathers the level kernels use when Shard::rccl is set.
-void initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128);
+int initRcclShard(SequenceDB *database, Option *option, int rank, int world, const void *id128);      // 0, or the code of twl_comm_init
 void ensureDevicesUp(Option *option);      // joins the twl_init started by beginInit
 // Subtree ownership of a sharded run (align_owned.cpp): levels [0, returned) of the main pass are done when it returns.
 size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *database, Option *option, Params &param);
