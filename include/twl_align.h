@@ -180,10 +180,12 @@ int twl_comm_destroy(int device);
      TWL_KNOB_MT_WIDE        1 (default): pairs whose band outgrew the 1024-row window re-run with all their tiles at once on the 3072-row geometry;
                              0: tile after tile on the 2048-row kernel (the path before round 4; tests hold the two to each other)
      TWL_KNOB_NO_SPEC        1: no speculative two-workgroup teams for levels of a few pairs outside the tile-parallel path (timing tools)
-     TWL_KNOB_SCOUT_XDROP_PCT  X-drop of the pair scouts of wide re-runs in percent of the call's (default 100; 10..100): they only predict tile starts */
+     TWL_KNOB_SCOUT_XDROP_PCT  X-drop of the pair scouts of wide re-runs in percent of the call's (default 100; 10..100): they only predict tile starts
+     TWL_KNOB_THR_SMALL      0 (default): levels of short pairs (R + Q <= 4096) start on the 512-row throughput geometry (five workgroups per CU) unless a recent
+                             such level outgrew it; 1: never; 2: every throughput level does (tests: pairs that outgrow it re-run on the 768-row geometry) */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15 };
 int twl_set_knob(int key, int value);
 /* The launch plan of a nucleotide call in words ("throughput; mode 2; window 768; bulk 1024 tail 277"), made by the very function the launch path
    uses, without touching a device: len[n_pairs][2] as twl_align_batch, num_cu / qry_onehot / wide_streak the facts the device would supply. */

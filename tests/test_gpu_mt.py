@@ -25,6 +25,7 @@ def knobs(gpu):
     gpu.set_knob(api.KNOB_MT_ROUNDS, 2)
     gpu.set_knob(api.KNOB_MT_THR_JOBS, 256)
     gpu.set_knob(api.KNOB_MT_WIDE, 1)
+    gpu.set_knob(api.KNOB_THR_SMALL, 0)
 
 
 def _compare(twl, batch, **pk):
@@ -231,6 +232,62 @@ def test_throughput_level_pairs_that_outgrow_the_768_row_window(knobs, onehot):
     for i in range(1104):
         assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"
     assert st.band_cells == ost.cells * 138
+
+
+@pytest.mark.parametrize("onehot", [0, 1])
+def test_levels_of_short_pairs_take_the_512_row_window_until_one_outgrows_it(knobs, onehot):
+    """Levels of more pairs than CUs whose pairs are short (R + Q <= 4096) run on 4 waves x 2 blocks, five workgroups per CU (512-row window: a band fits
+    when it touches at most 8 row blocks -- always up to 449 rows).  Pairs that outgrow it re-run on the 768-row geometry (and on from there); a level that
+    sent more than 3 % of its pairs there keeps the next eligible levels on 768 rows, one that fitted lets them start small.  Results are those of the oracle
+    whichever way a level went."""
+    pool = synth.make_level_batch(8, 1500, members=((1, 6), (1, 1) if onehot else (1, 6)), seed=107, sub=0.03)
+    idx = np.arange(1400) % pool.n_pairs
+    batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    knobs.set_knob(api.KNOB_THR_SMALL, 0)          # (also clears what earlier levels of this process found)
+    knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, onehot)
+    try:
+        seen = []
+        for pk in (dict(xdrop=3000), dict(xdrop=9000), dict(xdrop=3000)):
+            aln, ln, err = knobs.align_batch(knobs.make_params(M, **pk), batch)
+            st = knobs.get_stats(0)
+            oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), pool, threads=8)
+            seen.append((bytes(st.kernel), st.n_relaunched, ost.max_width))
+            assert st.matrix_mode == (5 if onehot else 2)
+            assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx]), pk
+            for i in range(1400):
+                assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"{pk} pair {i}: path differs"
+            assert st.band_cells == ost.cells * 175, pk      # (no failed pair: attempts in an outgrown window do not count)
+    finally:
+        knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 0)
+    # X-drop 3000: narrow bands, the level tries the small window and fits; X-drop 9000: starts there on that memory, every pair outgrows it (and the 768-row
+    # window after it); the next level stays on 768 rows although it would fit
+    assert b"<6, 4, 2" in seen[0][0] and seen[0][1] == 0 and seen[0][2] <= 449, seen
+    assert b"<6, 4, 2" in seen[1][0] and seen[1][1] >= 1400 and seen[1][2] > 512, seen
+    assert b"<6, 4, 3" in seen[2][0] and seen[2][1] == 0, seen
+
+
+@pytest.mark.parametrize("xdrop,expect", [(3000, b"<6, 4, 2"), (9000, b"<6, 4, 3")])
+def test_a_level_of_eight_rounds_asks_a_sample_of_its_own_pairs(knobs, xdrop, expect):
+    """2304 short pairs (nine rounds of one workgroup per CU) and nothing remembered: one pair per CU runs on the 512-row window first and the share that
+    outgrew it chooses the window of the rest -- narrow bands: the rest stays on 512 rows; X-drop 9000: the rest runs on 768 rows and the sample's own pairs
+    re-run.  Same results."""
+    pool = synth.make_level_batch(8, 1500, members=((1, 6), (1, 6)), seed=108, sub=0.03)
+    idx = np.arange(2304) % pool.n_pairs
+    batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    pk = dict(xdrop=xdrop)
+    knobs.set_knob(api.KNOB_THR_SMALL, 0)
+    aln, ln, err = knobs.align_batch(knobs.make_params(M, **pk), batch)
+    st = knobs.get_stats(0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), pool, threads=8)
+    assert expect in bytes(st.kernel), (st.kernel, st.n_relaunched, ost.max_width)
+    assert (st.n_relaunched > 0) == (xdrop == 9000), (st.n_relaunched, ost.max_width)
+    assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx])
+    for i in range(2304):
+        assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"
+    assert st.band_cells == ost.cells * 288
+    # ... and the next level does as the sample said, without asking again
+    aln2, ln2, err2 = knobs.align_batch(knobs.make_params(M, **pk), batch)
+    assert expect in bytes(knobs.get_stats(0).kernel) and np.array_equal(ln2, ln) and np.array_equal(aln2, aln)
 
 
 # ---- protein (P = 22): tile-parallel on the precomputed column scores ----

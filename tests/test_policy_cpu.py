@@ -21,10 +21,12 @@ def _lens(n, length):
     (1301, 10000, False, "throughput; mode 2; window 768; bulk 1024 tail 277"),    # the remainder through the tile-parallel path
     (1986, 10000, False, "throughput; mode 2; window 768; bulk 1986 tail 0"),      # 94 % of the second round: stays
     (3358, 10000, True, "throughput; mode 5; window 768; bulk 3072 tail 286"),     # a leaf level (one-letter query rows)
-    (1301, 1600, False, "throughput; mode 2; window 768; bulk 1301 tail 0"),       # short pairs (3-4 tiles): no tile-parallel remainder
+    (1301, 1600, False, "throughput; mode 2; window 512; bulk 1301 tail 0"),       # short pairs: five workgroups per CU on a 512-row window; 3-4 tiles: no tile-parallel remainder
+    (33325, 1600, True, "throughput; mode 5; window 512 or 768 (a sample of the level decides)"),      # the leaf level of 100 000 x 1.6 kbp: 8+ rounds
+    (1301, 2100, False, "throughput; mode 2; window 768"),                         # R + Q > 4096: the 768-row window
     (4, 900, False, "speculative teams, 16 waves; mode 2"),                        # too few tiles to spread: two workgroups per pair
     (200, 900, False, "speculative teams, 8 waves x 2 blocks; mode 2"),
-    (300, 900, False, "throughput; mode 2; window 768; bulk 300 tail 0"),
+    (300, 900, False, "throughput; mode 2; window 512; bulk 300 tail 0"),
 ])
 def test_plan_of_a_level(built, n, length, onehot, expect):
     got = api.plan_describe(twl.make_params(M), _lens(n, length), qry_onehot=onehot)
@@ -49,3 +51,23 @@ def test_plan_depends_on_the_matrix_and_on_the_streak(built):
     assert api.plan_describe(twl.make_params(M), _lens(100, 12000), wide_streak=1000).startswith("tile-parallel; mode 2; window 1024")
     assert api.plan_describe(twl.make_params(M), _lens(100, 12000), wide_streak=1051).startswith("tile-parallel; mode 2; window 1024")
     assert api.plan_describe(twl.make_params(M), _lens(300, 12000), wide_streak=1001).startswith("tile-parallel; mode 2; window 1024")      # (more pairs than CUs: the fast window first)
+
+
+def test_a_level_that_outgrew_the_small_window_keeps_the_next_ones_off_it(built):
+    p = twl.make_params(M)
+    assert "window 512;" in api.plan_describe(p, _lens(1500, 1600))                         # nothing remembered, a small level: it tries
+    assert "window 768;" in api.plan_describe(p, _lens(1500, 1600), small_state=-16)
+    assert "window 768;" in api.plan_describe(p, _lens(1500, 1600), small_state=-1)
+    assert "window 512;" in api.plan_describe(p, _lens(1500, 1600), small_state=7)
+    # a level of eight or more rounds with nothing remembered asks a sample of its own pairs
+    assert "a sample of the level decides" in api.plan_describe(p, _lens(5000, 1600))
+    assert "window 512;" in api.plan_describe(p, _lens(5000, 1600), small_state=16)
+    assert "window 768;" in api.plan_describe(p, _lens(5000, 1600), small_state=-3)
+    assert "a sample" not in api.plan_describe(p, _lens(5000, 10000))
+    twl.set_knob(api.KNOB_THR_SMALL, 1)
+    try:
+        assert "window 768;" in api.plan_describe(p, _lens(5000, 1600))
+        twl.set_knob(api.KNOB_THR_SMALL, 2)
+        assert "window 512;" in api.plan_describe(p, _lens(5000, 10000), small_state=-3)
+    finally:
+        twl.set_knob(api.KNOB_THR_SMALL, 0)

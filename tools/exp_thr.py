@@ -1,5 +1,5 @@
 """Throughput-geometry experiments: one wide level (2048 pairs x 10 kbp, the bench's peak_level workload) and the leaf-shaped variant on a
-cross-compiled variant of the library (build_exp/*.so).   python tools/exp_thr.py <library.so | base> [pairs]"""
+cross-compiled variant of the library (build_exp/*.so).   python tools/exp_thr.py <library.so | base> [pairs] [length]"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +8,7 @@ import torch
 from twilight_amd import synth, api
 which = sys.argv[1] if len(sys.argv) > 1 else "base"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+length = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 if which != "base":
     api.LIB_PATH = os.path.abspath(which)
 api.init([0])
@@ -15,7 +16,7 @@ dev = torch.device("cuda:0")
 p = api.make_params(synth.nucleotide_matrix())
 for label, members, sub in (("profiles 1-8 x 1-8", ((1, 8), (1, 8)), 0.06), ("bench-like 0.03", ((1, 8), (1, 8)), 0.03), ("leaf x leaf", (1, 1), 0.03)):
     api.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 1 if members == (1, 1) else 0)
-    b = synth.make_level_batch(64, 10000, members=members, seed=20260501 + 3, sub=sub)
+    b = synth.make_level_batch(64, length, members=members, seed=20260501 + 3, sub=sub)
     idx = np.arange(n) % b.n_pairs
     t = lambda a: torch.from_numpy(a[idx]).to(dev)
     freq, gop, gex, ln, nm = t(b.freq), t(b.gap_open), t(b.gap_extend), t(b.len), t(b.num)

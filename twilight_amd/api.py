@@ -142,6 +142,7 @@ def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex
 
 KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN, KNOB_MT_ROUNDS, KNOB_MT_THR_JOBS, KNOB_FAIL_ROW_ALLOCS = 1, 2, 3, 4, 5, 6, 7, 8
 KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY, KNOB_MT_TAIL_PCT, KNOB_MT_WIDE, KNOB_NO_SPEC, KNOB_SCOUT_XDROP_PCT = 9, 10, 11, 12, 13, 14
+KNOB_THR_SMALL = 15
 PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 
 
@@ -150,8 +151,9 @@ def set_knob(key: int, value: int):
     _check(load_library().twl_set_knob(C.c_int(key), C.c_int(value)))
 
 
-def plan_describe(params, lens, num_cu=256, qry_onehot=False, wide_streak=0) -> str:
+def plan_describe(params, lens, num_cu=256, qry_onehot=False, wide_streak=0, small_state=0) -> str:
     """twl_plan_describe: the launch plan of a nucleotide call in words (no device needed)."""
+    wide_streak = int(wide_streak) + (100000 * (32 + int(small_state)) if small_state else 0)      # (-31 .. 31: levels the 512-row throughput window is still trusted / avoided for)
     lens = np.ascontiguousarray(lens, dtype=np.int32)
     buf = C.create_string_buffer(256)
     _check(load_library().twl_plan_describe(C.byref(params), C.c_int32(lens.shape[0]), _ptr(lens, C.c_int32), C.c_int32(num_cu), C.c_int32(int(qry_onehot)), C.c_int32(wide_streak), buf, C.c_int32(256)))

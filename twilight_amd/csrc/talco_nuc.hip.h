@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #if defined(TWL_EXP_QPRE)      // experiment builds: force either form for every geometry
     constexpr bool QPRE = !(MM == 2) || TWL_EXP_QPRE;
 #else
-    constexpr bool QPRE = !(RPL >= 3 && MM == 2);
+    constexpr bool QPRE = !((RPL >= 3 || MINW >= 5) && MM == 2);      // (five waves per SIMD: 96 registers)
 #endif
     constexpr int F4 = (P + 2) / 4;                       // float4 per packed column: 2 or 6
     constexpr bool SPARSE = (MM == 3), PRESIM = (MM == 4);

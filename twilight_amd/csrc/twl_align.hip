@@ -111,6 +111,8 @@ struct Device {
     Buf gc_zero;                          // [pair] flags of a call with pairs of both gap-character kinds (run_device)
     std::vector<uint8_t> gc_zero_host;
     std::vector<int16_t> last_err;                                               // error codes of the last run_device call, as read back by it
+    void *probe_h = nullptr; size_t probe_cap = 0;                               // pinned: error codes of a level's sample (run_device, Throughput)
+    int small_state = 0;                                                         // plan_nucleotide: what the last levels of short pairs found of the 512-row throughput window (> 0 levels it still holds for, < 0 levels still kept off it)
     int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
     void *comm = nullptr;                                                        // ncclComm_t of a sharded run (twl_comm_init)
     int comm_world = 0, comm_rank = 0;
@@ -321,6 +323,7 @@ int g_mt_lead = 320, g_mt_marg = 40;
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
 int g_scout_xdrop_pct = 100;         // twl_set_knob(TWL_KNOB_SCOUT_XDROP_PCT): X-drop of the pair scouts in percent of the call's (they only predict: a narrower band is a cheaper scout)
 int g_no_spec = 0;                   // twl_set_knob(TWL_KNOB_NO_SPEC): no speculative two-workgroup teams (tools that time the plain tile loop)
+int g_thr_small = 0;                 // twl_set_knob(TWL_KNOB_THR_SMALL): 0 = the 512-row throughput geometry for levels of short pairs (plan_nucleotide), 1 never, 2 whenever the throughput kernel runs (tests)
 int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
 int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
@@ -430,13 +433,14 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
 
 
 // ---- launch policy of the nucleotide path: a pure function of the call's facts (unit-tested without a GPU through twl_plan_describe) ----
-struct Knobs { int mt_max_pairs, mt_min_marker, mt_tail_pct, mt_wide, assume_onehot_query, no_spec; };
+struct Knobs { int mt_max_pairs, mt_min_marker, mt_tail_pct, mt_wide, assume_onehot_query, no_spec, thr_small; };
 struct NucFacts {
     int n_run = 0, num_cu = 0, marker = 0;
     const float *M = nullptr;             // 5 x 5 matrix
     float gap_char = 0;
     bool qry_onehot = false, dump = false;
     int wide_streak = 0, last_wide_pct = 0, wide_calls = 0;
+    int small_state = 0;                  // the 512-row throughput window (NucPlan::small): > 0 the last such level fitted it (levels this still holds for), < 0 it did not (levels kept off it), 0 unknown
     const int32_t *h_len = nullptr;       // [pair][2]
     const int32_t *order = nullptr;       // the pairs that run, longest first
 };
@@ -447,6 +451,9 @@ struct NucPlan {
     bool mm5 = false;                     // ... in its one-letter-query form (mode 5)
     bool lean = false;                    // the round-2 kernels (scores within fast_div's range)
     bool four = false;                    // throughput launch on 4 waves x 3 blocks, four workgroups per CU (768-row window)
+    bool small = false;                   // ... on 4 waves x 2 blocks, FIVE workgroups per CU (512-row window): levels of short pairs
+    bool probe = false;                   // ... to be decided by a sample of the level's pairs (run_device): levels of 8+ rounds with nothing remembered
+    bool held_back = false;               // ... not taken because a recent level outgrew it
     int bulk = 0, tail = 0;               // throughput: pairs in full rounds / remainder through the tile-parallel path
 };
 NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
@@ -480,7 +487,19 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
     // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the pairs fill the
     // ONE round of the throughput kernel badly -- tiles spread evenly, at the price of the scouts (~1.2x the work).  Levels of several rounds: the remainder rule below.
     pl.four = pl.lean && (pl.mm5 || mm == 2);
-    const int perRound = (pl.four ? 4 : 2) * f.num_cu;
+    // Short pairs (R + Q <= 4096: the 1.6 kbp families): their bands fit a 512-row window more often than not, and at 29 KB of LDS and 96 registers FIVE
+    // workgroups of 4 waves x 2 blocks share a CU -- five independent anti-diagonal chains per SIMD instead of four (16 384 pairs of 1.6 kbp: 95.7 -> 82.6 ms,
+    // leaf x leaf 76.2 -> 65.3 ms, tools/exp_thr.py).  A level whose pairs outgrow the window pays for it twice (they re-run on the 768-row geometry), so the
+    // outcome is remembered (run_device keeps small_state): a level that fitted lets the next sixteen eligible levels start there, one that sent more than 3 % of its
+    // pairs on keeps the next sixteen off it, and a level that finds nothing remembered asks ITS OWN pairs when it is large -- eight or more rounds: one pair per
+    // CU, spread over the cost order, runs on the small window first (they are part of the level: nothing is computed twice but what outgrows the window: ~3 ms
+    // for 1.6 kbp pairs) and the share of them that outgrew it decides for the rest -- and simply tries when it is small.
+    const long long longest = n_run > 0 ? (long long)f.h_len[2 * f.order[0]] + f.h_len[2 * f.order[0] + 1] : 0;
+    const bool eligible = pl.four && n_run > f.num_cu && k.thr_small == 0 && longest <= 4096;
+    pl.probe = eligible && f.small_state == 0 && n_run >= 8 * f.num_cu;
+    pl.small = (pl.four && n_run > f.num_cu && k.thr_small == 2) || (eligible && f.small_state >= 0);
+    pl.held_back = eligible && f.small_state < 0;
+    const int perRound = (pl.small ? 5 : (pl.four ? 4 : 2)) * f.num_cu;
     const double roundsThr = (double)n_run / (double)perRound;
     const bool mtOk = pl.lean && mm == 2 && !pl.mm5 && !f.dump && n_run <= k.mt_max_pairs && f.marker >= k.mt_min_marker &&
                       sumLen >= 3ll * f.marker * n_run && (2 * n_run <= f.num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
@@ -510,6 +529,7 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
         pl.tail = tail; pl.bulk = n_run - tail;
     }
     else pl.first = NucFirst::General;
+    if (pl.first != NucFirst::Throughput) pl.small = pl.probe = pl.held_back = false;
     return pl;
 }
 const char *nuc_first_name(NucFirst f)
@@ -526,7 +546,7 @@ const char *nuc_first_name(NucFirst f)
     }
 }
 
-Knobs current_knobs() { return Knobs{g_mt_max_pairs, g_mt_min_marker, g_mt_tail_pct, g_mt_wide, g_assume_onehot_query, g_no_spec}; }
+Knobs current_knobs() { return Knobs{g_mt_max_pairs, g_mt_min_marker, g_mt_tail_pct, g_mt_wide, g_assume_onehot_query, g_no_spec, g_thr_small}; }
 
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
@@ -626,7 +646,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int grid = 0, window = 0;
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
-    bool ranMt = false, leanMid = false, startedWide = false, thr768 = false;
+    bool ranMt = false, leanMid = false, startedWide = false, thr768 = false, thr512 = false;
+    bool probed = false;                  // the level's own sample chose the throughput window (and set the memory of it)
+    bool heldBack = false;                // a level of short pairs kept off the 512-row window by what an earlier one found
+    int from512Pairs = -1;                // pairs of a 512-row throughput launch that outgrew it (-1: no such launch)
     const int32_t *items = (const int32_t *)d->items.p;
     auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
         return prot ? launch_dp<22, 8, 9, false, false, false>(d, st, a, it, n_it, 1, g, w)
@@ -721,13 +744,14 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else {
         NucFacts nf;
         nf.n_run = n_run; nf.num_cu = d->num_cu; nf.marker = p->marker; nf.M = a.M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot; nf.dump = d->dump_on;
-        nf.wide_streak = d->wide_streak; nf.last_wide_pct = d->last_wide_pct; nf.wide_calls = d->wide_calls; nf.h_len = h_len; nf.order = order.data();
+        nf.wide_streak = d->wide_streak; nf.last_wide_pct = d->last_wide_pct; nf.wide_calls = d->wide_calls; nf.small_state = d->small_state; nf.h_len = h_len; nf.order = order.data();
         const NucPlan pl = plan_nucleotide(nf, current_knobs());
+        heldBack = pl.held_back;
         const int mm = pl.mm;
         const bool mm5 = pl.mm5;
         statMode = mm5 ? 5 : mm;
         leanMid = pl.lean && mm == 2;
-        TRACE("plan: %s, matrix mode %d%s", nuc_first_name(pl.first), mm, mm5 ? " (one-letter query rows)" : "");
+        TRACE("plan: %s%s, matrix mode %d%s", nuc_first_name(pl.first), pl.small ? " (512-row window, five workgroups per CU)" : "", mm, mm5 ? " (one-letter query rows)" : "");
         switch (pl.first) {
         case NucFirst::Dump:      // twl_dp_column_scores: the same kernel code with the score of every visited cell written out
             if (!pl.lean || n_run != 1) { g_err = "score dump: one pair, matrix within the fast-division range"; return TWL_ERR_UNSUPPORTED; }
@@ -768,12 +792,51 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             if (mm5) rc = launch_lean<6, TWL_EXP_THR_W, TWL_EXP_THR_RPL, 5, TWL_EXP_THR_MINW>(d, st, a, items, bulk, &grid, &window);
             else if (mm == 2) rc = launch_lean<6, TWL_EXP_THR_W, TWL_EXP_THR_RPL, 2, TWL_EXP_THR_MINW>(d, st, a, items, bulk, &grid, &window);
 #else
-            if (mm5) rc = launch_lean<6, 4, 3, 5, 4>(d, st, a, items, bulk, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 4, 3, 2, 4>(d, st, a, items, bulk, &grid, &window);
+            bool small = pl.small;
+            int done = 0;                 // pairs of the bulk the sample launch took
+            if (pl.probe && bulk >= 8 * d->num_cu) {
+                // the sample: one pair per CU, every (bulk / CUs)-th of the cost order, moved to the front of the launch order
+                const int S = d->num_cu;
+                std::vector<int32_t> front, rest;
+                front.reserve((size_t)S); rest.reserve((size_t)bulk);
+                for (int t = 0, nextPick = 0, j = 0; t < bulk; ++t) {
+                    if (j < S && t == nextPick) { front.push_back(order[t]); ++j; nextPick = (int)((long long)j * bulk / S); }
+                    else rest.push_back(order[t]);
+                }
+                std::copy(front.begin(), front.end(), order.begin());
+                std::copy(rest.begin(), rest.end(), order.begin() + (std::ptrdiff_t)front.size());
+                HIP_TRY(hipMemcpyAsync(d->items.p, order.data(), (size_t)bulk * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                done = (int)front.size();
+                rc = mm5 ? launch_lean<6, 4, 2, 5, 5>(d, st, a, items, done, &grid, &window) : launch_lean<6, 4, 2, 2, 5>(d, st, a, items, done, &grid, &window);
+                if (rc) return rc;
+                if ((size_t)n_pairs * sizeof(int16_t) > d->probe_cap) {
+                    if (d->probe_h) (void)hipHostFree(d->probe_h);
+                    d->probe_h = nullptr; d->probe_cap = 0;
+                    HIP_TRY(hipHostMalloc((void **)&d->probe_h, (size_t)n_pairs * sizeof(int16_t) * 2, hipHostMallocDefault));
+                    d->probe_cap = (size_t)n_pairs * sizeof(int16_t) * 2;
+                }
+                HIP_TRY(hipMemcpyAsync(d->probe_h, d_err, (size_t)n_pairs * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                int outgrew = 0;
+                for (int32_t pr : front) outgrew += ((const int16_t *)d->probe_h)[pr] == twl::kErrOverflow ? 1 : 0;
+                small = outgrew * 100 <= 3 * done;
+                d->small_state = small ? 16 : -16;        // (the levels that follow do as this one did)
+                probed = true;
+                TRACE("sample of %d pairs on the 512-row window: %d outgrew it -> the level runs on %d rows", done, outgrew, small ? 512 : 768);
+                d->kname[0] = 0;                          // (the level's kernel is the one the rest runs on)
+            }
+            if (small && mm5) rc = launch_lean<6, 4, 2, 5, 5>(d, st, a, items + done, bulk - done, &grid, &window);
+            else if (small) rc = launch_lean<6, 4, 2, 2, 5>(d, st, a, items + done, bulk - done, &grid, &window);
+            else if (mm5) rc = launch_lean<6, 4, 3, 5, 4>(d, st, a, items + done, bulk - done, &grid, &window);
+            else if (mm == 2) rc = launch_lean<6, 4, 3, 2, 4>(d, st, a, items + done, bulk - done, &grid, &window);
 #endif
             else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, bulk, &grid, &window);
             else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, bulk, &grid, &window);
-            thr768 = pl.four;
+#if defined(TWL_EXP_THR_W)
+            const bool small = false;
+#endif
+            thr768 = pl.four && !small;      // (after a sample that said no, its own pairs that outgrew 512 rows go straight on to the 1024-row window with the rest's)
+            thr512 = small;
             if (!rc && tail > 0) {
                 const std::vector<int32_t> tailOrder(order.begin() + bulk, order.begin() + n_run);
                 int g2 = 0, w2 = 0;
@@ -845,8 +908,15 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipEventRecord(d->ev[3], st));
         int grid2 = 0, w2 = 0;
-        const bool from768 = thr768 && !guardRound;      // the throughput launch's 768-row window was outgrown: first the 1024-row one (8 waves x 2 blocks), then the stages below
-        if (from768) {
+        const bool from512 = thr512 && !guardRound;      // the 512-row throughput window was outgrown: the 768-row throughput geometry takes these pairs, then the stages below
+        const bool from768 = thr768 && !guardRound && !from512;      // the throughput launch's 768-row window was outgrown: first the 1024-row one (8 waves x 2 blocks), then the stages below
+        if (from512) {
+            thr512 = false; thr768 = true; --stage;
+            from512Pairs = (int)redo.size();
+            rc = (statMode == 5) ? launch_lean<6, 4, 3, 5, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2)
+                                 : launch_lean<6, 4, 3, 2, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+        }
+        else if (from768) {
             thr768 = false; --stage;
             rc = (statMode == 5) ? launch_lean<6, 8, 2, 5, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2)
                                  : launch_lean<6, 8, 2, 2, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
@@ -875,7 +945,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         ms_redo += ms;
         d->stats.n_launches += 1;
         d->stats.n_relaunched += (int32_t)redo.size();
-        if (!mid && !guardRound && !from768) { stage = 2; }
+        if (!mid && !guardRound && !from768 && !from512) { stage = 2; }
     }
     // how the fast window fared (see wideFirst): every pair of a small call outgrew it / the call started wide -> the streak goes on
     if (!prot && leanMid && n_run > 0 && n_run <= 8) d->wide_streak = (startedWide || (redoMt && d->stats.n_relaunched >= n_run)) ? d->wide_streak + 1 : 0;
@@ -883,6 +953,11 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (startedWide) d->wide_calls += 1;
         else { d->last_wide_pct = (int)(100ll * widePairs / n_run); d->wide_calls = 0; }
     }
+    // how the 512-row throughput window fared (plan_nucleotide, small): a level that sent more than 3 % of its pairs on to the 768-row geometry keeps the next
+    // sixteen eligible levels off it, one that fitted lets them start on it; a level kept off it counts that memory down
+    if (probed || g_thr_small != 0) {}
+    else if (thr512 || from512Pairs >= 0) d->small_state = (std::max(from512Pairs, 0) * 100ll > 3ll * n_run) ? -16 : 16;
+    else if (heldBack) d->small_state += 1;
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     if (reran) {
         const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
@@ -999,6 +1074,7 @@ void twl_shutdown(void)
         if (d->stream2) (void)hipStreamDestroy(d->stream2);
         for (auto &e : d->ev2) if (e) (void)hipEventDestroy(e);
         if (d->res_h) (void)hipHostFree(d->res_h);
+        if (d->probe_h) (void)hipHostFree(d->probe_h);
         delete d;
     }
     g_devs.clear();
@@ -1306,6 +1382,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
+    case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }
@@ -1436,7 +1513,10 @@ int twl_comm_destroy(int device)
 // The launch plan of a nucleotide call, as run_device would make it, in words: no device is touched (unit tests of the policy on a CPU-only box).
 int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, int32_t num_cu, int32_t qry_onehot, int32_t wide_streak, char *out, int32_t cap)
 {
-    // (wide_streak >= 1000 encodes the other memory of the device: 1000 + 10 * calls started wide + (1 if three quarters of the last narrow-first call went wide))
+    // (wide_streak >= 1000 encodes the other memory of the device: 1000 + 10 * calls started wide + (1 if three quarters of the last narrow-first call went wide);
+    //  + 100000 * (32 + what is remembered of the 512-row throughput window, NucFacts::small_state in -31 .. 31) when that is not 0)
+    const int small_state = wide_streak >= 100000 ? wide_streak / 100000 - 32 : 0;
+    wide_streak %= 100000;
     if (!p || p->P != 6 || n_pairs < 0 || (n_pairs > 0 && !len) || num_cu < 1 || !out || cap < 64) { g_err = "bad argument (nucleotide parameters, a buffer of 64+ bytes)"; return TWL_ERR_BAD_ARGUMENT; }
     std::vector<int32_t> order;
     for (int32_t n = 0; n < n_pairs; ++n) if (len[2 * n] > 0 && len[2 * n + 1] > 0) order.push_back(n);
@@ -1446,10 +1526,11 @@ int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, 
     NucFacts nf;
     nf.n_run = (int)order.size(); nf.num_cu = num_cu; nf.marker = p->marker; nf.M = M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot != 0; nf.wide_streak = wide_streak < 1000 ? wide_streak : 0;
     if (wide_streak >= 1000) { nf.last_wide_pct = ((wide_streak - 1000) % 10) ? 100 : 0; nf.wide_calls = (wide_streak - 1000) / 10; }
+    nf.small_state = small_state;
     nf.h_len = len; nf.order = order.data();
     const NucPlan pl = plan_nucleotide(nf, current_knobs());
-    snprintf(out, (size_t)cap, "%s; mode %d; window %d; bulk %d tail %d", nuc_first_name(pl.first), pl.mm5 ? 5 : pl.mm,
-             pl.first == NucFirst::WideMt ? 3072 : ((pl.first == NucFirst::Throughput && pl.four) ? 768 : 1024), pl.bulk, pl.tail);
+    snprintf(out, (size_t)cap, "%s; mode %d; window %d%s; bulk %d tail %d", nuc_first_name(pl.first), pl.mm5 ? 5 : pl.mm,
+             pl.first == NucFirst::WideMt ? 3072 : ((pl.first == NucFirst::Throughput && pl.small) ? 512 : ((pl.first == NucFirst::Throughput && pl.four) ? 768 : 1024)), pl.probe ? " or 768 (a sample of the level decides)" : "", pl.bulk, pl.tail);
     return TWL_OK;
 }
 
