@@ -53,21 +53,21 @@ def test_plan_depends_on_the_matrix_and_on_the_streak(built):
     assert api.plan_describe(twl.make_params(M), _lens(300, 12000), wide_streak=1001).startswith("tile-parallel; mode 2; window 1024")      # (more pairs than CUs: the fast window first)
 
 
-def test_a_level_that_outgrew_the_small_window_keeps_the_next_ones_off_it(built):
+def test_a_level_that_outgrew_the_small_window_keeps_the_rest_of_the_pass_off_it(built):
     p = twl.make_params(M)
     assert "window 512;" in api.plan_describe(p, _lens(1500, 1600))                         # nothing remembered, a small level: it tries
-    assert "window 768;" in api.plan_describe(p, _lens(1500, 1600), small_state=-16)
     assert "window 768;" in api.plan_describe(p, _lens(1500, 1600), small_state=-1)
-    assert "window 512;" in api.plan_describe(p, _lens(1500, 1600), small_state=7)
+    assert "window 768;" in api.plan_describe(p, _lens(1500, 1600), small_state=-1)
+    assert "window 512;" in api.plan_describe(p, _lens(1500, 1600), small_state=1)
     # a level of eight or more rounds with nothing remembered asks a sample of its own pairs
     assert "a sample of the level decides" in api.plan_describe(p, _lens(5000, 1600))
-    assert "window 512;" in api.plan_describe(p, _lens(5000, 1600), small_state=16)
-    assert "window 768;" in api.plan_describe(p, _lens(5000, 1600), small_state=-3)
+    assert "window 512;" in api.plan_describe(p, _lens(5000, 1600), small_state=1)
+    assert "window 768;" in api.plan_describe(p, _lens(5000, 1600), small_state=-1)
     assert "a sample" not in api.plan_describe(p, _lens(5000, 10000))
     twl.set_knob(api.KNOB_THR_SMALL, 1)
     try:
         assert "window 768;" in api.plan_describe(p, _lens(5000, 1600))
         twl.set_knob(api.KNOB_THR_SMALL, 2)
-        assert "window 512;" in api.plan_describe(p, _lens(5000, 10000), small_state=-3)
+        assert "window 512;" in api.plan_describe(p, _lens(5000, 10000), small_state=-1)
     finally:
         twl.set_knob(api.KNOB_THR_SMALL, 0)

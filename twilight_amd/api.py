@@ -153,7 +153,7 @@ def set_knob(key: int, value: int):
 
 def plan_describe(params, lens, num_cu=256, qry_onehot=False, wide_streak=0, small_state=0) -> str:
     """twl_plan_describe: the launch plan of a nucleotide call in words (no device needed)."""
-    wide_streak = int(wide_streak) + (100000 * (32 + int(small_state)) if small_state else 0)      # (-31 .. 31: levels the 512-row throughput window is still trusted / avoided for)
+    wide_streak = int(wide_streak) + (100000 * (32 + int(small_state)) if small_state else 0)      # (1 / -1: the earlier levels of the pass fitted / outgrew the 512-row throughput window)
     lens = np.ascontiguousarray(lens, dtype=np.int32)
     buf = C.create_string_buffer(256)
     _check(load_library().twl_plan_describe(C.byref(params), C.c_int32(lens.shape[0]), _ptr(lens, C.c_int32), C.c_int32(num_cu), C.c_int32(int(qry_onehot)), C.c_int32(wide_streak), buf, C.c_int32(256)))

@@ -112,7 +112,7 @@ struct Device {
     std::vector<uint8_t> gc_zero_host;
     std::vector<int16_t> last_err;                                               // error codes of the last run_device call, as read back by it
     void *probe_h = nullptr; size_t probe_cap = 0;                               // pinned: error codes of a level's sample (run_device, Throughput)
-    int small_state = 0;                                                         // plan_nucleotide: what the last levels of short pairs found of the 512-row throughput window (> 0 levels it still holds for, < 0 levels still kept off it)
+    int small_state = 0, small_last_n = 0;                                       // plan_nucleotide: what the levels of short pairs of this pass found of the 512-row throughput window (1 fits, -1 outgrown), and the pairs of the last such level
     int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
     void *comm = nullptr;                                                        // ncclComm_t of a sharded run (twl_comm_init)
     int comm_world = 0, comm_rank = 0;
@@ -440,7 +440,7 @@ struct NucFacts {
     float gap_char = 0;
     bool qry_onehot = false, dump = false;
     int wide_streak = 0, last_wide_pct = 0, wide_calls = 0;
-    int small_state = 0;                  // the 512-row throughput window (NucPlan::small): > 0 the last such level fitted it (levels this still holds for), < 0 it did not (levels kept off it), 0 unknown
+    int small_state = 0;                  // the 512-row throughput window (NucPlan::small) on the earlier levels of this pass: 1 they fitted it, -1 one outgrew it, 0 nothing known
     const int32_t *h_len = nullptr;       // [pair][2]
     const int32_t *order = nullptr;       // the pairs that run, longest first
 };
@@ -490,10 +490,13 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
     // Short pairs (R + Q <= 4096: the 1.6 kbp families): their bands fit a 512-row window more often than not, and at 29 KB of LDS and 96 registers FIVE
     // workgroups of 4 waves x 2 blocks share a CU -- five independent anti-diagonal chains per SIMD instead of four (16 384 pairs of 1.6 kbp: 95.7 -> 82.6 ms,
     // leaf x leaf 76.2 -> 65.3 ms, tools/exp_thr.py).  A level whose pairs outgrow the window pays for it twice (they re-run on the 768-row geometry), so the
-    // outcome is remembered (run_device keeps small_state): a level that fitted lets the next sixteen eligible levels start there, one that sent more than 3 % of its
-    // pairs on keeps the next sixteen off it, and a level that finds nothing remembered asks ITS OWN pairs when it is large -- eight or more rounds: one pair per
-    // CU, spread over the cost order, runs on the small window first (they are part of the level: nothing is computed twice but what outgrows the window: ~3 ms
-    // for 1.6 kbp pairs) and the share of them that outgrew it decides for the rest -- and simply tries when it is small.
+    // outcome is remembered for the rest of the pass (run_device keeps small_state; bands widen up the tree, and a level LARGER than the one before it is the
+    // start of another pass or family: nothing is known again): after a level that fitted the next ones start there, after one that sent more than 1 % of its
+    // pairs on the rest of the pass stays off it (the window is worth ~16 % of a level's time; the pairs that outgrow it run twice AND their re-run is a launch
+    // of its own that takes a pair's full latency, ~3.5 ms for 1.6 kbp pairs, however few they are: on 100 000 x 1.6 kbp levels of 3-5 % lost 2-11 %), and a
+    // level that finds nothing remembered asks ITS OWN pairs when it is large -- eight or more rounds: one pair per CU, spread over the cost order, runs on the
+    // small window first (they are part of the level: nothing is computed twice but what outgrows the window; ~3 ms) and the share of them that outgrew it
+    // decides for the rest -- and simply tries when it is small.
     const long long longest = n_run > 0 ? (long long)f.h_len[2 * f.order[0]] + f.h_len[2 * f.order[0] + 1] : 0;
     const bool eligible = pl.four && n_run > f.num_cu && k.thr_small == 0 && longest <= 4096;
     pl.probe = eligible && f.small_state == 0 && n_run >= 8 * f.num_cu;
@@ -648,7 +651,6 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     int statMode = -1, statSpec = 0;
     bool ranMt = false, leanMid = false, startedWide = false, thr768 = false, thr512 = false;
     bool probed = false;                  // the level's own sample chose the throughput window (and set the memory of it)
-    bool heldBack = false;                // a level of short pairs kept off the 512-row window by what an earlier one found
     int from512Pairs = -1;                // pairs of a 512-row throughput launch that outgrew it (-1: no such launch)
     const int32_t *items = (const int32_t *)d->items.p;
     auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
@@ -744,9 +746,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     else {
         NucFacts nf;
         nf.n_run = n_run; nf.num_cu = d->num_cu; nf.marker = p->marker; nf.M = a.M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot; nf.dump = d->dump_on;
-        nf.wide_streak = d->wide_streak; nf.last_wide_pct = d->last_wide_pct; nf.wide_calls = d->wide_calls; nf.small_state = d->small_state; nf.h_len = h_len; nf.order = order.data();
+        nf.wide_streak = d->wide_streak; nf.last_wide_pct = d->last_wide_pct; nf.wide_calls = d->wide_calls; nf.small_state = (n_run > d->small_last_n) ? 0 : d->small_state; nf.h_len = h_len; nf.order = order.data();
         const NucPlan pl = plan_nucleotide(nf, current_knobs());
-        heldBack = pl.held_back;
+        if (pl.first == NucFirst::Throughput && (pl.small || pl.held_back)) { if (n_run > d->small_last_n) d->small_state = 0; d->small_last_n = n_run; }
         const int mm = pl.mm;
         const bool mm5 = pl.mm5;
         statMode = mm5 ? 5 : mm;
@@ -819,8 +821,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 HIP_TRY(hipStreamSynchronize(st));
                 int outgrew = 0;
                 for (int32_t pr : front) outgrew += ((const int16_t *)d->probe_h)[pr] == twl::kErrOverflow ? 1 : 0;
-                small = outgrew * 100 <= 3 * done;
-                d->small_state = small ? 16 : -16;        // (the levels that follow do as this one did)
+                small = outgrew * 100 <= 1 * done;
+                d->small_state = small ? 1 : -1;          // (the levels that follow in this pass do as this one did)
                 probed = true;
                 TRACE("sample of %d pairs on the 512-row window: %d outgrew it -> the level runs on %d rows", done, outgrew, small ? 512 : 768);
                 d->kname[0] = 0;                          // (the level's kernel is the one the rest runs on)
@@ -953,11 +955,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (startedWide) d->wide_calls += 1;
         else { d->last_wide_pct = (int)(100ll * widePairs / n_run); d->wide_calls = 0; }
     }
-    // how the 512-row throughput window fared (plan_nucleotide, small): a level that sent more than 3 % of its pairs on to the 768-row geometry keeps the next
-    // sixteen eligible levels off it, one that fitted lets them start on it; a level kept off it counts that memory down
+    // how the 512-row throughput window fared (plan_nucleotide, small): a level that sent more than 1 % of its pairs on to the 768-row geometry keeps the rest
+    // of the pass off it, one that fitted lets the next level start on it
     if (probed || g_thr_small != 0) {}
-    else if (thr512 || from512Pairs >= 0) d->small_state = (std::max(from512Pairs, 0) * 100ll > 3ll * n_run) ? -16 : 16;
-    else if (heldBack) d->small_state += 1;
+    else if (thr512 || from512Pairs >= 0) d->small_state = (std::max(from512Pairs, 0) * 100ll > 1ll * n_run) ? -1 : 1;
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     if (reran) {
         const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
@@ -1382,7 +1383,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
-    case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = 0; return TWL_OK;      // (and forgets what earlier levels found)
+    case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
     }
 }
@@ -1514,7 +1515,7 @@ int twl_comm_destroy(int device)
 int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, int32_t num_cu, int32_t qry_onehot, int32_t wide_streak, char *out, int32_t cap)
 {
     // (wide_streak >= 1000 encodes the other memory of the device: 1000 + 10 * calls started wide + (1 if three quarters of the last narrow-first call went wide);
-    //  + 100000 * (32 + what is remembered of the 512-row throughput window, NucFacts::small_state in -31 .. 31) when that is not 0)
+    //  + 100000 * (32 + what the pass remembers of the 512-row throughput window, NucFacts::small_state: -1 / 1) when that is not 0)
     const int small_state = wide_streak >= 100000 ? wide_streak / 100000 - 32 : 0;
     wide_streak %= 100000;
     if (!p || p->P != 6 || n_pairs < 0 || (n_pairs > 0 && !len) || num_cu < 1 || !out || cap < 64) { g_err = "bad argument (nucleotide parameters, a buffer of 64+ bytes)"; return TWL_ERR_BAD_ARGUMENT; }
