@@ -1,5 +1,5 @@
 """Throughput-geometry experiments: one wide level (2048 pairs x 10 kbp, the bench's peak_level workload) and the leaf-shaped variant on a
-cross-compiled variant of the library (build_exp/*.so).   python tools/exp_thr.py <library.so | base> [pairs] [length]"""
+cross-compiled variant of the library (build_exp/*.so).   python tools/exp_thr.py <library.so | base> [pairs] [length] [TWL_KNOB_THR_SMALL]"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +9,12 @@ from twilight_amd import synth, api
 which = sys.argv[1] if len(sys.argv) > 1 else "base"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 length = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
+small = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 if which != "base":
     api.LIB_PATH = os.path.abspath(which)
 api.init([0])
+if small:
+    api.set_knob(api.KNOB_THR_SMALL, small)
 dev = torch.device("cuda:0")
 p = api.make_params(synth.nucleotide_matrix())
 for label, members, sub in (("profiles 1-8 x 1-8", ((1, 8), (1, 8)), 0.06), ("bench-like 0.03", ((1, 8), (1, 8)), 0.03), ("leaf x leaf", (1, 1), 0.03)):
