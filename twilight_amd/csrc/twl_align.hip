@@ -412,7 +412,10 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
-        rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, WIDE ? 16 : SW, WIDE ? 1 : SR, MM, 1, 2>(d, st, a, nScout);
+        // (nucleotide scouts of the throughput geometry run ~330 diagonals from one cell: their band opens by a row per diagonal and cannot outgrow 449 rows, so
+        //  they take the 512-row window -- 4 waves x 2 blocks, FIVE workgroups per CU, see plan_nucleotide -- whatever the tiles need)
+        if constexpr (P == 6 && TW == 4 && !WIDE) rc = thrS ? launch_mt_kernel<6, 4, 2, MM, 5, 2>(d, st, a, nScout) : launch_mt_kernel<P, SW, SR, MM, 1, 2>(d, st, a, nScout);
+        else rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, WIDE ? 16 : SW, WIDE ? 1 : SR, MM, 1, 2>(d, st, a, nScout);
         if (rc) return rc;
     }
     for (int r = 0; r < rounds; ++r) {
@@ -650,7 +653,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
     bool ranMt = false, leanMid = false, startedWide = false, thr768 = false, thr512 = false;
-    bool probed = false;                  // the level's own sample chose the throughput window (and set the memory of it)
+    bool probed = false;                  // the level's own sample kept the level off the 512-row window (and set the memory of it)
     int from512Pairs = -1;                // pairs of a 512-row throughput launch that outgrew it (-1: no such launch)
     const int32_t *items = (const int32_t *)d->items.p;
     auto launch_wide = [&](const int32_t *it, int n_it, int *g, int *w) {
@@ -823,7 +826,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 for (int32_t pr : front) outgrew += ((const int16_t *)d->probe_h)[pr] == twl::kErrOverflow ? 1 : 0;
                 small = outgrew * 100 <= 1 * done;
                 d->small_state = small ? 1 : -1;          // (the levels that follow in this pass do as this one did)
-                probed = true;
+                probed = !small;                          // (a sample that said yes leaves the verdict to the whole level, below)
                 TRACE("sample of %d pairs on the 512-row window: %d outgrew it -> the level runs on %d rows", done, outgrew, small ? 512 : 768);
                 d->kname[0] = 0;                          // (the level's kernel is the one the rest runs on)
             }
