@@ -220,6 +220,7 @@ def test_throughput_level_pairs_that_outgrow_the_768_row_window(knobs, onehot):
     pk = dict(xdrop=9000)
     p = knobs.make_params(M, **pk)
     knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, onehot)
+    knobs.set_knob(api.KNOB_THR_SMALL, 1)          # (this test is about the 768-row window: not the 512-row one first)
     try:
         aln, ln, err = knobs.align_batch(p, batch)
         st = knobs.get_stats(0)
@@ -288,6 +289,34 @@ def test_a_level_of_eight_rounds_asks_a_sample_of_its_own_pairs(knobs, xdrop, ex
     # ... and the next level does as the sample said, without asking again
     aln2, ln2, err2 = knobs.align_batch(knobs.make_params(M, **pk), batch)
     assert expect in bytes(knobs.get_stats(0).kernel) and np.array_equal(ln2, ln) and np.array_equal(aln2, aln)
+
+
+@pytest.mark.parametrize("onehot", [0, 1])
+@pytest.mark.parametrize("xdrop", [5000, 9000])
+def test_long_pairs_that_outgrow_the_512_row_window_rerun_tile_parallel(knobs, onehot, xdrop):
+    """A level of long pairs tries the 512-row window too; the pairs that outgrow it re-run with all their tiles at once (up to TWL_KNOB_MT_MAX_PAIRS of them,
+    8+ tiles each) instead of one pair after the other -- a 10 kbp pair's full latency is ~18 ms, its tiles side by side ~3 ms -- and go on to the 3072-row
+    stage from there.  1200 pairs of ~5 kbp (94 % of one round of five workgroups per CU: the throughput launch); X-drop 9000: every pair outgrows 512 rows."""
+    pool = synth.make_level_batch(8, 5000, members=((1, 6), (1, 1) if onehot else (1, 6)), seed=109)
+    idx = np.arange(1200) % pool.n_pairs
+    batch = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    pk = dict(xdrop=xdrop)
+    knobs.set_knob(api.KNOB_THR_SMALL, 0)
+    knobs.set_knob(api.KNOB_MT_MAX_PAIRS, 2048)       # (all 1200 through the tile-parallel re-run)
+    knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, onehot)
+    try:
+        aln, ln, err = knobs.align_batch(knobs.make_params(M, **pk), batch)
+        st = knobs.get_stats(0)
+    finally:
+        knobs.set_knob(api.KNOB_ASSUME_ONEHOT_QUERY, 0)
+    oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), pool, threads=8)
+    assert b"<6, 4, 2" in bytes(st.kernel) and st.matrix_mode == (5 if onehot else 2), (st.kernel, st.matrix_mode)
+    if xdrop == 9000:
+        assert ost.max_width > 512 and st.n_relaunched >= 1200 and st.mt_tiles_predicted + st.mt_tiles_inline > 0, (ost.max_width, st.n_relaunched)
+    assert np.array_equal(err, oerr[idx]) and np.array_equal(ln, on[idx])
+    for i in range(1200):
+        assert np.array_equal(aln[i, : ln[i]], oa[idx[i], : on[idx[i]]]), f"pair {i}: path differs"
+    assert st.band_cells == ost.cells * 150
 
 
 # ---- protein (P = 22): tile-parallel on the precomputed column scores ----

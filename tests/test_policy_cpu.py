@@ -17,13 +17,14 @@ def _lens(n, length):
     (1, 10000, False, "tile-parallel; mode 2; window 1024"),                       # a lone long pair: every tile at once
     (128, 10000, False, "tile-parallel; mode 2; window 1024"),                     # up to CUs / 2 pairs: always
     (200, 10000, False, "tile-parallel; mode 2; window 1024"),                     # a badly filled single round of the throughput kernel
-    (900, 10000, False, "throughput; mode 2; window 768; bulk 900 tail 0"),        # 88 % of one round of 4 x 256 workgroups
-    (1301, 10000, False, "throughput; mode 2; window 768; bulk 1024 tail 277"),    # the remainder through the tile-parallel path
-    (1986, 10000, False, "throughput; mode 2; window 768; bulk 1986 tail 0"),      # 94 % of the second round: stays
-    (3358, 10000, True, "throughput; mode 5; window 768; bulk 3072 tail 286"),     # a leaf level (one-letter query rows)
+    (900, 10000, False, "tile-parallel; mode 2; window 1024"),                     # 70 % of one round of 5 x 256 workgroups: tiles spread better
+    (1200, 10000, False, "throughput; mode 2; window 512; bulk 1200 tail 0"),      # 94 % of one round
+    (1301, 10000, False, "throughput; mode 2; window 512; bulk 1280 tail 21"),     # the remainder through the tile-parallel path
+    (1986, 10000, False, "throughput; mode 2; window 512; bulk 1280 tail 706"),
+    (3358, 10000, True, "throughput; mode 5; window 512; bulk 2560 tail 798"),     # a leaf level (one-letter query rows): it tries the small window
+    (5000, 10000, False, "throughput; mode 2; window 512; bulk 5000 tail 0"),      # 91 % of the fourth round: stays
     (1301, 1600, False, "throughput; mode 2; window 512; bulk 1301 tail 0"),       # short pairs: five workgroups per CU on a 512-row window; 3-4 tiles: no tile-parallel remainder
     (33325, 1600, True, "throughput; mode 5; window 512 or 768 (a sample of the level decides)"),      # the leaf level of 100 000 x 1.6 kbp: 8+ rounds
-    (1301, 2100, False, "throughput; mode 2; window 768"),                         # R + Q > 4096: the 768-row window
     (4, 900, False, "speculative teams, 16 waves; mode 2"),                        # too few tiles to spread: two workgroups per pair
     (200, 900, False, "speculative teams, 8 waves x 2 blocks; mode 2"),
     (300, 900, False, "throughput; mode 2; window 512; bulk 300 tail 0"),
@@ -63,7 +64,9 @@ def test_a_level_that_outgrew_the_small_window_keeps_the_rest_of_the_pass_off_it
     assert "a sample of the level decides" in api.plan_describe(p, _lens(5000, 1600))
     assert "window 512;" in api.plan_describe(p, _lens(5000, 1600), small_state=1)
     assert "window 768;" in api.plan_describe(p, _lens(5000, 1600), small_state=-1)
-    assert "a sample" not in api.plan_describe(p, _lens(5000, 10000))
+    assert "a sample" not in api.plan_describe(p, _lens(5000, 10000))                    # long pairs are not sampled (a pair's latency): they try, or do as the level before them
+    assert api.plan_describe(p, _lens(1986, 10000), small_state=-1).startswith("throughput; mode 2; window 768; bulk 1986 tail 0")
+    assert api.plan_describe(p, _lens(3358, 10000), qry_onehot=True, small_state=-1).startswith("throughput; mode 5; window 768; bulk 3072 tail 286")
     twl.set_knob(api.KNOB_THR_SMALL, 1)
     try:
         assert "window 768;" in api.plan_describe(p, _lens(5000, 1600))

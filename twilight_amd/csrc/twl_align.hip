@@ -490,7 +490,7 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
     // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the pairs fill the
     // ONE round of the throughput kernel badly -- tiles spread evenly, at the price of the scouts (~1.2x the work).  Levels of several rounds: the remainder rule below.
     pl.four = pl.lean && (pl.mm5 || mm == 2);
-    // Short pairs (R + Q <= 4096: the 1.6 kbp families): their bands fit a 512-row window more often than not, and at 29 KB of LDS and 96 registers FIVE
+    // With X-drop 5000 a band is ~440 rows wide whatever the length of the pair: most pairs fit a 512-row window, and at 29 KB of LDS and 96 registers FIVE
     // workgroups of 4 waves x 2 blocks share a CU -- five independent anti-diagonal chains per SIMD instead of four (16 384 pairs of 1.6 kbp: 95.7 -> 82.6 ms,
     // leaf x leaf 76.2 -> 65.3 ms, tools/exp_thr.py).  A level whose pairs outgrow the window pays for it twice (they re-run on the 768-row geometry), so the
     // outcome is remembered for the rest of the pass (run_device keeps small_state; bands widen up the tree, and a level LARGER than the one before it is the
@@ -501,8 +501,12 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
     // small window first (they are part of the level: nothing is computed twice but what outgrows the window; ~3 ms) and the share of them that outgrew it
     // decides for the rest -- and simply tries when it is small.
     const long long longest = n_run > 0 ? (long long)f.h_len[2 * f.order[0]] + f.h_len[2 * f.order[0] + 1] : 0;
-    const bool eligible = pl.four && n_run > f.num_cu && k.thr_small == 0 && longest <= 4096;
-    pl.probe = eligible && f.small_state == 0 && n_run >= 8 * f.num_cu;
+    // LONG pairs are eligible too (late round 4: on 10 000 x 10 kbp no pair of any level outgrows 512 rows, and the five workgroups are worth 97.8 against 110 ms
+    // on its leaf level, 442 against 469 ms per pass): what made a lost bet expensive there -- the re-run of a FEW 10 kbp pairs, one after the other, a pair's
+    // full latency of ~18 ms -- goes through the tile-parallel path instead (run_device: ~3 ms).  They are not sampled (a sample would cost that latency): the
+    // first level of a pass pairs sibling leaves, the most similar sequences of the family, and simply tries; the levels above it do as it fared.
+    const bool eligible = pl.four && n_run > f.num_cu && k.thr_small == 0;
+    pl.probe = eligible && f.small_state == 0 && n_run >= 8 * f.num_cu && longest <= 4096;
     pl.small = (pl.four && n_run > f.num_cu && k.thr_small == 2) || (eligible && f.small_state >= 0);
     pl.held_back = eligible && f.small_state < 0;
     const int perRound = (pl.small ? 5 : (pl.four ? 4 : 2)) * f.num_cu;
@@ -916,10 +920,21 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         const bool from512 = thr512 && !guardRound;      // the 512-row throughput window was outgrown: the 768-row throughput geometry takes these pairs, then the stages below
         const bool from768 = thr768 && !guardRound && !from512;      // the throughput launch's 768-row window was outgrown: first the 1024-row one (8 waves x 2 blocks), then the stages below
         if (from512) {
-            thr512 = false; thr768 = true; --stage;
+            thr512 = false; --stage;
             from512Pairs = (int)redo.size();
-            rc = (statMode == 5) ? launch_lean<6, 4, 3, 5, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2)
-                                 : launch_lean<6, 4, 3, 2, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+            // a few LONG pairs (8+ tiles each): all their tiles at once (1024-row stitch window) instead of one pair after the other for a pair's full latency
+            long long redoLen = 0;
+            for (int32_t n : redo) redoLen += (long long)h_len[2 * n] + h_len[2 * n + 1];
+            const bool viaMt = (int)redo.size() <= g_mt_max_pairs && p->marker >= g_mt_min_marker && redoLen >= 8ll * p->marker * (long long)redo.size() && !d->dump_on;
+            if (viaMt) {
+                rc = (statMode == 5) ? launch_mt<6, 5, 3, false, 4>(d, st, a, (const int32_t *)d->items.p, redo, (int)redo.size(), h_len, &grid2, &w2)
+                                     : launch_mt<6, 2, 3, false, 4>(d, st, a, (const int32_t *)d->items.p, redo, (int)redo.size(), h_len, &grid2, &w2);
+                redoMt = true;       // (what outgrows that goes on to the 3072-row stage)
+            } else {
+                thr768 = true;
+                rc = (statMode == 5) ? launch_lean<6, 4, 3, 5, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2)
+                                     : launch_lean<6, 4, 3, 2, 4>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), &grid2, &w2);
+            }
         }
         else if (from768) {
             thr768 = false; --stage;
@@ -958,10 +973,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (startedWide) d->wide_calls += 1;
         else { d->last_wide_pct = (int)(100ll * widePairs / n_run); d->wide_calls = 0; }
     }
-    // how the 512-row throughput window fared (plan_nucleotide, small): a level that sent more than 1 % of its pairs on to the 768-row geometry keeps the rest
+    // how the 512-row throughput window fared (plan_nucleotide, small): a level that sent more than 1 % of its pairs on (5 % when they are long) keeps the rest
     // of the pass off it, one that fitted lets the next level start on it
     if (probed || g_thr_small != 0) {}
-    else if (thr512 || from512Pairs >= 0) d->small_state = (std::max(from512Pairs, 0) * 100ll > 1ll * n_run) ? -1 : 1;
+    else if (thr512 || from512Pairs >= 0) {
+        const long long longestRun = n_run > 0 ? (long long)h_len[2 * order[0]] + h_len[2 * order[0] + 1] : 0;      // (order[0] is the longest pair, or one of the sample's: lengths of a level are alike)
+        d->small_state = (std::max(from512Pairs, 0) * 100ll > (longestRun <= 4096 ? 1ll : 5ll) * n_run) ? -1 : 1;   // (long pairs re-run tile-parallel: the bet is lost later)
+    }
     // a band that outgrew even the widest window (only possible with flen > 4096, i.e. in a retry of the deferred pass)
     if (reran) {
         const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
