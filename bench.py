@@ -321,6 +321,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()          # rank 0 has written the family
     twl.init([local_rank])
+    if os.environ.get("TWL_BENCH_MT_TAIL_PCT"):          # development: how full a last round of the throughput kernel must be to stay there
+        twl.set_knob(twl.knobs.KNOB_MT_TAIL_PCT, int(os.environ["TWL_BENCH_MT_TAIL_PCT"]))
     if os.environ.get("TWL_BENCH_THR_SMALL"):            # development: the 512-row throughput window never (1) / on every throughput level (2)
         twl.set_knob(twl.knobs.KNOB_THR_SMALL, int(os.environ["TWL_BENCH_THR_SMALL"]))
     if os.environ.get("TWL_BENCH_SCOUT_XDROP_PCT"):      # development: what a narrower band of the pair scouts costs and saves

@@ -319,6 +319,36 @@ def test_long_pairs_that_outgrow_the_512_row_window_rerun_tile_parallel(knobs, o
     assert st.band_cells == ost.cells * 150
 
 
+def test_tile_jobs_take_the_512_row_window_while_the_pass_fits_it(knobs):
+    """After a throughput level that fitted the 512-row window the tile jobs of the tile-parallel levels above it run on that geometry too (five workgroups
+    per CU); a tile that outgrows it is computed in line by the stitch launch (its failed record is of a window narrower than the stitch launch's), and
+    once a level had tiles go that way the rest of the pass is back on 768 rows.  Same results every time."""
+    knobs.set_knob(api.KNOB_THR_SMALL, 0)
+    pool = synth.make_level_batch(8, 1500, members=((1, 6), (1, 6)), seed=107, sub=0.03)
+    idx = np.arange(1400) % pool.n_pairs
+    wide_level = synth.LevelBatch(P=pool.P, seq_len=pool.seq_len, freq=pool.freq[idx], gap_open=pool.gap_open[idx], gap_extend=pool.gap_extend[idx], len=pool.len[idx], num=pool.num[idx])
+    knobs.align_batch(knobs.make_params(M, xdrop=3000), wide_level)
+    assert b"<6, 4, 2" in bytes(knobs.get_stats(0).kernel) and knobs.get_stats(0).n_relaunched == 0
+    pool2 = synth.make_level_batch(10, 6000, members=((1, 6), (1, 6)), seed=110, sub=0.03)
+    idx2 = np.arange(100) % pool2.n_pairs
+    level = synth.LevelBatch(P=pool2.P, seq_len=pool2.seq_len, freq=pool2.freq[idx2], gap_open=pool2.gap_open[idx2], gap_extend=pool2.gap_extend[idx2], len=pool2.len[idx2], num=pool2.num[idx2])
+    seen = []
+    for xdrop in (3000, 9000, 3000):
+        pk = dict(xdrop=xdrop)
+        aln, ln, err = knobs.align_batch(knobs.make_params(M, **pk), level)
+        st = knobs.get_stats(0)
+        oa, on, oerr, ost = O.align_batch(O.make_params(M, **pk), pool2, threads=8)
+        seen.append((bytes(st.kernel)[:48], st.mt_tiles_predicted, st.mt_tiles_inline, ost.max_width))
+        assert st.speculative == 3
+        assert np.array_equal(err, oerr[idx2]) and np.array_equal(ln, on[idx2]), pk
+        for i in range(100):
+            assert np.array_equal(aln[i, : ln[i]], oa[idx2[i], : on[idx2[i]]]), f"{pk} pair {i}: path differs"
+        assert st.band_cells == ost.cells * 10, pk
+    assert b"<6, 4, 2, 2, 5" in seen[0][0] and seen[0][2] == 0, seen                  # small tiles, every one kept
+    assert b"<6, 4, 2, 2, 5" in seen[1][0] and seen[1][2] > 0 and seen[1][3] > 512, seen      # tiles outgrew the window: computed in line
+    assert b"<6, 4, 3, 2, 4" in seen[2][0] and seen[2][2] == 0, seen                  # the pass is off the small window
+
+
 # ---- protein (P = 22): tile-parallel on the precomputed column scores ----
 PM = synth.protein_matrix()
 

@@ -332,8 +332,13 @@ struct Knobs;
 
 template <int P, int MM, int TRPL, bool WIDE = false, int TW = 8>      // TW x TRPL: waves and 64-row blocks per wave of the throughput geometry (nucleotide 4 x 3: 768 rows, four workgroups per CU; protein 8 x 1: 512 rows, two)
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
-              const int32_t *h_len, int *grid_out, int *window_out)
+              const int32_t *h_len, int *grid_out, int *window_out, bool small_tiles = false)
 {
+    // small_tiles (nucleotide, throughput geometry): the tile jobs too run on 4 waves x 2 blocks, five workgroups per CU -- the earlier levels of this pass
+    // fitted the 512-row window (plan_nucleotide, small).  A tile that outgrows it leaves a failed record of a window narrower than the stitch launch's, which
+    // the stitch launch does not adopt: it computes that tile in line (run_device counts them and takes the pass off the small window when they are many).
+    constexpr bool kCanSmall = (P == 6 && TW == 4 && !WIDE);
+    const bool smallT = kCanSmall && small_tiles;
     // WIDE (nucleotide): the tiles and the stitch launch on 16 waves x 3 blocks, a 3072-row window -- for the pairs whose band outgrew the
     // 1024-row window of the fast geometries.  Until round 4 those ran their ~20 tiles one after the other on the 2048- and 4608-row kernels
     // (0.2-0.6 s per 10 kbp pair); their tiles are as independent as anybody's.  The scouts keep the narrow geometry: a scout's band opens
@@ -394,7 +399,8 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     const bool thr = !WIDE && nTile > g_mt_thr_jobs;
     TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, WIDE ? "16x3 (wide)" : (thr ? "throughput geometry" : "16x1"));
     if (!d->kname[0]) {
-        if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TW, TRPL, MM, P, MM);
+        if (thr && smallT) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 4, 2, %d, 5, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, MM, P, MM);
+        else if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TW, TRPL, MM, P, MM);
         else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, %d, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, SR, MM);
     }
     if (WIDE) {
@@ -424,7 +430,9 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
                            (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
         HIP_TRY(hipGetLastError());
         a.mt_jobs = (const int32_t *)d->mt_jobs.p + 3 * (size_t)nScout;
-        rc = thr ? launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
+        if constexpr (kCanSmall) rc = thr ? (smallT ? launch_mt_kernel<6, 4, 2, MM, 5, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out))
+                                          : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
+        else rc = thr ? launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
         if (rc) return rc;
         a.mt_jobs = nullptr;
         a.mt_inline = (r == rounds - 1) ? 1 : 0;
@@ -657,6 +665,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
     bool ranMt = false, leanMid = false, startedWide = false, thr768 = false, thr512 = false;
+    bool smallTiles = false;              // the tile jobs of a tile-parallel launch of this call ran on the 512-row window
     bool probed = false;                  // the level's own sample kept the level off the 512-row window (and set the memory of it)
     int from512Pairs = -1;                // pairs of a 512-row throughput launch that outgrew it (-1: no such launch)
     const int32_t *items = (const int32_t *)d->items.p;
@@ -774,7 +783,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             statSpec = 3; ranMt = true; startedWide = true;
             break;
         case NucFirst::Mt:        // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
-            rc = launch_mt<6, 2, 3, false, 4>(d, st, a, items, order, n_run, h_len, &grid, &window);
+            smallTiles = nf.small_state > 0;      // (the throughput levels of this pass fitted the 512-row window: so do the tiles of their pairs' descendants, until they do not)
+            rc = launch_mt<6, 2, 3, false, 4>(d, st, a, items, order, n_run, h_len, &grid, &window, smallTiles);
             statSpec = 3; ranMt = true;
             break;
         case NucFirst::SpecShared:
@@ -850,8 +860,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 const std::vector<int32_t> tailOrder(order.begin() + bulk, order.begin() + n_run);
                 int g2 = 0, w2 = 0;
                 // (one-letter query rows: the tiles too take the four-product form of the column score)
-                rc = mm5 ? launch_mt<6, 5, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2)
-                         : launch_mt<6, 2, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2);
+                smallTiles = small && !probed;
+                rc = mm5 ? launch_mt<6, 5, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2, smallTiles)
+                         : launch_mt<6, 2, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2, smallTiles);
                 ranMt = true;
             }
             break;
@@ -973,6 +984,9 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if (startedWide) d->wide_calls += 1;
         else { d->last_wide_pct = (int)(100ll * widePairs / n_run); d->wide_calls = 0; }
     }
+    // tiles that outgrew the 512-row window were computed in line by the stitch launch, one after the other per pair -- the expensive way to lose (10 000 x 10 kbp:
+    // its levels 6 and 7, where tiles begin to outgrow 512 rows, took 34 and 33 ms instead of 23 and 16 with a 2 % allowance): ANY tile in line takes the pass off it
+    if (smallTiles && g_thr_small == 0 && mtStat[1] > 0ull) d->small_state = -1;
     // how the 512-row throughput window fared (plan_nucleotide, small): a level that sent more than 1 % of its pairs on (5 % when they are long) keeps the rest
     // of the pass off it, one that fitted lets the next level start on it
     if (probed || g_thr_small != 0) {}
