@@ -181,8 +181,10 @@ int twl_comm_destroy(int device);
                              0: tile after tile on the 2048-row kernel (the path before round 4; tests hold the two to each other)
      TWL_KNOB_NO_SPEC        1: no speculative two-workgroup teams for levels of a few pairs outside the tile-parallel path (timing tools)
      TWL_KNOB_SCOUT_XDROP_PCT  X-drop of the pair scouts of wide re-runs in percent of the call's (default 100; 10..100): they only predict tile starts
-     TWL_KNOB_THR_SMALL      0 (default): levels of short pairs (R + Q <= 4096) start on the 512-row throughput geometry (five workgroups per CU) unless a recent
-                             such level outgrew it; 1: never; 2: every throughput level does (tests: pairs that outgrow it re-run on the 768-row geometry) */
+     TWL_KNOB_THR_SMALL      0 (default): a level of more pairs than CUs starts on the 512-row throughput geometry (4 waves x 2 blocks, FIVE workgroups per CU) unless
+                             an earlier level of the pass outgrew it -- large levels of short pairs ask a sample of their own pairs first; pairs that outgrow it re-run
+                             (768-row geometry, a few long pairs tile-parallel); scouts and, while the pass fits it, tile jobs of tile-parallel launches take it too.
+                             1: never; 2: every throughput level does (tests, tools).  Setting the knob also forgets what earlier levels found */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
                 TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15 };
