@@ -16,6 +16,7 @@ M = synth.nucleotide_matrix()
 
 @pytest.fixture()
 def knobs(gpu):
+    gpu.set_knob(api.KNOB_THR_SMALL, 0)          # (also forgets what the levels of earlier tests found of the 512-row window)
     yield gpu
     gpu.set_knob(api.KNOB_MT_PERTURB, 0)
     gpu.set_knob(api.KNOB_MT_MAX_PAIRS, 1024)
