@@ -267,6 +267,33 @@ int main(int argc, char **argv)
         CHECK("schedule_has_n_minus_1_pairs", pairs == 4 && !levels.empty() && !levels[0].empty());
         delete sub;
     }
+    // ---- reroot (tree.cpp:588-696), derived by hand: the longest path of ((((A,B),C),D),(E,F)) has 7 nodes whichever leaf the search starts from
+    // (the start leaf is the first leaf of an unordered_map: the quirk the level batches of real trees depend on), its middle node is X = (((A,B),C),D).
+    // Every edge of the path X -> old root turns over: the old root hangs under X with the edge's length 7 and keeps (E,F) as its only child, so it is
+    // spliced out and (E,F) carries 10 + 7; X now has three children [((A,B),C), D, (E,F)], of which the first two get a joint of length 0; the root
+    // keeps the NAME of the old root.
+    {
+        const std::string f = tmp + "/reroot.nwk";
+        { std::ofstream o(f); o << "((((A:1,B:2):3,C:4):5,D:6):7,(E:8,F:9):10);\n"; }
+        Tree T(f);
+        const std::string rootName = T.root->identifier;
+        phylogeny::assignSinglePartition(T.root);
+        Tree *sub = new Tree(T.root, true);
+        std::function<std::string(Node *)> show = [&](Node *n) -> std::string {
+            std::string s;
+            if (n->is_leaf()) s = n->identifier;
+            else { s = "("; for (size_t c = 0; c < n->children.size(); ++c) { if (c) s += ","; s += show(n->children[c]); if (n->children[c]->parent != n) s += "!"; } s += ")"; }
+            char b[32]; snprintf(b, sizeof b, ":%g", (double)n->branchLength);
+            return s + b;
+        };
+        const std::string got = show(sub->root);
+        bool ok = got == "((((A:1,B:2):3,C:4):5,D:6):0,(E:8,F:9):17):0" && sub->root->identifier == rootName && sub->root->parent == nullptr;
+        ok = ok && sub->allNodes.at(rootName) == sub->root && sub->m_numLeaves == 6 && sub->root->level == 1;
+        for (auto &kv : sub->allNodes) ok = ok && kv.second->identifier == kv.first;       // every key still names its node
+        if (!ok) printf("  reroot gave %s\n", got.c_str());
+        CHECK("reroot_turns_the_path_over_and_keeps_the_root_s_name", ok);
+        delete sub;
+    }
     // ---- subtree ownership of a sharded run (progressive::planOwnership; used by gpu/align_owned.cpp) ----
     {
         // a random binary tree of 600 leaves with uniform splits (as twilight_amd/synth.py makes them: unbalanced on purpose)

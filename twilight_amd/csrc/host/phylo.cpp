@@ -337,28 +337,28 @@ void Tree::reroot()
     Node *newRoot = path[path.size() / 2];
     if (newRoot->identifier == root->identifier) return;      // note: leaves numLeaves/weights/m_numLeaves untouched (:658)
 
-    std::vector<Node *> chain;                                  // old root ... new root
-    for (Node *cur = newRoot; cur != nullptr; cur = cur->parent) chain.push_back(cur);
-    std::reverse(chain.begin(), chain.end());
-    for (size_t i = 0; i + 1 < chain.size(); ++i) {
-        Node *n = chain[i];
-        n->parent = chain[i + 1];
-        n->children.erase(std::remove(n->children.begin(), n->children.end(), chain[i + 1]), n->children.end());
-        n->branchLength = n->parent->branchLength;
-        if (i > 0) n->children.push_back(chain[i - 1]);
+    // Turn the path new root -> old root upside down, walking it from the bottom: every edge keeps its length and its two ends trade places,
+    // so a node of the path hangs under the neighbour we came from, carries the length of the edge between them, loses that neighbour as a
+    // child and gains its former parent as its last child (tree.cpp:657-674 builds the same links from the top; child order is observable:
+    // convert2binaryTree and the level schedule walk children in order).
+    {
+        Node *came = nullptr;
+        float edge = 0.0f;                                      // length of the edge between `came` and the node in hand
+        for (Node *cur = newRoot; cur != nullptr;) {
+            Node *up = cur->parent;
+            const float upEdge = cur->branchLength;
+            if (came) cur->children.erase(std::remove(cur->children.begin(), cur->children.end(), came), cur->children.end());
+            if (up) cur->children.push_back(up);
+            cur->parent = came;
+            cur->branchLength = came ? edge : 0.0f;
+            came = cur; edge = upEdge; cur = up;
+        }
     }
-    newRoot->children.push_back(newRoot->parent);
-    newRoot->parent = nullptr;
-    newRoot->branchLength = 0.0f;
     updateLevels(newRoot, 1);
-    Node *oldRoot = root;
-    std::string rootName = oldRoot->identifier;
-    oldRoot->identifier = newRoot->identifier;
-    newRoot->identifier = rootName;
-    allNodes.erase(rootName);
-    allNodes.erase(newRoot->identifier);
-    allNodes[oldRoot->identifier] = oldRoot;
-    allNodes[newRoot->identifier] = newRoot;
+    // The root keeps its NAME (tree.cpp:679-686): the node that is the root now and the one that was trade identifiers; both keys exist, so
+    // the two map slots trade their nodes.
+    std::swap(root->identifier, newRoot->identifier);
+    std::swap(allNodes.at(root->identifier), allNodes.at(newRoot->identifier));
     root = newRoot;
     convert2binaryTree();
     calLeafNum();
