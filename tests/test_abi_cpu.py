@@ -88,3 +88,38 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "libtwl_oracle" not in text and "talco_oracle" not in text, f
+
+
+def test_forked_cli_leaves_nobody_behind_when_a_rank_fails(built, tmp_path):
+    """twilight-mi355x --gpu-index a,b,c forks one process per GPU before anything touches a device.  On a box without those devices rank 0 fails in
+    twl_init -- the children, which wait on the shared page for the communicator id, must end too (they used to spin for ever)."""
+    import gzip
+    import signal
+    import subprocess
+    import time
+
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 3:
+        pytest.skip("three devices present: the ranks would come up")
+    fa = tmp_path / "s.fa"
+    fa.write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", "sars_20.fa.gz")).read())
+    exe = os.path.join(ROOT, "twilight_amd", "twilight-mi355x")
+    p = subprocess.Popen([exe, "-t", os.path.join(ROOT, "tests", "golden", "sars_20.nwk"), "-i", str(fa), "-o", str(tmp_path / "o.aln"), "--gpu-index", "0,1,2"],
+                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=120)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        raise
+    assert p.returncode != 0, err
+    deadline = time.time() + 10
+    while time.time() < deadline:
+        try:
+            os.killpg(p.pid, 0)          # anybody left in the session's process group?
+        except ProcessLookupError:
+            break
+        time.sleep(0.05)
+    else:
+        os.killpg(p.pid, signal.SIGKILL)
+        raise AssertionError("children of a failed run are still alive")

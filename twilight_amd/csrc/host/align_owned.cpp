@@ -131,8 +131,12 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
     if (!store) { uploadSequences(database, option); store = ctx.stores[0]; }      // (a rank without a pair below the cut)
     const int P = (option->type == 'n') ? 6 : 22;
     Writer w;
+    // fixed header: magic, cut, how the rows travel, their byte count (patched in below) -- everything a receiver must believe before it sizes a buffer
     w.put<uint64_t>(kMagic);
-    w.put<int32_t>(cut); w.put<int32_t>((int32_t)touched.size());
+    w.put<int32_t>(cut); w.put<int32_t>(0 /* rows on device, patched */);
+    const size_t rowBytesAt = w.b.size();
+    w.put<uint64_t>(0);
+    w.put<int32_t>((int32_t)touched.size());
     std::vector<int32_t> mySeqs;
     for (int k : touched) {
         Node *n = nodeOf[k];
@@ -176,8 +180,7 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
         w.bytes(myLens.data(), myLens.size() * sizeof(int32_t));
         for (int32_t s : mySeqs) w.put<uint8_t>(database->sequences[s]->lowQuality ? 1 : 0);
         w.align8();
-        w.put<uint64_t>((uint64_t)myRowBytes);
-        w.put<uint64_t>(rowsOnDevice ? 1 : 0);
+        { const uint64_t rb = (uint64_t)myRowBytes; memcpy(&w.b[rowBytesAt], &rb, 8); const int32_t od = rowsOnDevice ? 1 : 0; memcpy(&w.b[rowBytesAt - 4], &od, 4); }
         if (!rowsOnDevice) {
             const size_t at = w.b.size();
             w.b.resize(at + myRowBytes);
@@ -190,12 +193,13 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
     size_t rowsBlk = 0;
     if (rowsOnDevice) {
         for (int r = 0; r < sh.world; ++r) {
+            // the header is checked BEFORE its byte count sizes anything: magic, cut, and the same idea of how the rows travel
             Reader probe{blobs[r].data(), blobs[r].size()};
-            // (the row-bytes field sits right in front of the flag at the end of the block)
-            if (blobs[r].size() < 16) { std::cerr << "ERROR: malformed subtree block from rank " << r << ".\n"; exit(1); }
-            uint64_t rb; memcpy(&rb, blobs[r].data() + blobs[r].size() - 16, 8);
+            if (probe.get<uint64_t>() != kMagic || probe.get<int32_t>() != cut) { std::cerr << "ERROR: subtree block of rank " << r << " does not belong to this run.\n"; exit(1); }
+            if (probe.get<int32_t>() != 1) { std::cerr << "ERROR: the ranks disagree on how the subtrees' rows travel.\n"; exit(1); }
+            const uint64_t rb = probe.get<uint64_t>();
+            if (rb > ((uint64_t)1 << 40)) { std::cerr << "ERROR: malformed subtree block from rank " << r << ".\n"; exit(1); }
             rowsBlk = std::max(rowsBlk, (size_t)rb);
-            (void)probe;
         }
         rowsBlk = (rowsBlk + 255) & ~(size_t)255;
         if (rowsBlk > 0) {
@@ -215,6 +219,9 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
     for (int r = 0; r < sh.world; ++r) {
         Reader rd{blobs[r].data(), blobs[r].size()};
         if (rd.get<uint64_t>() != kMagic || rd.get<int32_t>() != cut) { std::cerr << "ERROR: subtree block of rank " << r << " does not belong to this run.\n"; exit(1); }
+        const bool onDev = rd.get<int32_t>() != 0;
+        const uint64_t total = rd.get<uint64_t>();
+        if (onDev != rowsOnDevice) { std::cerr << "ERROR: the ranks disagree on how the subtrees' rows travel.\n"; exit(1); }
         const int nTouched = rd.get<int32_t>();
         for (int t = 0; t < nTouched; ++t) {
             const int k = rd.get<int32_t>();
@@ -260,10 +267,7 @@ size_t ownedPrefix(Tree *T, std::vector<NodePairVec> &levels, SequenceDB *databa
         const char *lens = rd.bytes((size_t)nSeqs * sizeof(int32_t));
         const char *lowq = rd.bytes((size_t)nSeqs);
         rd.align8();
-        const uint64_t total = rd.get<uint64_t>();
-        const bool onDev = rd.get<uint64_t>() != 0;
         const char *rows = onDev ? nullptr : rd.bytes((size_t)total);
-        if (onDev != rowsOnDevice) { std::cerr << "ERROR: the ranks disagree on how the subtrees' rows travel.\n"; exit(1); }
         if (r == sh.rank || nSeqs == 0) continue;
         std::vector<int32_t> idv((size_t)nSeqs), lenv((size_t)nSeqs);
         memcpy(idv.data(), ids, idv.size() * sizeof(int32_t));

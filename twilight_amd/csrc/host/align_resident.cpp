@@ -384,6 +384,10 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
             if (task == 1) {
                 for (int i = 0; i < n; ++i) {
                     if (!mask[i] || err[i] == 0) continue;
+                    // a retry is a call of the whole level with a one-pair mask, and a DP call zero-fills the outputs of ALL the level's pairs: with more
+                    // than one pair it would wipe what the others have just produced.  The deferred pass aligns one profile per level
+                    // (progressive.cpp:283-291); anything else is refused rather than silently wrong
+                    if (n != 1) { std::cerr << "ERROR: a deferred-pass level of " << n << " pairs cannot be retried pair by pair.\n"; return (int)TWL_ERR_UNSUPPORTED; }
                     twl_params tr = maskZero[i] ? tz : tp;
                     const int minLen = std::min(ps[i].lens.first, ps[i].lens.second);
                     std::vector<uint8_t> one(n, 0);

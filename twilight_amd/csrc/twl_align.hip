@@ -1493,13 +1493,10 @@ int twl_comm_init(int device, int rank, int world, const void *id128)
     return TWL_OK;
 }
 
-int twl_comm_all_gather(int device, const void *d_send, void *d_recv, int64_t bytes_per_rank)
+namespace {
+// (the device's lock is held by the caller)
+int comm_all_gather_locked(Device *d, const void *d_send, void *d_recv, int64_t bytes_per_rank)
 {
-    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
-    Device *d = nullptr;
-    int rc = find_dev(device, &d);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> dl(d->mu);
     if (!d->comm || !d_send || !d_recv || bytes_per_rank <= 0) { g_err = "no communicator on this device (twl_comm_init) or bad argument"; return TWL_ERR_BAD_ARGUMENT; }
     HIP_TRY(hipSetDevice(d->id));
     // on the library's stream: ordered behind the kernels that packed the block, ahead of those that unpack the others'
@@ -1508,6 +1505,17 @@ int twl_comm_all_gather(int device, const void *d_send, void *d_recv, int64_t by
     HIP_TRY(hipStreamSynchronize(d->stream));
     return TWL_OK;
 }
+}  // namespace
+
+int twl_comm_all_gather(int device, const void *d_send, void *d_recv, int64_t bytes_per_rank)
+{
+    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
+    Device *d = nullptr;
+    int rc = find_dev(device, &d);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> dl(d->mu);
+    return comm_all_gather_locked(d, d_send, d_recv, bytes_per_rank);
+}
 
 int twl_comm_all_gather_host(int device, const void *send, void *recv, int64_t bytes_per_rank)
 {
@@ -1515,18 +1523,15 @@ int twl_comm_all_gather_host(int device, const void *send, void *recv, int64_t b
     Device *d = nullptr;
     int rc = find_dev(device, &d);
     if (rc) return rc;
-    int world = 0;
-    {
-        std::lock_guard<std::mutex> dl(d->mu);
-        if (!d->comm || !send || !recv || bytes_per_rank <= 0) { g_err = "no communicator on this device (twl_comm_init) or bad argument"; return TWL_ERR_BAD_ARGUMENT; }
-        world = d->comm_world;
-        HIP_TRY(hipSetDevice(d->id));
-        if ((rc = d->comm_send.ensure((size_t)bytes_per_rank))) return rc;
-        if ((rc = d->comm_recv.ensure((size_t)bytes_per_rank * (size_t)world))) return rc;
-        HIP_TRY(hipMemcpyAsync(d->comm_send.p, send, (size_t)bytes_per_rank, hipMemcpyHostToDevice, d->stream));
-    }
-    if ((rc = twl_comm_all_gather(device, d->comm_send.p, d->comm_recv.p, bytes_per_rank))) return rc;
+    // ONE hold of the device's lock from staging to copy-back (the staging buffers are the device's, two callers would have raced on them)
     std::lock_guard<std::mutex> dl(d->mu);
+    if (!d->comm || !send || !recv || bytes_per_rank <= 0) { g_err = "no communicator on this device (twl_comm_init) or bad argument"; return TWL_ERR_BAD_ARGUMENT; }
+    const int world = d->comm_world;
+    HIP_TRY(hipSetDevice(d->id));
+    if ((rc = d->comm_send.ensure((size_t)bytes_per_rank))) return rc;
+    if ((rc = d->comm_recv.ensure((size_t)bytes_per_rank * (size_t)world))) return rc;
+    HIP_TRY(hipMemcpyAsync(d->comm_send.p, send, (size_t)bytes_per_rank, hipMemcpyHostToDevice, d->stream));
+    if ((rc = comm_all_gather_locked(d, d->comm_send.p, d->comm_recv.p, bytes_per_rank))) return rc;
     HIP_TRY(hipMemcpy(recv, d->comm_recv.p, (size_t)bytes_per_rank * (size_t)world, hipMemcpyDeviceToHost));
     return TWL_OK;
 }
