@@ -264,9 +264,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus N > 1 must be launched with one process per GPU: python -m torch.distributed.run --nnodes=1 "
-                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port <port> bench.py --gpus {args.gpus} ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # A plain `python bench.py --gpus N`: one process per GPU is started HERE, as a child, before this process has imported torch or touched a
+        # GPU (never a re-exec); rank 0's JSON line is relayed, the child's exit code is ours.
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            print(lines[-1], flush=True)
+        sys.exit(r.returncode if (r.returncode != 0 or lines) else 1)
     # the host library reports on C-level stdout as TWILIGHT does; this process's stdout carries the ONE JSON line only
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -412,6 +425,13 @@ def main():
         exch_ms = 0.0
         levels, tot, md5, open_s = [], None, None, 0.0
 
+    # ranks the collective's communicator holds: the library's own (twl_comm_*) or torch.distributed's RCCL; None when gloo carried the exchange (one-GPU development run)
+    rccl_world = 0
+    if family and sharded:
+        if native:
+            rccl_world = world
+        elif dist.is_initialized() and dist.get_backend() == "nccl":
+            rccl_world = dist.get_world_size()
     dt_max = tdist.reduce_report(0.0, dt, device=(None if one_gpu else dev))[1] if world > 1 else dt      # MAX of seconds over ranks (cells are whole-job already)
 
     if rank == 0:
@@ -423,6 +443,7 @@ def main():
             "value": cells / dt_max,
             "unit": "cells/s",
             "n_gpus": world,
+            "n_ranks_seen_by_rccl": (int(rccl_world) if rccl_world else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / steps,

@@ -14,6 +14,15 @@
  * Plain C types only.  All functions return 0 on success or a negative twl_status; algorithmic
  * failures of a pair are NOT errors: they travel in err_out[] as the reference's errorType so the
  * caller can apply the reference's retry/defer policy unchanged (alignment-cpu.cpp:108-129).
+ *
+ * Threads.  The reference calls its per-pair kernel from TBB workers (alignment-cpu.cpp:46) and its level kernel with one pair
+ * per level from the deferred / merge paths (progressive.cpp:286-291), so every entry point of this header and of twl_level.h
+ * may be called from any host thread, concurrently.  What is serialised: calls that touch the same device take that device's
+ * lock for their whole duration (a call is a whole level batch and fills the device by itself; twl_level_* calls of different
+ * stores on one device interleave call by call, in the order the lock grants); calls on different devices run side by side.
+ * What is per thread: twl_last_error().  What is per device and therefore belongs to the LAST call of any thread:
+ * twl_get_stats / twl_get_pair_cells -- concurrent callers read their results from their own output arrays.  twl_init /
+ * twl_shutdown / twl_set_knob are not meant to race with running calls.  tests/test_gpu_threads.py.
  */
 #ifndef TWL_ALIGN_H
 #define TWL_ALIGN_H

@@ -126,3 +126,25 @@ def test_no_communicator_is_an_error_code_and_the_handle_stays_usable(built, tmp
     mp.start_processes(_worker, args=(2, _free_port(), t, f, d, typ, flags, env, True, True), nprocs=2, join=True, start_method="spawn")
     for rank in range(2):
         assert hashlib.md5(open(os.path.join(d, f"rank{rank}.aln"), "rb").read()).hexdigest() == FIX[name]["md5"], f"rank {rank}"
+
+
+@pytest.mark.timeout(900)
+def test_bench_with_gpus_2_as_a_plain_command(built, tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the script starts torch.distributed.run itself as a child (before it touches a GPU) and relays rank 0's
+    ONE JSON line.  TWL_BENCH_ONE_GPU puts both ranks on this box's one device (gloo between them: a code-path run, never a measurement)."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, TWL_BENCH_ONE_GPU="1", TWL_BENCH_DIR=str(tmp_path / "fam"))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--leaves", "400", "--length", "1200",
+                        "--no-cpu", "--no-peak", "--no-e2e", "--no-survey8d"], capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert "n_ranks_seen_by_rccl" in line and line["n_ranks_seen_by_rccl"] is None      # (gloo carried this run's exchange)
+    assert line["config"]["msa_md5"]
