@@ -193,10 +193,12 @@ int twl_comm_destroy(int device);
      TWL_KNOB_THR_SMALL      0 (default): a level of more pairs than CUs starts on the 512-row throughput geometry (4 waves x 2 blocks, FIVE workgroups per CU) unless
                              an earlier level of the pass outgrew it -- large levels of short pairs ask a sample of their own pairs first; pairs that outgrow it re-run
                              (768-row geometry, a few long pairs tile-parallel); scouts and, while the pass fits it, tile jobs of tile-parallel launches take it too.
-                             1: never; 2: every throughput level does (tests, tools).  Setting the knob also forgets what earlier levels found */
+                             1: never; 2: every throughput level does (tests, tools).  Setting the knob also forgets what earlier levels found
+     TWL_KNOB_FORCE_GLOBAL   1: every pair of every call runs on the global-memory kernel, the last stage of the re-run chain (bands of any width; normally only
+                             reached by bands beyond 4480 rows, i.e. fLen > 4608 in a retry of the deferred pass): tests of that kernel on small cases */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16 };
 int twl_set_knob(int key, int value);
 /* The launch plan of a nucleotide call in words ("throughput; mode 2; window 768; bulk 1024 tail 277"), made by the very function the launch path
    uses, without touching a device: len[n_pairs][2] as twl_align_batch, num_cu / qry_onehot / wide_streak the facts the device would supply. */

@@ -143,6 +143,7 @@ def align_batch_device(params: TwlParams, n_pairs, seq_len, d_freq, d_gop, d_gex
 KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MARGIN, KNOB_MT_ROUNDS, KNOB_MT_THR_JOBS, KNOB_FAIL_ROW_ALLOCS = 1, 2, 3, 4, 5, 6, 7, 8
 KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY, KNOB_MT_TAIL_PCT, KNOB_MT_WIDE, KNOB_NO_SPEC, KNOB_SCOUT_XDROP_PCT = 9, 10, 11, 12, 13, 14
 KNOB_THR_SMALL = 15
+KNOB_FORCE_GLOBAL = 16
 PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 
 

@@ -8,6 +8,7 @@
 #include "restore_kernels.hip.h"
 #include "talco_kernel.hip.h"
 #include "talco_nuc.hip.h"
+#include "talco_global.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -232,6 +233,36 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     return TWL_OK;
 }
 
+// The last stage of the re-run chain (talco_global.hip.h): DP rows in global scratch, any band width.  One workgroup of 1024 threads per pair; as many
+// workgroups as the pairs need, within a scratch budget (a 30 kbp pair at marker 1024 takes ~33 MB: 14 rows of fLen + 2 words and (marker + 2) rows of pointer bytes).
+template <int P>
+int launch_global(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int32_t seq_len, int *grid_out, int *window_out)
+{
+    const size_t rowcap = (size_t)std::min(std::max(base.flen, 1), std::max(seq_len, 1)) + 2;
+    const size_t words = 14 * rowcap + (((size_t)base.marker + 2) * rowcap + 3) / 4;
+    const size_t budget = (size_t)4 << 30;
+    int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_items, budget / (words * sizeof(uint32_t))));
+    grid = std::min(grid, d->num_cu);
+    int rc = d->tb.ensure(words * sizeof(uint32_t) * (size_t)grid);
+    if (rc) return rc;
+    twl::GArgs g;
+    g.k = base;
+    g.k.tb = (uint32_t *)d->tb.p;
+    g.k.tb_words = (int32_t)words;
+    if ((size_t)g.k.tb_words != words) { g_err = "a pair too long for the global-memory kernel's scratch index"; return TWL_ERR_UNSUPPORTED; }
+    g.k.items = d_items;
+    g.k.n_items = n_items;
+    g.rowcap = (int32_t)rowcap;
+    FILL_TRY(queue_fill(d, st, d->queue.p, sizeof(int32_t), 0));
+    FILL_TRY(flush_fills(d, st));
+    TRACE("launch global P=%d grid=%d n_items=%d rowcap=%zu words=%zu", P, grid, n_items, rowcap, words);
+    hipLaunchKernelGGL((twl::talco_global_kernel<P>), dim3(grid), dim3(1024), 0, st, g);
+    HIP_TRY(hipGetLastError());
+    *grid_out = grid;
+    if (window_out) *window_out = (int)rowcap - 2;
+    return TWL_OK;
+}
+
 // The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
 template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
 int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
@@ -327,6 +358,7 @@ int g_thr_small = 0;                 // twl_set_knob(TWL_KNOB_THR_SMALL): 0 = th
 int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
 int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
 int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
+int g_force_global = 0;             // twl_set_knob(TWL_KNOB_FORCE_GLOBAL): every pair of every call runs on the global-memory kernel (tests of that kernel on small cases)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 struct Knobs;
 
@@ -674,6 +706,10 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                     : launch_dp<6, 8, 9, false, false, true>(d, st, a, it, n_it, 1, g, w);
     };
     if (n_run == 0) rc = TWL_OK;      // nothing to align in this call
+    else if (g_force_global) {
+        rc = prot ? launch_global<22>(d, st, a, items, n_run, seq_len, &grid, &window) : launch_global<6>(d, st, a, items, n_run, seq_len, &grid, &window);
+        snprintf(d->kname, sizeof d->kname, "talco_global_kernel<%d>", prot ? 22 : 6);
+    }
     else if (prot) {
         // default: sparse score loop over the non-zero letters of the reference column (matrix mode 3, bit-identical to the dense loop)
         // TWL_KNOB_PROT_MODE: auto | dense | sparse | presim | r1 (round-1 kernels) | lean_sparse | lean_presim
@@ -1000,8 +1036,34 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         if ((rc = collect(true))) return rc;
         for (int t = 0; t < 4; ++t) mtStat[t] = keep[t] + (redoMt ? mtStat[t] : 0ull);      // (the counters of the first launch, plus those of a tile-parallel re-run)
     }
+    // A band that outgrew even the 4608-row window (only possible with flen > 4608, i.e. in a retry of the deferred pass, alignment-cpu.cpp:116-129), or an
+    // operand outside the fast division's range that met such a band: the global-memory kernel, which has no window and divides the IEEE way (round 5;
+    // TWL_ERR_UNSUPPORTED ended the run here before)
+    {
+        std::vector<int32_t> redo;
+        for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) redo.push_back(n);
+        if (!redo.empty()) {
+            HIP_TRY(hipMemcpyAsync(d->items.p, redo.data(), redo.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipEventRecord(d->ev[3], st));
+            int grid2 = 0, w2 = 0;
+            rc = prot ? launch_global<22>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), seq_len, &grid2, &w2)
+                      : launch_global<6>(d, st, a, (const int32_t *)d->items.p, (int)redo.size(), seq_len, &grid2, &w2);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(d->ev[4], st));
+            HIP_TRY(hipStreamSynchronize(st));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4]));
+            ms_redo += ms;
+            d->stats.n_launches += 1;
+            d->stats.n_relaunched += (int32_t)redo.size();
+            d->stats.window = std::max(d->stats.window, w2);
+            const unsigned long long keep[4] = {mtStat[0], mtStat[1], mtStat[2], mtStat[3]};
+            if ((rc = collect(true))) return rc;
+            for (int t = 0; t < 4; ++t) mtStat[t] = keep[t];
+        }
+    }
     for (int32_t n = 0; n < n_pairs; ++n)
-        if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) { g_err = "an anti-diagonal band outgrew the 4608-row window of the widest kernel"; return TWL_ERR_UNSUPPORTED; }
+        if (h_err[n] == twl::kErrOverflow || h_err[n] == twl::kErrGuard) { g_err = "internal: a re-run code survived the global-memory kernel"; return TWL_ERR_HIP; }
     uint64_t total = 0;
     for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
     if (ranMt || redoMt) { d->stats.mt_tiles_predicted = (int32_t)mtStat[0]; d->stats.mt_tiles_inline = (int32_t)mtStat[1]; d->stats.mt_scouts_failed = (int32_t)mtStat[2]; }
@@ -1417,6 +1479,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_TAIL_PCT: g_mt_tail_pct = std::max(0, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_FORCE_GLOBAL: g_force_global = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
