@@ -26,6 +26,12 @@
 
 namespace twl {
 
+__device__ __forceinline__ unsigned long long lane_mask(int lo, int hi)
+{
+    const int a = max(lo, 0), b = min(hi, 63);
+    const unsigned long long m = (~0ull << a) & (~0ull >> (63 - b));
+    return (a <= b) ? m : 0ull;
+}
 template <int W>
 struct PkCfg {
     static constexpr int NV = 2 * W;             // 64-row half blocks resident at once

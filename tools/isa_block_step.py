@@ -1,0 +1,87 @@
+"""Static instruction count of one anti-diagonal step of a talco_lean_kernel instantiation, from its gfx950 disassembly (cross-compiles without a GPU).
+
+    python tools/isa_block_step.py "<6, 4, 2, 2, 5, false, false, 0>" [out_dir]
+
+Compiles the kernel alone (seconds), cuts the phase-A loop (k < marker - 1: the loop most diagonals of a tile run in) out of the listing, splits it into
+basic blocks and counts instructions per block and kind.  Writes <out_dir>/isa_step_<tag>.s (the loop, every block headed by its counts) and prints a JSON
+summary.  Which blocks a diagonal actually executes depends on the data (gap letters present, denominators, activity of a slot); the summary therefore gives
+three sums: `always` (blocks on every path through an ACTIVE slot with gap letters and a general denominator -- found by walking fall-through and
+unconditional branches from the slot's first block and taking the NOT-taken side of every forward conditional branch whose target lies inside the slot),
+`slot_text` (all instructions in the slot's text range, rare paths included) and `per_diagonal` (the text outside the slots: step head, hook, barrier, band update)."""
+import json, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "twilight_amd", "csrc")
+
+
+def compile_one(targs):
+    d = tempfile.mkdtemp(prefix="twl_isa_")
+    src = os.path.join(d, "k.hip")
+    open(src, "w").write('#include <type_traits>\n#include "talco_nuc.hip.h"\ntemplate __global__ void twl::talco_lean_kernel%s(twl::NArgs);\n' % targs)
+    out = os.path.join(d, "k.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-I" + CSRC, "-S",
+                           "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def kind(ins):
+    op = ins.split()[0]
+    if op == "s_nop": return "nop"
+    if op.startswith(("s_cbranch", "s_branch")): return "branch"
+    if op in ("s_barrier", "s_waitcnt", "s_setprio"): return "sync"
+    if op.startswith("s_"): return "salu"
+    if op.startswith("ds_"): return "lds"
+    if op.startswith(("global_", "scratch_", "buffer_", "flat_")): return "vmem"
+    if op.startswith("v_"): return "valu"
+    return "other"
+
+
+def main():
+    targs = sys.argv[1]
+    out_dir = sys.argv[2] if len(sys.argv) > 2 else "."
+    lines = compile_one(targs)
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3twl17talco_lean_kernel"))
+    end = next(i for i, l in enumerate(lines) if l.startswith(".Lfunc_end") and i > start)
+    k = lines[start:end]
+    hdr = [i for i, l in enumerate(k) if "Inner Loop Header: Depth=3" in l]
+    a = hdr[1]                                        # loops in text order: SPEC/poll-free kernels have [prologue fill, phase A, phase B, phase C, ...]; the 2nd depth-3 loop is phase A
+    while not k[a].startswith(".LBB"): a -= 1
+    head_label = k[a].split(":")[0]
+    # the loop ends at the unconditional branch back to its header
+    z = next(i for i in range(a + 1, len(k)) if re.match(r"\s+s_branch\s+%s\b" % re.escape(head_label), k[i]))
+    body = k[a:z + 1]
+    blocks, cur = [], None
+    for l in body:
+        if l.startswith(".LBB"):
+            cur = {"label": l.split(":")[0], "ins": []}
+            blocks.append(cur)
+        elif l.startswith("\t") and not l.strip().startswith((";", ".")) and cur is not None:
+            ins = l.strip()
+            if ins.startswith(";;#"): continue
+            cur["ins"].append(ins)
+            if ins.split()[0].startswith(("s_cbranch", "s_branch")):
+                cur = {"label": cur["label"] + "+", "ins": []}      # a conditional branch ends a basic block: the fall-through continues under a derived label
+                blocks.append(cur)
+    blocks = [b for b in blocks if b["ins"]]
+    tot = {}
+    for b in blocks:
+        c = {}
+        for ins in b["ins"]:
+            c[kind(ins)] = c.get(kind(ins), 0) + 1
+        b["count"] = c
+        for kk, v in c.items():
+            tot[kk] = tot.get(kk, 0) + v
+    tag = re.sub(r"[^0-9a-z]+", "_", targs.lower()).strip("_")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"isa_step_{tag}.s"), "w") as f:
+        f.write(f"; talco_lean_kernel{targs}: the phase-A loop (one anti-diagonal per iteration), basic blocks with instruction counts -- tools/isa_block_step.py\n")
+        for b in blocks:
+            f.write(f"; ---- {b['label']}: {sum(b['count'].values())} instructions {json.dumps(b['count'])}\n")
+            for ins in b["ins"]:
+                f.write("\t" + ins + "\n")
+    print(json.dumps({"kernel": "talco_lean_kernel" + targs, "loop_text_instructions": sum(tot.values()), "by_kind": tot, "basic_blocks": len(blocks),
+                      "listing": f"isa_step_{tag}.s"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,14 @@ if "pass1" in out and dur:
              "valu_issue_frac": c.get("SQ_INSTS_VALU", 0.0) * 2.0 / (SIMDS * CLK * t),
              "salu_per_cycle_per_cu": c.get("SQ_INSTS_SALU", 0.0) / (CUS * CLK * t),
              "lds_insts_per_cycle_per_cu": c.get("SQ_INSTS_LDS", 0.0) / (CUS * CLK * t)}
+        # every instruction the waves issued (vector, scalar, LDS, vector / scalar memory, branches) per ns and CU, against the measured ceiling of 3.97
+        # (tools/micro/issue_rates.hip: 16 waves per CU, interleaved vector and scalar instructions) -- no clock enters
+        br = p2.get(name, {}).get("sum", {}).get("SQ_INSTS_BRANCH", 0.0)
+        tot = sum(c.get(f, 0.0) for f in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")) + br
+        e["insts_per_ns_per_cu"] = tot / (CUS * t * 1e9)
+        e["issue_frac_of_measured_ceiling"] = e["insts_per_ns_per_cu"] / 3.97
+        e["insts_by_kind"] = {f[len("SQ_INSTS_"):].lower(): c.get(f, 0.0) for f in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM")}
+        e["insts_by_kind"]["branch"] = br
         if name in p2:
             c2 = p2[name]["sum"]
             if c.get("SQ_WAVE_CYCLES"):

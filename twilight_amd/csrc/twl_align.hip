@@ -176,427 +176,11 @@ int check_params(const twl_params *p)
     return TWL_OK;
 }
 
-template <class CfgT>
-size_t tb_words_for(int marker) { return ((size_t)(marker >> 3) + 1) * (size_t)CfgT::WINDOW; }
+#include "twl_knobs.inc.hip"
+#include "twl_launch.inc.hip"
 
-template <int P, int W, int RPL, bool PRE, bool REFLDS, bool QREG = true, int MINW = 1, int MM = 0>
-int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int blocks_per_cu, int *grid_out,
-              int *window_out = nullptr)
-{
-    using CfgT = twl::Cfg<P, W, RPL, PRE, REFLDS, QREG>;
-    if (blocks_per_cu <= 0) {
-        static std::atomic<int> cached{0};      // one value per template instantiation (device threads may race to fill it: same value)
-        if (cached.load() == 0) {
-            int nb = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), CfgT::THREADS, 0));
-            cached.store(std::max(1, nb));
-        }
-        blocks_per_cu = cached.load();
-    }
-    if (window_out) *window_out = CfgT::WINDOW;
-    int grid = std::min(n_items, d->num_cu * std::max(1, blocks_per_cu));
-    if (grid < 1) grid = 1;
-    const size_t tbw = tb_words_for<CfgT>(base.marker);
-    int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
-    if (rc) return rc;
-    twl::KArgs a = base;
-    a.tb = (uint32_t *)d->tb.p;
-    a.tb_words = (int32_t)tbw;
-    a.items = d_items;
-    a.n_items = n_items;
-    FILL_TRY(queue_fill(d, st, d->queue.p, sizeof(int32_t), 0));
-    int32_t *hb = nullptr;
-#ifdef TWL_KERNEL_DEBUG
-    if (dbg_on()) {
-        HIP_TRY(hipHostMalloc((void **)&hb, 16 * sizeof(int32_t), hipHostMallocMapped));
-        for (int i = 0; i < 16; ++i) hb[i] = -777;
-        a.hb = hb;
-    }
-#endif
-    TRACE("launch dp W=%d RPL=%d grid=%d threads=%d n_items=%d tb_words=%zu", W, RPL, grid, CfgT::THREADS, n_items, tbw);
-    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_kernel<%d, %d, %d, %s, %s, %s, %d, %d>", P, W, RPL, PRE ? "true" : "false", REFLDS ? "true" : "false", QREG ? "true" : "false", MINW, MM);
-    FILL_TRY(flush_fills(d, st));
-    hipLaunchKernelGGL((twl::talco_kernel<P, W, RPL, PRE, REFLDS, QREG, MINW, MM>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    if (hb) {   // debug only: poll the heartbeat until the kernel is done (or 20 s)
-        for (int t = 0; t < 200; ++t) {
-            if (hipStreamQuery(st) == hipSuccess) break;
-            std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            if (t % 10 == 9)
-                TRACE("hb: start %d item %d tile %d k %d preB %d postB %d preTB %d postTB %d n %d err %d done %d", hb[0], hb[1], hb[2], hb[3],
-                      hb[4], hb[5], hb[6], hb[7], hb[8], hb[9], hb[10]);
-        }
-        TRACE("hb final: start %d item %d tile %d k %d preB %d postB %d preTB %d postTB %d n %d err %d done %d", hb[0], hb[1], hb[2], hb[3],
-              hb[4], hb[5], hb[6], hb[7], hb[8], hb[9], hb[10]);
-    }
-    *grid_out = grid;
-    return TWL_OK;
-}
+#include "twl_policy.inc.hip"
 
-// The last stage of the re-run chain (talco_global.hip.h): DP rows in global scratch, any band width.  One workgroup of 1024 threads per pair; as many
-// workgroups as the pairs need, within a scratch budget (a 30 kbp pair at marker 1024 takes ~33 MB: 14 rows of fLen + 2 words and (marker + 2) rows of pointer bytes).
-template <int P>
-int launch_global(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int32_t seq_len, int *grid_out, int *window_out)
-{
-    const size_t rowcap = (size_t)std::min(std::max(base.flen, 1), std::max(seq_len, 1)) + 2;
-    const size_t words = 14 * rowcap + (((size_t)base.marker + 2) * rowcap + 3) / 4;
-    const size_t budget = (size_t)4 << 30;
-    int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_items, budget / (words * sizeof(uint32_t))));
-    grid = std::min(grid, d->num_cu);
-    int rc = d->tb.ensure(words * sizeof(uint32_t) * (size_t)grid);
-    if (rc) return rc;
-    twl::GArgs g;
-    g.k = base;
-    g.k.tb = (uint32_t *)d->tb.p;
-    g.k.tb_words = (int32_t)words;
-    if ((size_t)g.k.tb_words != words) { g_err = "a pair too long for the global-memory kernel's scratch index"; return TWL_ERR_UNSUPPORTED; }
-    g.k.items = d_items;
-    g.k.n_items = n_items;
-    g.rowcap = (int32_t)rowcap;
-    FILL_TRY(queue_fill(d, st, d->queue.p, sizeof(int32_t), 0));
-    FILL_TRY(flush_fills(d, st));
-    TRACE("launch global P=%d grid=%d n_items=%d rowcap=%zu words=%zu", P, grid, n_items, rowcap, words);
-    hipLaunchKernelGGL((twl::talco_global_kernel<P>), dim3(grid), dim3(1024), 0, st, g);
-    HIP_TRY(hipGetLastError());
-    *grid_out = grid;
-    if (window_out) *window_out = (int)rowcap - 2;
-    return TWL_OK;
-}
-
-// The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
-template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
-int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
-{
-    using CfgT = twl::NCfg<W, RPL>;
-    static std::atomic<int> cached{0};      // one value per template instantiation
-    if (cached.load() == 0) {
-        int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), CfgT::THREADS, 0));
-        cached.store(std::max(1, nb));
-    }
-    int blocks_per_cu = cached.load();
-    if (window_out) *window_out = CfgT::WINDOW;
-    int grid = std::min(n_items, d->num_cu * blocks_per_cu);
-    if (grid < 1) grid = 1;
-    if (SPEC) {      // two workgroups per pair that wait for each other: all of them must be resident at once
-        grid = 2 * n_items;
-        if (grid > d->num_cu * blocks_per_cu) { g_err = "speculative launch larger than the device"; return TWL_ERR_BAD_ARGUMENT; }
-    }
-    const size_t tbw = ((size_t)(base.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
-    int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
-    if (rc) return rc;
-    twl::NArgs a{};
-    a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
-    a.cells = base.cells; a.tb = (uint32_t *)d->tb.p; a.queue = base.queue; a.items = d_items; a.n_items = n_items;
-    a.seq_len = base.seq_len; a.tb_words = (int32_t)tbw; a.dbg = base.dbg; a.n_pairs_total = base.n_pairs_total;
-    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char; a.gc_zero = base.gc_zero;
-    a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
-    for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
-    a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
-    FILL_TRY(queue_fill(d, st, d->queue.p, sizeof(int32_t), 0));
-    if (SPEC) {
-        if ((rc = d->team.ensure((size_t)n_items * twl::kTeamWords * sizeof(unsigned long long)))) return rc;
-        FILL_TRY(queue_fill(d, st, d->team.p, (size_t)n_items * twl::kTeamWords * sizeof(unsigned long long), 0));
-        FILL_TRY(queue_fill(d, st, a.cells, (size_t)base.n_pairs_total * sizeof(unsigned long long), 0));
-        a.team = (unsigned long long *)d->team.p;
-    }
-    TRACE("launch lean P=%d W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", P, W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
-    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, %d, %s, %s, 0>", P, W, RPL, MM, MINW, SPEC ? "true" : "false", DUMP ? "true" : "false");
-    a.simdump = DUMP ? (float *)d->simdump.p : nullptr;
-    FILL_TRY(flush_fills(d, st));
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    if (SPEC && dbg_on()) {      // development: how often the guessed tile start was the true one
-        std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
-        HIP_TRY(hipMemcpyAsync(tw.data(), d->team.p, tw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long g = 0, h = 0;
-        for (int t = 0; t < n_items; ++t) { g += tw[(size_t)t * twl::kTeamWords + twl::kTeamStat]; h += tw[(size_t)t * twl::kTeamWords + twl::kTeamStat + 1]; }
-        fprintf(stderr, "[twl spec] %d pairs: %llu tile starts guessed, %llu confirmed\n", n_items, g, h);
-    }
-    *grid_out = grid;
-    return TWL_OK;
-}
-
-constexpr int kMtMaxRounds = 7, kMtCounters = 16;      // 1 + 2 * rounds launches, each with its own work counter (the count is clamped wherever it is set)
-// One launch of a tile-parallel kernel (MT 1 tiles / 2 scouts / 3 stitch) of geometry <W, RPL>; the caller has filled the NArgs.
-template <int P, int W, int RPL, int MM, int MINW, int MT>
-int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *grid_out = nullptr, size_t tb_groups = 0)
-{
-    using CfgT = twl::NCfg<W, RPL>;
-    static std::atomic<int> cached{0};
-    if (cached.load() == 0) {
-        int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), CfgT::THREADS, 0));
-        cached.store(std::max(1, nb));
-    }
-    int grid = std::max(1, std::min(n_items, d->num_cu * cached.load()));
-    // traceback words of a workgroup: the groups of 8 anti-diagonals up to the marker, or (pair scouts, MT 4) of a whole pair
-    const size_t tbw = (tb_groups ? tb_groups : (size_t)(a.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
-    if (tb_groups) grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)8 << 30) / (tbw * sizeof(uint32_t))));      // (at most 8 GB of them: fewer workgroups take the pairs in turn)
-    int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
-    if (rc) return rc;
-    a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
-    // (every launch of a tile-parallel level has its own work counter: launch_mt zeroed the 16 of them in one go)
-    a.queue = (int32_t *)d->queue.p + (d->mt_launch++ % kMtCounters);
-    FILL_TRY(flush_fills(d, st));
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    if (grid_out) *grid_out = grid;
-    return TWL_OK;
-}
-
-// Tile-parallel alignment of a level with few pairs (talco_nuc.hip.h, MT kernels): scouts, then rounds of chain -> tiles -> stitch, on `st`.
-// `order` = the pairs that run, h_len their lengths on the host.  Scouts and tiles run on the 16-wave geometry (one workgroup per CU, the
-// shortest diagonal step) while they fit the device at once (one workgroup per CU), on the throughput geometry (8 waves x 2 blocks, two per CU) beyond.
-int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
-int g_mt_lead = 320, g_mt_marg = 40;
-int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
-int g_scout_xdrop_pct = 100;         // twl_set_knob(TWL_KNOB_SCOUT_XDROP_PCT): X-drop of the pair scouts in percent of the call's (they only predict: a narrower band is a cheaper scout)
-int g_no_spec = 0;                   // twl_set_knob(TWL_KNOB_NO_SPEC): no speculative two-workgroup teams (tools that time the plain tile loop)
-int g_thr_small = 0;                 // twl_set_knob(TWL_KNOB_THR_SMALL): 0 = the 512-row throughput geometry for levels of short pairs (plan_nucleotide), 1 never, 2 whenever the throughput kernel runs (tests)
-int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
-int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
-int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
-int g_force_global = 0;             // twl_set_knob(TWL_KNOB_FORCE_GLOBAL): every pair of every call runs on the global-memory kernel (tests of that kernel on small cases)
-int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
-struct Knobs;
-
-template <int P, int MM, int TRPL, bool WIDE = false, int TW = 8>      // TW x TRPL: waves and 64-row blocks per wave of the throughput geometry (nucleotide 4 x 3: 768 rows, four workgroups per CU; protein 8 x 1: 512 rows, two)
-int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
-              const int32_t *h_len, int *grid_out, int *window_out, bool small_tiles = false)
-{
-    // small_tiles (nucleotide, throughput geometry): the tile jobs too run on 4 waves x 2 blocks, five workgroups per CU -- the earlier levels of this pass
-    // fitted the 512-row window (plan_nucleotide, small).  A tile that outgrows it leaves a failed record of a window narrower than the stitch launch's, which
-    // the stitch launch does not adopt: it computes that tile in line (run_device counts them and takes the pass off the small window when they are many).
-    constexpr bool kCanSmall = (P == 6 && TW == 4 && !WIDE);
-    const bool smallT = kCanSmall && small_tiles;
-    // WIDE (nucleotide): the tiles and the stitch launch on 16 waves x 3 blocks, a 3072-row window -- for the pairs whose band outgrew the
-    // 1024-row window of the fast geometries.  Until round 4 those ran their ~20 tiles one after the other on the 2048- and 4608-row kernels
-    // (0.2-0.6 s per 10 kbp pair); their tiles are as independent as anybody's.  The scouts keep the narrow geometry: a scout's band opens
-    // from one cell by a row per diagonal over the ~400 diagonals it runs.
-#if defined(TWL_EXP_LAT_W)      // geometry experiments of the latency launches (tools/lone_pair_probe.py on cross-compiled variants)
-    constexpr int SW = WIDE ? 16 : TWL_EXP_LAT_W, SR = WIDE ? 3 : TWL_EXP_LAT_RPL;
-#else
-    constexpr int SW = 16, SR = WIDE ? 3 : 1;       // geometry of the stitch launch and of tiles while they fit the device at once
-#endif
-    if (window_out) *window_out = twl::NCfg<SW, SR>::WINDOW;
-    const int marker = base.marker;
-    const int slots = (2 * base.seq_len) / (marker - 1) + 2;
-    const int segcap = 2 * marker + 16;
-    const int sp_pitch = 2 * base.seq_len + 8;
-    const size_t np = (size_t)n_run;               // the tables are indexed by the position of a pair in `order` (not by pair id)
-    // jobs {pair, slot, row}: scouts for every tile boundary t >= 1 that exists, tiles for t >= 0 (tile-major, so that the tiles of a pair spread over the launch)
-    std::vector<int32_t> &jobs = d->mt_jobs_host;       // scouts first, then tiles (kept with the device: the upload below is asynchronous)
-    jobs.clear();
-    int maxT = 0;
-    std::vector<int> T((size_t)n_run);
-    for (int t = 0; t < n_run; ++t) {
-        const int pr = order[t];
-        const long long RQ = (long long)h_len[2 * pr] + h_len[2 * pr + 1];
-        int n = 1;
-        while (n < slots && (long long)(marker - 1) * n - 1 <= RQ - 2) ++n;
-        T[t] = n; maxT = std::max(maxT, n);
-    }
-    for (int s = 1; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); jobs.push_back(t); }
-    const int nScout = (int)(jobs.size() / 3);
-    for (int s = 0; s < maxT; ++s) for (int t = 0; t < n_run; ++t) if (s < T[t]) { jobs.push_back(order[t]); jobs.push_back(s); jobs.push_back(t); }
-    const int nTile = (int)(jobs.size() / 3) - nScout;
-    int rc;
-    if ((rc = d->mt_chain.ensure(np * slots * 2 * sizeof(int32_t)))) return rc;
-    if ((rc = d->mt_rec.ensure(np * slots * twl::kMtRec * sizeof(int32_t)))) return rc;
-    if ((rc = d->mt_seg.ensure(np * slots * (size_t)segcap))) return rc;
-    if ((rc = d->mt_spath.ensure(np * (size_t)sp_pitch * sizeof(int32_t)))) return rc;
-    if ((rc = d->mt_stat.ensure(4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t)))) return rc;      // counters, then the per-pair frontier
-    if ((rc = d->mt_jobs.ensure(jobs.size() * sizeof(int32_t)))) return rc;
-    HIP_TRY(hipMemcpyAsync(d->mt_jobs.p, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    FILL_TRY(queue_fill(d, st, d->mt_rec.p, np * slots * twl::kMtRec * sizeof(int32_t), 0));
-    FILL_TRY(queue_fill(d, st, d->mt_spath.p, np * (size_t)sp_pitch * sizeof(int32_t), 0xFE));
-    FILL_TRY(queue_fill(d, st, d->mt_stat.p, 4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t), 0));
-    const int rounds = std::max(1, std::min(g_mt_rounds, kMtMaxRounds));
-    FILL_TRY(queue_fill(d, st, d->queue.p, kMtCounters * sizeof(int32_t), 0));      // one work counter per launch: scouts + rounds x (tiles, stitch)
-    d->mt_launch = 0;
-    twl::NArgs a{};
-    a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
-    a.cells = base.cells; a.queue = base.queue; a.items = d_items;
-    a.seq_len = base.seq_len; a.dbg = nullptr; a.n_pairs_total = base.n_pairs_total;
-    a.step_slack = base.step_slack; a.gap_open = base.gap_open; a.gap_extend = base.gap_extend; a.gap_char = base.gap_char; a.gc_zero = base.gc_zero;
-    a.xdrop = base.xdrop; a.flen = base.flen; a.marker = base.marker;
-    for (int t = 0; t < 25; ++t) a.M[t] = base.M[t];
-    a.M24 = (const float *)d->m24.p; a.sim = base.sim; a.sim_off = base.sim_off;
-    a.mt_chain = (int32_t *)d->mt_chain.p; a.mt_rec = (int32_t *)d->mt_rec.p; a.mt_seg = (int8_t *)d->mt_seg.p; a.mt_spath = (int32_t *)d->mt_spath.p;
-    a.mt_stat = (unsigned long long *)d->mt_stat.p;
-    a.mt_front = (int32_t *)((unsigned long long *)d->mt_stat.p + 4);
-    a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
-    const bool thr = !WIDE && nTile > g_mt_thr_jobs;
-    TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, WIDE ? "16x3 (wide)" : (thr ? "throughput geometry" : "16x1"));
-    if (!d->kname[0]) {
-        if (thr && smallT) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 4, 2, %d, 5, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, MM, P, MM);
-        else if (thr) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, 4, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, TW, TRPL, MM, P, MM);
-        else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 16, %d, %d, 1, false, false, 2 / 1 / 3> (tile-parallel: scouts, tiles, stitch)", P, SR, MM);
-    }
-    if (WIDE) {
-        // pairs that outgrew the fast window are, more often than not, pairs whose tiles converge late or never (diffuse profiles): a tile then runs
-        // to the end of the pair and the next one starts where the path from the END cell crosses the marker diagonal -- nothing a scout that
-        // starts 320 diagonals ahead can know.  One workgroup per pair runs the whole DP once with every traceback word kept (MT 4) and leaves the
-        // global path's crossing of every anti-diagonal; its suffixes are what the tiles' own paths follow.
-        int maxRQ = 0;
-        for (int t = 0; t < n_run; ++t) maxRQ = std::max(maxRQ, h_len[2 * order[t]] + h_len[2 * order[t] + 1]);
-        if constexpr (P == 6) {
-            twl::NArgs as = a;
-            as.xdrop = (int32_t)((long long)a.xdrop * g_scout_xdrop_pct / 100);
-            if ((rc = launch_mt_kernel<P, SW, SR, MM, 1, 4>(d, st, as, n_run, nullptr, (size_t)(maxRQ >> 3) + 2))) return rc;
-        }
-    } else if (nScout > 0) {
-        a.mt_jobs = (const int32_t *)d->mt_jobs.p;
-        const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
-        // (nucleotide scouts of the throughput geometry run ~330 diagonals from one cell: their band opens by a row per diagonal and cannot outgrow 449 rows, so
-        //  they take the 512-row window -- 4 waves x 2 blocks, FIVE workgroups per CU, see plan_nucleotide -- whatever the tiles need)
-        if constexpr (P == 6 && TW == 4 && !WIDE) rc = thrS ? launch_mt_kernel<6, 4, 2, MM, 5, 2>(d, st, a, nScout) : launch_mt_kernel<P, SW, SR, MM, 1, 2>(d, st, a, nScout);
-        else rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, WIDE ? 16 : SW, WIDE ? 1 : SR, MM, 1, 2>(d, st, a, nScout);
-        if (rc) return rc;
-    }
-    for (int r = 0; r < rounds; ++r) {
-        FILL_TRY(flush_fills(d, st));
-        hipLaunchKernelGGL(twl::mt_chain_kernel, dim3((n_run + 63) / 64), dim3(64), 0, st, (const int32_t *)d->mt_spath.p, sp_pitch, base.len, d_items, n_run,
-                           (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
-        HIP_TRY(hipGetLastError());
-        a.mt_jobs = (const int32_t *)d->mt_jobs.p + 3 * (size_t)nScout;
-        if constexpr (kCanSmall) rc = thr ? (smallT ? launch_mt_kernel<6, 4, 2, MM, 5, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out))
-                                          : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
-        else rc = thr ? launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
-        if (rc) return rc;
-        a.mt_jobs = nullptr;
-        a.mt_inline = (r == rounds - 1) ? 1 : 0;
-        a.dbg = a.mt_inline ? base.dbg : nullptr;
-        if ((rc = launch_mt_kernel<P, SW, SR, MM, 1, 3>(d, st, a, n_run))) return rc;
-    }
-    return TWL_OK;
-}
-
-
-// ---- launch policy of the nucleotide path: a pure function of the call's facts (unit-tested without a GPU through twl_plan_describe) ----
-struct Knobs { int mt_max_pairs, mt_min_marker, mt_tail_pct, mt_wide, assume_onehot_query, no_spec, thr_small; };
-struct NucFacts {
-    int n_run = 0, num_cu = 0, marker = 0;
-    const float *M = nullptr;             // 5 x 5 matrix
-    float gap_char = 0;
-    bool qry_onehot = false, dump = false;
-    int wide_streak = 0, last_wide_pct = 0, wide_calls = 0;
-    int small_state = 0;                  // the 512-row throughput window (NucPlan::small) on the earlier levels of this pass: 1 they fitted it, -1 one outgrew it, 0 nothing known
-    const int32_t *h_len = nullptr;       // [pair][2]
-    const int32_t *order = nullptr;       // the pairs that run, longest first
-};
-enum class NucFirst { Dump, WideMt, Mt, SpecShared, Spec16, Few16, Throughput, General };
-struct NucPlan {
-    NucFirst first = NucFirst::General;
-    int mm = 0;                           // matrix mode 0 general / 1 zero N row and column / 2 match-transition-transversion
-    bool mm5 = false;                     // ... in its one-letter-query form (mode 5)
-    bool lean = false;                    // the round-2 kernels (scores within fast_div's range)
-    bool four = false;                    // throughput launch on 4 waves x 3 blocks, four workgroups per CU (768-row window)
-    bool small = false;                   // ... on 4 waves x 2 blocks, FIVE workgroups per CU (512-row window): levels of short pairs
-    bool probe = false;                   // ... to be decided by a sample of the level's pairs (run_device): levels of 8+ rounds with nothing remembered
-    bool held_back = false;               // ... not taken because a recent level outgrew it
-    int bulk = 0, tail = 0;               // throughput: pairs in full rounds / remainder through the tile-parallel path
-};
-NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
-{
-    NucPlan pl;
-    const float *M = f.M;
-    // matrix mode (see talco_kernel): 2 = default match/transition/transversion structure with a zero N row/column
-    bool nz = true, st3 = true;
-    for (int t = 0; t < 5; ++t) nz = nz && M[20 + t] == 0.0f && M[5 * t + 4] == 0.0f;
-    for (int l = 0; l < 4; ++l)
-        for (int m = 0; m < 4; ++m) st3 = st3 && M[5 * l + m] == ((l == m) ? M[0] : (((l ^ m) == 2) ? M[2] : M[1]));
-    pl.mm = nz ? (st3 ? 2 : 1) : 0;
-    // fast_div's guard (talco_nuc.hip.h): non-zero scores within [2^-10, 2^10]; anything else takes the IEEE-division kernel
-    bool divOk = true;
-    auto inRange = [](float x) { const float ax = std::fabs(x); return x == 0.0f || (ax >= 0.0009765625f && ax <= 1024.0f); };
-    for (int t = 0; t < 25; ++t) divOk = divOk && inRange(M[t]);
-    pl.lean = divOk && inRange(f.gap_char);
-    const int mm = pl.mm, n_run = f.n_run;
-    // few pairs: one 64-row block per wave (16 waves) for the shortest diagonal step
-    const bool few = n_run <= f.num_cu;
-    int32_t maxLen = 0;
-    long long sumLen = 0;
-    for (int32_t t = 0; t < n_run; ++t) {
-        const int32_t R = f.h_len[2 * f.order[t]], Q = f.h_len[2 * f.order[t] + 1];
-        maxLen = std::max(maxLen, std::max(R, Q)); sumLen += (long long)R + Q;
-    }
-    // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
-    pl.mm5 = pl.lean && mm >= 1 && (f.qry_onehot || k.assume_onehot_query);
-    // very few pairs: two workgroups per pair take the tiles in turn (the mailbox words of that start carry absolute positions in 16 bits each)
-    const bool spec = pl.lean && few && (mm == 2 || pl.mm5) && 2 * n_run <= f.num_cu && maxLen <= 65535 && !k.no_spec;
-    // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the pairs fill the
-    // ONE round of the throughput kernel badly -- tiles spread evenly, at the price of the scouts (~1.2x the work).  Levels of several rounds: the remainder rule below.
-    pl.four = pl.lean && (pl.mm5 || mm == 2);
-    // With X-drop 5000 a band is ~440 rows wide whatever the length of the pair: most pairs fit a 512-row window, and at 29 KB of LDS and 96 registers FIVE
-    // workgroups of 4 waves x 2 blocks share a CU -- five independent anti-diagonal chains per SIMD instead of four (16 384 pairs of 1.6 kbp: 95.7 -> 82.6 ms,
-    // leaf x leaf 76.2 -> 65.3 ms, tools/exp_thr.py).  A level whose pairs outgrow the window pays for it twice (they re-run on the 768-row geometry), so the
-    // outcome is remembered for the rest of the pass (run_device keeps small_state; bands widen up the tree, and a level LARGER than the one before it is the
-    // start of another pass or family: nothing is known again): after a level that fitted the next ones start there, after one that sent more than 1 % of its
-    // pairs on the rest of the pass stays off it (the window is worth ~16 % of a level's time; the pairs that outgrow it run twice AND their re-run is a launch
-    // of its own that takes a pair's full latency, ~3.5 ms for 1.6 kbp pairs, however few they are: on 100 000 x 1.6 kbp levels of 3-5 % lost 2-11 %), and a
-    // level that finds nothing remembered asks ITS OWN pairs when it is large -- eight or more rounds: one pair per CU, spread over the cost order, runs on the
-    // small window first (they are part of the level: nothing is computed twice but what outgrows the window; ~3 ms) and the share of them that outgrew it
-    // decides for the rest -- and simply tries when it is small.
-    const long long longest = n_run > 0 ? (long long)f.h_len[2 * f.order[0]] + f.h_len[2 * f.order[0] + 1] : 0;
-    // LONG pairs are eligible too (late round 4: on 10 000 x 10 kbp no pair of any level outgrows 512 rows, and the five workgroups are worth 97.8 against 110 ms
-    // on its leaf level, 442 against 469 ms per pass): what made a lost bet expensive there -- the re-run of a FEW 10 kbp pairs, one after the other, a pair's
-    // full latency of ~18 ms -- goes through the tile-parallel path instead (run_device: ~3 ms).  They are not sampled (a sample would cost that latency): the
-    // first level of a pass pairs sibling leaves, the most similar sequences of the family, and simply tries; the levels above it do as it fared.
-    const bool eligible = pl.four && n_run > f.num_cu && k.thr_small == 0;
-    pl.probe = eligible && f.small_state == 0 && n_run >= 8 * f.num_cu && longest <= 4096;
-    pl.small = (pl.four && n_run > f.num_cu && k.thr_small == 2) || (eligible && f.small_state >= 0);
-    pl.held_back = eligible && f.small_state < 0;
-    const int perRound = (pl.small ? 5 : (pl.four ? 4 : 2)) * f.num_cu;
-    const double roundsThr = (double)n_run / (double)perRound;
-    const bool mtOk = pl.lean && mm == 2 && !pl.mm5 && !f.dump && n_run <= k.mt_max_pairs && f.marker >= k.mt_min_marker &&
-                      sumLen >= 3ll * f.marker * n_run && (2 * n_run <= f.num_cu || (roundsThr <= 1.0 && std::ceil(roundsThr) >= 1.2 * roundsThr));
-    // the last calls' pairs all outgrew the fast window (the deferred pass: one pair per level against the same growing root): no point in finding
-    // that out again -- straight to the 3072-row geometry; every 8th such call tries the fast window again
-    // ... and so for a level of up to CUs pairs when three quarters of the previous narrow-first level's pairs went on to the wide window (the upper levels
-    // of a family whose pairs outgrow the fast window: their narrow attempts cost 40-80 ms each in tiles computed in line up to the overflow); every 6th probes
-    const bool wideFirst = k.mt_wide && (n_run <= 8 ? (f.wide_streak >= 2 && (f.wide_streak & 7) != 7)
-                                                    : (n_run <= f.num_cu && f.last_wide_pct >= 75 && (f.wide_calls % 6) != 5));
-    if (f.dump) pl.first = NucFirst::Dump;
-    else if (mtOk && wideFirst) pl.first = NucFirst::WideMt;
-    else if (mtOk) pl.first = NucFirst::Mt;
-    // CUs/2 < pairs <= CUs: two workgroups per pair taking the tiles in turn, of the 8-wave geometry, two to a CU (all 2n resident at once, as the teams
-    // wait for each other).  250 pairs of 10 kbp: 27.6 -> 20.1 ms against one 16-wave workgroup per pair
-    else if (pl.lean && mm == 2 && n_run <= f.num_cu && 2 * n_run > f.num_cu && maxLen <= 65535 && !k.no_spec) pl.first = NucFirst::SpecShared;
-    else if (spec) pl.first = NucFirst::Spec16;
-    else if (pl.lean && few) pl.first = NucFirst::Few16;
-    else if (pl.lean) {
-        // Many pairs: persistent workgroups take them in rounds.  A last round that is badly filled costs a whole round: when the remainder is small enough
-        // its pairs (the shortest ones, the order is longest first) go through the tile-parallel path instead, where they spread over all CUs.
-        pl.first = NucFirst::Throughput;
-        int tail = n_run % perRound;
-        long long tailLen = 0;
-        for (int32_t t = n_run - tail; t < n_run; ++t) tailLen += (long long)f.h_len[2 * f.order[t]] + f.h_len[2 * f.order[t] + 1];
-        // (pairs of 8+ tiles: with fewer the scouts and extra launches cost more than the idle workgroups)
-        if (!(n_run > perRound && tail > 0 && tail * 100 <= k.mt_tail_pct * perRound && tail <= k.mt_max_pairs && pl.four && f.marker >= k.mt_min_marker && tailLen >= 8ll * f.marker * tail)) tail = 0;
-        pl.tail = tail; pl.bulk = n_run - tail;
-    }
-    else pl.first = NucFirst::General;
-    if (pl.first != NucFirst::Throughput) pl.small = pl.probe = pl.held_back = false;
-    return pl;
-}
-const char *nuc_first_name(NucFirst f)
-{
-    switch (f) {
-    case NucFirst::Dump: return "dump";
-    case NucFirst::WideMt: return "tile-parallel, 3072-row window";
-    case NucFirst::Mt: return "tile-parallel";
-    case NucFirst::SpecShared: return "speculative teams, 8 waves x 2 blocks";
-    case NucFirst::Spec16: return "speculative teams, 16 waves";
-    case NucFirst::Few16: return "16 waves x 1 block";
-    case NucFirst::Throughput: return "throughput";
-    default: return "general (IEEE division)";
-    }
-}
-
-Knobs current_knobs() { return Knobs{g_mt_max_pairs, g_mt_min_marker, g_mt_tail_pct, g_mt_wide, g_assume_onehot_query, g_no_spec, g_thr_small}; }
 
 // Device-resident core.  len/num are needed on the host for cost ordering (they are tiny).
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
@@ -1486,133 +1070,7 @@ int twl_set_knob(int key, int value)
     }
 }
 
-// ---- RCCL, loaded at run time (include/twl_align.h) ----
-namespace {
-struct RcclId { char b[TWL_COMM_ID_BYTES]; };      // ncclUniqueId: 128 opaque bytes, passed by value
-struct Rccl {
-    void *h = nullptr;
-    int (*getUniqueId)(void *) = nullptr;
-    int (*commInitRank)(void **, int, RcclId, int) = nullptr;
-    int (*allGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
-    int (*commDestroy)(void *) = nullptr;
-    const char *(*errorString)(int) = nullptr;
-};
-Rccl g_rccl;
-int rccl_load()
-{
-    if (g_rccl.h) return TWL_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);      // a copy the process has already (PyTorch-ROCm brings its own)
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { g_err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return TWL_ERR_HIP; }
-    Rccl r;
-    r.h = h;
-    r.getUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-    r.commInitRank = (int (*)(void **, int, RcclId, int))dlsym(h, "ncclCommInitRank");
-    r.allGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
-    r.commDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-    r.errorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!r.getUniqueId || !r.commInitRank || !r.allGather || !r.commDestroy) { g_err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy"; return TWL_ERR_HIP; }
-    g_rccl = r;
-    return TWL_OK;
-}
-void comm_destroy_raw(void *comm) { if (g_rccl.commDestroy) (void)g_rccl.commDestroy(comm); }
-int rccl_fail(const char *what, int rc)
-{
-    g_err = std::string(what) + ": " + (g_rccl.errorString ? g_rccl.errorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
-    return TWL_ERR_HIP;
-}
-}  // namespace
-
-int twl_comm_unique_id(void *id128)
-{
-    if (!id128) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = rccl_load();
-    if (rc) return rc;
-    const int n = g_rccl.getUniqueId(id128);
-    return n == 0 ? TWL_OK : rccl_fail("ncclGetUniqueId", n);
-}
-
-int twl_comm_init(int device, int rank, int world, const void *id128)
-{
-    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
-    if (!id128 || world < 1 || rank < 0 || rank >= world) { g_err = "bad argument"; return TWL_ERR_BAD_ARGUMENT; }
-    Device *d = nullptr;
-    int rc = find_dev(device, &d);
-    if (rc) return rc;
-    { std::lock_guard<std::mutex> lk(g_mu); if ((rc = rccl_load())) return rc; }
-    std::lock_guard<std::mutex> dl(d->mu);
-    // (one communicator per process and device: a second run of the process -- bench.py opens its handles ahead of the clock -- shares it; every rank does)
-    if (d->comm) { if (d->comm_world == world && d->comm_rank == rank) return TWL_OK; g_err = "device already has a communicator of another shape"; return TWL_ERR_BAD_ARGUMENT; }
-    HIP_TRY(hipSetDevice(d->id));
-    RcclId id;
-    memcpy(id.b, id128, sizeof id.b);
-    void *comm = nullptr;
-    const int n = g_rccl.commInitRank(&comm, world, id, rank);
-    if (n != 0) return rccl_fail("ncclCommInitRank", n);
-    d->comm = comm; d->comm_world = world; d->comm_rank = rank;
-    return TWL_OK;
-}
-
-namespace {
-// (the device's lock is held by the caller)
-int comm_all_gather_locked(Device *d, const void *d_send, void *d_recv, int64_t bytes_per_rank)
-{
-    if (!d->comm || !d_send || !d_recv || bytes_per_rank <= 0) { g_err = "no communicator on this device (twl_comm_init) or bad argument"; return TWL_ERR_BAD_ARGUMENT; }
-    HIP_TRY(hipSetDevice(d->id));
-    // on the library's stream: ordered behind the kernels that packed the block, ahead of those that unpack the others'
-    const int n = g_rccl.allGather(d_send, d_recv, (size_t)bytes_per_rank, 0 /* ncclChar */, d->comm, d->stream);
-    if (n != 0) return rccl_fail("ncclAllGather", n);
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return TWL_OK;
-}
-}  // namespace
-
-int twl_comm_all_gather(int device, const void *d_send, void *d_recv, int64_t bytes_per_rank)
-{
-    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
-    Device *d = nullptr;
-    int rc = find_dev(device, &d);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> dl(d->mu);
-    return comm_all_gather_locked(d, d_send, d_recv, bytes_per_rank);
-}
-
-int twl_comm_all_gather_host(int device, const void *send, void *recv, int64_t bytes_per_rank)
-{
-    if (!g_init) { g_err = "twl_init not called"; return TWL_ERR_NOT_INITIALIZED; }
-    Device *d = nullptr;
-    int rc = find_dev(device, &d);
-    if (rc) return rc;
-    // ONE hold of the device's lock from staging to copy-back (the staging buffers are the device's, two callers would have raced on them)
-    std::lock_guard<std::mutex> dl(d->mu);
-    if (!d->comm || !send || !recv || bytes_per_rank <= 0) { g_err = "no communicator on this device (twl_comm_init) or bad argument"; return TWL_ERR_BAD_ARGUMENT; }
-    const int world = d->comm_world;
-    HIP_TRY(hipSetDevice(d->id));
-    if ((rc = d->comm_send.ensure((size_t)bytes_per_rank))) return rc;
-    if ((rc = d->comm_recv.ensure((size_t)bytes_per_rank * (size_t)world))) return rc;
-    HIP_TRY(hipMemcpyAsync(d->comm_send.p, send, (size_t)bytes_per_rank, hipMemcpyHostToDevice, d->stream));
-    if ((rc = comm_all_gather_locked(d, d->comm_send.p, d->comm_recv.p, bytes_per_rank))) return rc;
-    HIP_TRY(hipMemcpy(recv, d->comm_recv.p, (size_t)bytes_per_rank * (size_t)world, hipMemcpyDeviceToHost));
-    return TWL_OK;
-}
-
-int twl_comm_destroy(int device)
-{
-    if (!g_init) return TWL_OK;
-    Device *d = nullptr;
-    int rc = find_dev(device, &d);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> dl(d->mu);
-    if (!d->comm) return TWL_OK;
-    (void)hipSetDevice(d->id);
-    (void)hipStreamSynchronize(d->stream);
-    const int n = g_rccl.commDestroy(d->comm);
-    d->comm = nullptr; d->comm_world = 0;
-    return n == 0 ? TWL_OK : rccl_fail("ncclCommDestroy", n);
-}
+#include "twl_comm.inc.hip"
 
 // The launch plan of a nucleotide call, as run_device would make it, in words: no device is touched (unit tests of the policy on a CPU-only box).
 int twl_plan_describe(const twl_params *p, int32_t n_pairs, const int32_t *len, int32_t num_cu, int32_t qry_onehot, int32_t wide_streak, char *out, int32_t cap)

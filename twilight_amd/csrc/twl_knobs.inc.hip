@@ -1,0 +1,15 @@
+// twilight_amd/csrc/twl_knobs.inc.hip -- the development / test knobs of the dispatch (twl_set_knob, include/twl_align.h): their variables and defaults.
+// Included by twl_align.hip (one translation unit: it shares that file's Device bookkeeping, error string and fill queue).
+
+int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
+int g_mt_lead = 320, g_mt_marg = 40;
+int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
+int g_scout_xdrop_pct = 100;         // twl_set_knob(TWL_KNOB_SCOUT_XDROP_PCT): X-drop of the pair scouts in percent of the call's (they only predict: a narrower band is a cheaper scout)
+int g_no_spec = 0;                   // twl_set_knob(TWL_KNOB_NO_SPEC): no speculative two-workgroup teams (tools that time the plain tile loop)
+int g_thr_small = 0;                 // twl_set_knob(TWL_KNOB_THR_SMALL): 0 = the 512-row throughput geometry for levels of short pairs (plan_nucleotide), 1 never, 2 whenever the throughput kernel runs (tests)
+int g_mt_wide = 1;                   // twl_set_knob(TWL_KNOB_MT_WIDE): 0 = pairs that outgrew the 1024-row window run tile after tile (the path before round 4; tests compare the two)
+int g_mt_tail_pct = 70;              // twl_set_knob(TWL_KNOB_MT_TAIL_PCT): a last round filled up to this share of 2 * CUs workgroups goes through the tile-parallel path (0 = never)
+int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force a protein kernel variant (tests of every variant)
+int g_force_global = 0;             // twl_set_knob(TWL_KNOB_FORCE_GLOBAL): every pair of every call runs on the global-memory kernel (tests of that kernel on small cases)
+int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
+struct Knobs;
