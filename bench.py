@@ -339,6 +339,8 @@ def main():
         twl.set_knob(twl.knobs.KNOB_MT_TAIL_PCT, int(os.environ["TWL_BENCH_MT_TAIL_PCT"]))
     if os.environ.get("TWL_BENCH_THR_SMALL"):            # development: the 512-row throughput window never (1) / on every throughput level (2)
         twl.set_knob(twl.knobs.KNOB_THR_SMALL, int(os.environ["TWL_BENCH_THR_SMALL"]))
+    if os.environ.get("TWL_BENCH_LEAF_STEP"):            # development: 0 = leaf x leaf levels on the general step
+        twl.set_knob(twl.knobs.KNOB_LEAF_STEP, int(os.environ["TWL_BENCH_LEAF_STEP"]))
     if os.environ.get("TWL_BENCH_SCOUT_XDROP_PCT"):      # development: what a narrower band of the pair scouts costs and saves
         twl.set_knob(twl.knobs.KNOB_SCOUT_XDROP_PCT, int(os.environ["TWL_BENCH_SCOUT_XDROP_PCT"]))
     num_cu = torch.cuda.get_device_properties(dev).multi_processor_count

@@ -417,3 +417,56 @@ def test_one_launch_takes_pairs_of_both_gap_character_kinds(gpu, regime):
     aln_1, n_1, err_1 = st.align(p, zero_gap=np.ones(n, dtype=np.uint8))
     assert np.array_equal(n_1, n_a) and np.array_equal(err_1, err_a) and all(np.array_equal(aln_1[i, : n_1[i]], aln_a[i, : n_a[i]]) for i in range(n))
     st.close()
+
+
+def test_leaf_level_runs_the_step_without_gap_terms_and_division(gpu):
+    """A level whose pairs are all single sequences on both sides (the bottom of every guide tree) runs talco_lean_kernel<..., SP = 1>: no gap-letter terms, no
+    division, none of their per-block tests.  Same paths, lengths, error codes and band cells as the general step (TWL_KNOB_LEAF_STEP 0) and as the oracle;
+    a level with ONE two-sequence side does not take it."""
+    import twilight_amd as twl
+    from twilight_amd import api, level as L, synth
+
+    rng = np.random.default_rng(5)
+    n = 600                                        # more pairs than CUs: the throughput launch (+ its tile-parallel remainder when the last round is badly filled)
+    M = LC.matrix_of("n")
+    p = twl.make_params(M)
+
+    def leaf_pairs(extra_member):
+        seqs, pairs = [], []
+        for i in range(n):
+            a = "".join("ACGT"[c] for c in rng.integers(0, 4, size=900 + int(rng.integers(0, 60))))
+            b = list(a)
+            for _ in range(25):
+                b[int(rng.integers(0, len(b)))] = "ACGTN"[int(rng.integers(0, 5))]
+            if i % 3 == 0: del b[100:104]
+            b = "".join(b)
+            ids_a = [len(seqs)]; seqs.append(a)
+            ids_b = [len(seqs)]; seqs.append(b)
+            if extra_member and i == 17:
+                ids_a.append(len(seqs)); seqs.append(a)      # (same length as its row mate)
+            sides = [L.Side(members=m, member_weight=[1.0] * len(m), len=len(seqs[m[0]]), num=len(m), weight=float(len(m))) for m in (ids_a, ids_b)]
+            pairs.append(sides)
+        return seqs, pairs
+
+    seqs, pairs = leaf_pairs(False)
+    st = L.Store(seqs, "n")
+    st.prepare(p, pairs, gappy_threshold=0.95)
+    aln1, n1, err1 = st.align(p)
+    s1 = twl.get_stats(0)
+    assert b", 0, 1>" in s1.kernel and s1.matrix_mode == 5, s1.kernel
+    twl.set_knob(api.KNOB_LEAF_STEP, 0)
+    try:
+        aln0, n0, err0 = st.align(p)
+        s0 = twl.get_stats(0)
+    finally:
+        twl.set_knob(api.KNOB_LEAF_STEP, 1)
+    assert b", 0, 1>" not in s0.kernel, s0.kernel
+    assert np.array_equal(n1, n0) and np.array_equal(err1, err0) and np.array_equal(aln1, aln0) and s1.band_cells == s0.band_cells
+    # (against the oracle: every end-to-end pin of tests/test_e2e_pin.py and tests/test_gpu_variants.py starts with such a level)
+    st.close()
+    seqs, pairs = leaf_pairs(True)
+    st = L.Store(seqs, "n")
+    st.prepare(p, pairs, gappy_threshold=0.95)
+    st.align(p)
+    assert b", 0, 1>" not in twl.get_stats(0).kernel
+    st.close()

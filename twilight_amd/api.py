@@ -144,6 +144,7 @@ KNOB_MT_PERTURB, KNOB_MT_MAX_PAIRS, KNOB_MT_MIN_MARKER, KNOB_MT_LEAD, KNOB_MT_MA
 KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY, KNOB_MT_TAIL_PCT, KNOB_MT_WIDE, KNOB_NO_SPEC, KNOB_SCOUT_XDROP_PCT = 9, 10, 11, 12, 13, 14
 KNOB_THR_SMALL = 15
 KNOB_FORCE_GLOBAL = 16
+KNOB_LEAF_STEP = 17
 PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 
 

@@ -254,9 +254,17 @@ struct NCfg {
 // talco_kernel): nucleotide 0 general 5x5, 1 zero N row/column (4x4 core), 2 mode 1 with the match / transition / transversion
 // structure (three products per row letter), 5 modes 1 / 2 for query rows with one non-zero letter (single sequences); protein 3 loop over the non-zero letters of the reference column, 4 scores
 // precomputed by score_matrix_kernel for the whole R x Q matrix (launches with few pairs: the other CUs are idle anyway).
-template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false, int MT = 0>
+// SP (round 5) = what the host knows about every pair of the launch, taken out of the per-block tests (15 of the ~111 instructions of a leaf x leaf block step are
+// the tests "does a row of this block hold gap letters", "does a column in the band", "is the denominator 1" and their branches; profiles/r05/isa_block_step.json):
+//   0  nothing: the tests run (every other launch)
+//   1  leaf x leaf: single sequences on both sides -- no gap letter anywhere and refNum * qryNum = 1: neither the gap-letter terms (:394-395) nor the division (:444)
+//      exist in the step (leaf level of 10 000 x 10 kbp 94.7 -> 88.6 ms).  The promise is checked: a gap letter or another denominator sends the pair to the
+//      general kernel (kErrGuard).  (The opposite specialisation -- several sequences on both sides, terms always formed -- was built and measured: no level of a
+//      random tree qualifies, every level joins some leaf to a subtree.)
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false, int MT = 0, int SP = 0>
 __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 {
+    static_assert(SP == 0 || (SP == 1 && P == 6 && !SPEC && !DUMP && MM == 5), "the leaf x leaf step: nucleotide, one-letter query rows");
     static_assert((P == 6 && ((MM >= 0 && MM <= 2) || MM == 5)) || (P == 22 && (MM == 3 || MM == 4)), "profile width / column-score mode");
     static_assert(MT == 0 || (!SPEC && !DUMP), "the tile-parallel kernels are plain ones");
     constexpr bool GUESS = SPEC || MT == 2;      // the best cells of the two marker diagonals are collected
@@ -393,6 +401,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         // The row tags of the reductions hold k + 1 in 16 bits and a row in 16 bits -- TILE-local values, so sequences of any length pass
         // (a tile that has not converged after 65 534 diagonals goes to the round-1 kernel, below); the mailbox words of the speculative
         // start carry absolute positions in 16 bits each (the host does not pick that kernel for longer sequences).
+        if (SP == 1 && !last_tile && !denomOne) { err = kErrGuard; last_tile = true; }      // (the leaf x leaf step has no division)
         if (!last_tile && ((SPEC && (R > 65535 || Q > 65535)) || !(denom >= 1.0f && denom <= 1.0995116e12f))) { err = (denom >= 1.0f && denom <= 1.0995116e12f) ? kErrOverflow : kErrGuard; last_tile = true; }
         int dbg_lastk = 0, dbg_conv = 0, dbg_L = 0, dbg_U = 0;
         bool guardBad = false;
@@ -550,8 +559,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             qM[r][m] = qv[r][m] * a.M[20 + m];
                         }
                     }
-                    q5any[r] = gcNZ && __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
+                    if constexpr (SP == 1) q5any[r] = false;
+                    else q5any[r] = gcNZ && __builtin_amdgcn_ballot_w64(cb[P - 1] != 0.0f) != 0ull;
                     bool bad = false;
+                    if constexpr (SP == 1) bad = (cb[P - 1] != 0.0f);      // a gap letter in a "leaf" row: the promise does not hold
 #pragma unroll
                     for (int t = 0; t < P; ++t) bad = bad | div_guard_bad(cb[t]);
                     guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
@@ -577,6 +588,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (4 * t + u < P) bad = bad | div_guard_bad(f[u]);
+                            if (SP == 1 && 4 * t + u == P - 1) bad = bad | (f[u] != 0.0f);
                             if (SPARSE && 4 * t + u < 21) mk |= (f[u] != 0.0f) ? (1u << (4 * t + u)) : 0u;
                         }
                     }
@@ -749,7 +761,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #pragma unroll
                                 for (int l = 0; l < 5; ++l) numer += (rc[l] * qv[r][5]) * gc;          // :394
                             }
-                            if ((__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f) & gcMask) != 0ull) {
+                            bool rgAny;
+                            if constexpr (SP == 1) rgAny = false;
+                            else rgAny = (__builtin_amdgcn_ballot_w64(inband) & __builtin_amdgcn_ballot_w64(rg != 0.0f) & gcMask) != 0ull;
+                            if (rgAny) {
 #pragma unroll
                                 for (int m = 0; m < 5; ++m) numer += (rg * qv[r][m]) * gc;             // :395
                             }
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             else sim = colOk ? simP[(size_t)(k + simK0) * (size_t)simPitch + col] : 0.0f;
                             simNext[r] = (colOk && k + 1 < kEnd) ? simP[(size_t)(k + 1 + simK0) * (size_t)simPitch + col] : 0.0f;
                             simFor[r] = k + 1;
-                        } else if (!denomOne) {      // (a real branch: leaf pairs, a third of all cells, have refNum * qryNum == 1)
+                        } else if (SP == 0 && !denomOne) {      // (a real branch: leaf pairs, a third of all cells, have refNum * qryNum == 1)
                             sim = fast_div(numer, denom, rden);
                             asm volatile("" : "+v"(sim));
                         }
@@ -1151,7 +1166,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             if (tile_err != 0) { err = tile_err; break; }
             // a profile entry outside fast_div's range: the IEEE-division kernel re-runs the pair (every wave saw different columns:
             // the verdict goes through LDS so that all of them leave together)
-            if (!denomOne) {
+            if (SP == 1 || !denomOne) {
                 if (guardBad) s_misc[4] = 1;
                 __syncthreads();
                 guardBad = __builtin_amdgcn_readfirstlane(s_misc[4]) != 0;

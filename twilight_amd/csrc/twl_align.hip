@@ -186,10 +186,12 @@ int check_params(const twl_params *p)
 int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, int32_t seq_len, const float *d_freq,
                const float *d_gop, const float *d_gex, const int32_t *d_len, const int32_t *d_num, int8_t *d_aln,
                int32_t *d_alnlen, int16_t *d_err, const int32_t *h_len, const float *d_packed = nullptr, bool qry_onehot = false,
-               const uint8_t *h_gc_zero = nullptr)
+               const uint8_t *h_gc_zero = nullptr, int shape = 0)
 {
     // h_gc_zero: optional [n_pairs], 1 = the pair's gapCharScore is 0 whatever p->gap_char says (the reference decides it per pair,
     // alignment-cpu.cpp:88; one launch then takes the pairs of both kinds -- the top levels of a 100 000-leaf tree hold a few of each)
+    // shape: what the caller knows about EVERY pair that runs: 2 = single sequences on both sides (no gap letters, denominators of 1): the throughput kernels
+    // then run a step without the per-block tests (talco_lean_kernel, SP 1)
     // qry_onehot: every query row of every pair of this call has at most one non-zero letter (single sequences: the device-resident
     // level path knows, it built the profiles) -- the nucleotide kernels then take the four-product form of the column score
     // d_packed: the level's columns already in the packed [P+2] layout (device-resident level path); no packing pass then
@@ -381,7 +383,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     }
     else {
         NucFacts nf;
-        nf.n_run = n_run; nf.num_cu = d->num_cu; nf.marker = p->marker; nf.M = a.M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot; nf.dump = d->dump_on;
+        nf.n_run = n_run; nf.num_cu = d->num_cu; nf.marker = p->marker; nf.M = a.M; nf.gap_char = p->gap_char; nf.qry_onehot = qry_onehot; nf.shape = shape; nf.dump = d->dump_on;
         nf.wide_streak = d->wide_streak; nf.last_wide_pct = d->last_wide_pct; nf.wide_calls = d->wide_calls; nf.small_state = (n_run > d->small_last_n) ? 0 : d->small_state; nf.h_len = h_len; nf.order = order.data();
         const NucPlan pl = plan_nucleotide(nf, current_knobs());
         if (pl.first == NucFirst::Throughput && (pl.small || pl.held_back)) { if (n_run > d->small_last_n) d->small_state = 0; d->small_last_n = n_run; }
@@ -404,7 +406,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
             break;
         case NucFirst::Mt:        // few pairs of many tiles each: all tiles of all pairs side by side from predicted starts (talco_nuc.hip.h, MT kernels)
             smallTiles = nf.small_state > 0;      // (the throughput levels of this pass fitted the 512-row window: so do the tiles of their pairs' descendants, until they do not)
-            rc = launch_mt<6, 2, 3, false, 4>(d, st, a, items, order, n_run, h_len, &grid, &window, smallTiles);
+            rc = launch_mt<6, 2, 3, false, 4>(d, st, a, items, order, n_run, h_len, &grid, &window, smallTiles, pl.sp);
             statSpec = 3; ranMt = true;
             break;
         case NucFirst::SpecShared:
@@ -446,7 +448,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 std::copy(rest.begin(), rest.end(), order.begin() + (std::ptrdiff_t)front.size());
                 HIP_TRY(hipMemcpyAsync(d->items.p, order.data(), (size_t)bulk * sizeof(int32_t), hipMemcpyHostToDevice, st));
                 done = (int)front.size();
-                rc = mm5 ? launch_lean<6, 4, 2, 5, 5>(d, st, a, items, done, &grid, &window) : launch_lean<6, 4, 2, 2, 5>(d, st, a, items, done, &grid, &window);
+                rc = launch_thr<4, 2, 5>(d, st, a, items, done, &grid, &window, mm5, pl.sp);
                 if (rc) return rc;
                 if ((size_t)n_pairs * sizeof(int16_t) > d->probe_cap) {
                     if (d->probe_h) (void)hipHostFree(d->probe_h);
@@ -464,10 +466,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 TRACE("sample of %d pairs on the 512-row window: %d outgrew it -> the level runs on %d rows", done, outgrew, small ? 512 : 768);
                 d->kname[0] = 0;                          // (the level's kernel is the one the rest runs on)
             }
-            if (small && mm5) rc = launch_lean<6, 4, 2, 5, 5>(d, st, a, items + done, bulk - done, &grid, &window);
-            else if (small) rc = launch_lean<6, 4, 2, 2, 5>(d, st, a, items + done, bulk - done, &grid, &window);
-            else if (mm5) rc = launch_lean<6, 4, 3, 5, 4>(d, st, a, items + done, bulk - done, &grid, &window);
-            else if (mm == 2) rc = launch_lean<6, 4, 3, 2, 4>(d, st, a, items + done, bulk - done, &grid, &window);
+            if (small && (mm5 || mm == 2)) rc = launch_thr<4, 2, 5>(d, st, a, items + done, bulk - done, &grid, &window, mm5, pl.sp);
+            else if (mm5 || mm == 2) rc = launch_thr<4, 3, 4>(d, st, a, items + done, bulk - done, &grid, &window, mm5, pl.sp);
 #endif
             else if (mm == 1) rc = launch_lean<6, 8, 2, 1, 2>(d, st, a, items, bulk, &grid, &window);
             else rc = launch_lean<6, 8, 2, 0, 2>(d, st, a, items, bulk, &grid, &window);
@@ -481,8 +481,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 int g2 = 0, w2 = 0;
                 // (one-letter query rows: the tiles too take the four-product form of the column score)
                 smallTiles = small && !probed;
-                rc = mm5 ? launch_mt<6, 5, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2, smallTiles)
-                         : launch_mt<6, 2, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2, smallTiles);
+                rc = mm5 ? launch_mt<6, 5, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2, smallTiles, pl.sp)
+                         : launch_mt<6, 2, 3, false, 4>(d, st, a, items + bulk, tailOrder, tail, h_len, &g2, &w2, smallTiles, pl.sp);
                 ranMt = true;
             }
             break;
@@ -1064,6 +1064,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_WIDE: g_mt_wide = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_FORCE_GLOBAL: g_force_global = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_LEAF_STEP: g_leaf_step = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;

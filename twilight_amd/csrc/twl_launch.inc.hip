@@ -89,14 +89,14 @@ int launch_global(Device *d, hipStream_t st, const twl::KArgs &base, const int32
 }
 
 // The round-2 nucleotide kernel (talco_nuc.hip.h): same launch protocol as launch_dp.
-template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false>
+template <int P, int W, int RPL, int MM, int MINW, bool SPEC = false, bool DUMP = false, int SP = 0>
 int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, int n_items, int *grid_out, int *window_out)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};      // one value per template instantiation
     if (cached.load() == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), CfgT::THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP, 0, SP>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
     int blocks_per_cu = cached.load();
@@ -126,10 +126,13 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
         a.team = (unsigned long long *)d->team.p;
     }
     TRACE("launch lean P=%d W=%d RPL=%d MM=%d grid=%d threads=%d n_items=%d tb_words=%zu", P, W, RPL, MM, grid, CfgT::THREADS, n_items, tbw);
-    if (!d->kname[0]) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, %d, %s, %s, 0>", P, W, RPL, MM, MINW, SPEC ? "true" : "false", DUMP ? "true" : "false");
+    if (!d->kname[0]) {
+        if constexpr (SP != 0) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, %d, %s, %s, 0, %d>", P, W, RPL, MM, MINW, SPEC ? "true" : "false", DUMP ? "true" : "false", SP);
+        else snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, %d, %d, %d, %d, %s, %s, 0>", P, W, RPL, MM, MINW, SPEC ? "true" : "false", DUMP ? "true" : "false");
+    }
     a.simdump = DUMP ? (float *)d->simdump.p : nullptr;
     FILL_TRY(flush_fills(d, st));
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, SPEC, DUMP, 0, SP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (SPEC && dbg_on()) {      // development: how often the guessed tile start was the true one
         std::vector<unsigned long long> tw((size_t)n_items * twl::kTeamWords);
@@ -145,14 +148,14 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
 
 constexpr int kMtMaxRounds = 7, kMtCounters = 16;      // 1 + 2 * rounds launches, each with its own work counter (the count is clamped wherever it is set)
 // One launch of a tile-parallel kernel (MT 1 tiles / 2 scouts / 3 stitch) of geometry <W, RPL>; the caller has filled the NArgs.
-template <int P, int W, int RPL, int MM, int MINW, int MT>
+template <int P, int W, int RPL, int MM, int MINW, int MT, int SP = 0>
 int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *grid_out = nullptr, size_t tb_groups = 0)
 {
     using CfgT = twl::NCfg<W, RPL>;
     static std::atomic<int> cached{0};
     if (cached.load() == 0) {
         int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), CfgT::THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT, SP>), CfgT::THREADS, 0));
         cached.store(std::max(1, nb));
     }
     int grid = std::max(1, std::min(n_items, d->num_cu * cached.load()));
@@ -165,12 +168,30 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
     // (every launch of a tile-parallel level has its own work counter: launch_mt zeroed the 16 of them in one go)
     a.queue = (int32_t *)d->queue.p + (d->mt_launch++ % kMtCounters);
     FILL_TRY(flush_fills(d, st));
-    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
+    hipLaunchKernelGGL((twl::talco_lean_kernel<P, W, RPL, MM, MINW, false, false, MT, SP>), dim3(grid), dim3(CfgT::THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     if (grid_out) *grid_out = grid;
     return TWL_OK;
 }
 
+
+// What the host knows about every pair of a nucleotide launch, taken out of the kernel's per-block tests (talco_lean_kernel, SP): 1 = leaf x leaf (needs the
+// one-letter-query column score, MM 5).  Only the throughput geometries have the specialised step.
+template <int W, int RPL, int MINW>
+int launch_thr(Device *d, hipStream_t st, const twl::KArgs &a, const int32_t *items, int n, int *grid, int *window, bool mm5, int sp)
+{
+    if (mm5) {
+        if (sp == 1) return launch_lean<6, W, RPL, 5, MINW, false, false, 1>(d, st, a, items, n, grid, window);
+        return launch_lean<6, W, RPL, 5, MINW>(d, st, a, items, n, grid, window);
+    }
+    return launch_lean<6, W, RPL, 2, MINW>(d, st, a, items, n, grid, window);
+}
+template <int W, int RPL, int MM, int MINW, int MT>
+int launch_mt_thr(Device *d, hipStream_t st, const twl::NArgs &a, int n_items, int *grid_out, int sp)
+{
+    if constexpr (MM == 5) { if (sp == 1) return launch_mt_kernel<6, W, RPL, MM, MINW, MT, 1>(d, st, a, n_items, grid_out); }
+    return launch_mt_kernel<6, W, RPL, MM, MINW, MT>(d, st, a, n_items, grid_out);
+}
 
 // Tile-parallel alignment of a level with few pairs (talco_nuc.hip.h, MT kernels): scouts, then rounds of chain -> tiles -> stitch, on `st`.
 // `order` = the pairs that run, h_len their lengths on the host.  Scouts and tiles run on the 16-wave geometry (one workgroup per CU, the
@@ -178,7 +199,7 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
 
 template <int P, int MM, int TRPL, bool WIDE = false, int TW = 8>      // TW x TRPL: waves and 64-row blocks per wave of the throughput geometry (nucleotide 4 x 3: 768 rows, four workgroups per CU; protein 8 x 1: 512 rows, two)
 int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *d_items, const std::vector<int32_t> &order, int n_run,
-              const int32_t *h_len, int *grid_out, int *window_out, bool small_tiles = false)
+              const int32_t *h_len, int *grid_out, int *window_out, bool small_tiles = false, int sp = 0)
 {
     // small_tiles (nucleotide, throughput geometry): the tile jobs too run on 4 waves x 2 blocks, five workgroups per CU -- the earlier levels of this pass
     // fitted the 512-row window (plan_nucleotide, small).  A tile that outgrows it leaves a failed record of a window narrower than the stitch launch's, which
@@ -266,7 +287,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
         // (nucleotide scouts of the throughput geometry run ~330 diagonals from one cell: their band opens by a row per diagonal and cannot outgrow 449 rows, so
         //  they take the 512-row window -- 4 waves x 2 blocks, FIVE workgroups per CU, see plan_nucleotide -- whatever the tiles need)
-        if constexpr (P == 6 && TW == 4 && !WIDE) rc = thrS ? launch_mt_kernel<6, 4, 2, MM, 5, 2>(d, st, a, nScout) : launch_mt_kernel<P, SW, SR, MM, 1, 2>(d, st, a, nScout);
+        if constexpr (P == 6 && TW == 4 && !WIDE) rc = thrS ? launch_mt_thr<4, 2, MM, 5, 2>(d, st, a, nScout, nullptr, sp) : launch_mt_kernel<P, SW, SR, MM, 1, 2>(d, st, a, nScout);
         else rc = thrS ? launch_mt_kernel<P, TW, TRPL, MM, 4, 2>(d, st, a, nScout) : launch_mt_kernel<P, WIDE ? 16 : SW, WIDE ? 1 : SR, MM, 1, 2>(d, st, a, nScout);
         if (rc) return rc;
     }
@@ -276,7 +297,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
                            (int32_t *)d->mt_chain.p, slots, marker, g_mt_perturb, (const int32_t *)a.mt_front);
         HIP_TRY(hipGetLastError());
         a.mt_jobs = (const int32_t *)d->mt_jobs.p + 3 * (size_t)nScout;
-        if constexpr (kCanSmall) rc = thr ? (smallT ? launch_mt_kernel<6, 4, 2, MM, 5, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out))
+        if constexpr (kCanSmall) rc = thr ? (smallT ? launch_mt_thr<4, 2, MM, 5, 1>(d, st, a, nTile, grid_out, sp) : launch_mt_thr<TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out, sp))
                                           : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
         else rc = thr ? launch_mt_kernel<P, TW, TRPL, MM, 4, 1>(d, st, a, nTile, grid_out) : launch_mt_kernel<P, SW, SR, MM, 1, 1>(d, st, a, nTile, grid_out);
         if (rc) return rc;

@@ -776,8 +776,22 @@ int twl_level_align_mixed(twl_store *s, const twl_params *p, const uint8_t *run_
     bool qryOneHot = true;
     for (int32_t i = 0; i < n && qryOneHot; ++i)
         if (lm[2 * i] > 0 && lm[2 * i + 1] > 0) qryOneHot = s->sides[2 * (size_t)i + 1].n_members == 1 && s->sides[2 * (size_t)i + 1].cache_id < 0;
+    // what every selected pair looks like (run_device, shape): single uncached sequences on both sides -- no gap letter, denominators of 1
+    int shape = 0;
+    if (g_leaf_step) {
+        bool leaf = true, any = false;
+        for (int32_t i = 0; i < n && leaf; ++i) {
+            if (!(lm[2 * i] > 0 && lm[2 * i + 1] > 0)) continue;
+            any = true;
+            for (int side = 0; side < 2; ++side) {
+                const twl_side &sd = s->sides[2 * (size_t)i + side];
+                leaf = leaf && sd.n_members == 1 && sd.cache_id < 0 && sd.num == 1;
+            }
+        }
+        shape = (any && leaf) ? 2 : 0;
+    }
     rc = run_device(d, st, p, n, s->seq_len, nullptr, nullptr, nullptr, (const int32_t *)s->lv->d_lenmask.p, (const int32_t *)s->lv->d_num.p, (int8_t *)s->lv->d_aln.p,
-                    (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot, zero_gap);
+                    (int32_t *)s->lv->d_alnlen.p, (int16_t *)s->lv->d_err.p, lm.data(), (const float *)s->lv->d_cols.p, qryOneHot, zero_gap, shape);
     if (rc) return rc;
     if ((int32_t)d->last_err.size() == n && (int32_t)d->last_alnlen.size() == n) {      // (run_device read them back already, in its one synchronisation)
         std::copy(d->last_err.begin(), d->last_err.end(), err_out);

@@ -8,6 +8,7 @@ struct NucFacts {
     const float *M = nullptr;             // 5 x 5 matrix
     float gap_char = 0;
     bool qry_onehot = false, dump = false;
+    int shape = 0;                        // what the caller knows about every pair: 0 nothing, 2 leaf x leaf (single sequences on both sides)
     int wide_streak = 0, last_wide_pct = 0, wide_calls = 0;
     int small_state = 0;                  // the 512-row throughput window (NucPlan::small) on the earlier levels of this pass: 1 they fitted it, -1 one outgrew it, 0 nothing known
     const int32_t *h_len = nullptr;       // [pair][2]
@@ -24,6 +25,7 @@ struct NucPlan {
     bool probe = false;                   // ... to be decided by a sample of the level's pairs (run_device): levels of 8+ rounds with nothing remembered
     bool held_back = false;               // ... not taken because a recent level outgrew it
     int bulk = 0, tail = 0;               // throughput: pairs in full rounds / remainder through the tile-parallel path
+    int sp = 0;                           // the specialised step of the throughput geometries (talco_lean_kernel, SP): 1 leaf x leaf
 };
 NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
 {
@@ -51,6 +53,8 @@ NucPlan plan_nucleotide(const NucFacts &f, const Knobs &k)
     }
     // single-sequence query sides and no score for N: matrix mode 5 (the one-letter form of modes 1 and 2)
     pl.mm5 = pl.lean && mm >= 1 && (f.qry_onehot || k.assume_onehot_query);
+    // the step without the per-block tests (talco_lean_kernel, SP 1): leaf x leaf, on the one-letter-query score
+    pl.sp = (pl.lean && mm == 2 && f.shape == 2 && pl.mm5) ? 1 : 0;
     // very few pairs: two workgroups per pair take the tiles in turn (the mailbox words of that start carry absolute positions in 16 bits each)
     const bool spec = pl.lean && few && (mm == 2 || pl.mm5) && 2 * n_run <= f.num_cu && maxLen <= 65535 && !k.no_spec;
     // Tile-parallel path: always for levels of up to CUs/2 pairs (a pair's tile chain is what they wait for); beyond that when the pairs fill the
