@@ -440,10 +440,10 @@ def test_leaf_level_runs_the_step_without_gap_terms_and_division(gpu):
                 b[int(rng.integers(0, len(b)))] = "ACGTN"[int(rng.integers(0, 5))]
             if i % 3 == 0: del b[100:104]
             b = "".join(b)
-            ids_a = [len(seqs)]; seqs.append(a)
-            ids_b = [len(seqs)]; seqs.append(b)
+            ids_a = [len(seqs)]; seqs.append(a.encode())
+            ids_b = [len(seqs)]; seqs.append(b.encode())
             if extra_member and i == 17:
-                ids_a.append(len(seqs)); seqs.append(a)      # (same length as its row mate)
+                ids_a.append(len(seqs)); seqs.append(a.encode())      # (same length as its row mate)
             sides = [L.Side(members=m, member_weight=[1.0] * len(m), len=len(seqs[m[0]]), num=len(m), weight=float(len(m))) for m in (ids_a, ids_b)]
             pairs.append(sides)
         return seqs, pairs

@@ -644,6 +644,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             bool spec = true;                            // the next diagonal may be a "special" one (k == 0, or tile 0's first row/column)
             bool tbPending = false;
             unsigned tbOff = (unsigned)lane * 4u;        // byte offset of this lane's word in the current group of 8 diagonals (slot 0)
+            // Round 5: the traceback word of a slot is stored only when its block can have held band cells in the group of 8 diagonals (until then every window row
+            // wrote its word every 8th diagonal: 69 % of the path's HBM traffic).  L never decreases and U grows by at most a row per diagonal, so the bands of a
+            // group lie within [L, U + 8] of the diagonal in front of it (tbL0, tbU0); a slot that moved to another block in the group stores anyway (tbMust).
+            // The walk only reads words of cells on the path, and those are band cells.
+            int tbL0 = 0, tbU0 = 0;
+            unsigned tbMust = 0u;
             // Parity: vcur is the struct of diagonal k, vprev that of k-1; they swap by one xor each per diagonal.
             constexpr unsigned PARX = (unsigned)sizeof(ParBuf);      // s_par[1] - s_par[0]
             unsigned vcur = lds_off(&s_par[0]), vprev = lds_off(&s_par[1]);
@@ -921,6 +927,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         while (64 * blk[r] + 63 < Lk) blk[r] += NV;
                         ring_addr(r, k);
                         load_q(r);
+                        tbMust |= 1u << r;
                     }
                     ra[r] += 16u;
                     if (ra[r] == lds_off(s_ring) + CAP * 16u) ra[r] = lds_off(s_ring);
@@ -931,9 +938,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if constexpr (TB) {
 #pragma unroll
                         for (int r = 0; r < RPL; ++r) {
-                            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
+                            const int bb = 64 * blk[r];
+                            if (((tbMust >> r) & 1u) != 0u || (bb + 63 >= tbL0 && bb <= tbU0 + 8))
+                                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
                             tbacc[r] = 0;
                         }
+                        tbMust = 0u; tbL0 = Lk; tbU0 = Uk;
                         tbOff += (unsigned)WINDOW * 4u;
                         tbPending = false;
                     }
@@ -1056,7 +1066,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             // a band this wide can need the successor of a block on the diagonal the block leaves it: advance before the activity test
 #pragma unroll
                             for (int r = 0; r < RPL; ++r)
-                                if (64 * blk[r] + 63 < Lk) { while (64 * blk[r] + 63 < Lk) blk[r] += NV; ring_addr(r, k); load_q(r); }
+                                if (64 * blk[r] + 63 < Lk) { while (64 * blk[r] + 63 < Lk) blk[r] += NV; ring_addr(r, k); load_q(r); tbMust |= 1u << r; }
                         }
                     }
                 }
