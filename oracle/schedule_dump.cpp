@@ -24,6 +24,7 @@ int main(int argc, char **argv)
     msa::Option option;
     if (!msa::parseCommandLine(argc, argv, option)) return 1;
     msa::SequenceDB db;
+    db.updateSeqTh = option.updateSeqTh;
     msa::Tree *T = new msa::Tree(option.treeFile);
     phylogeny::assignSinglePartition(T->root);
     msa::Tree *subT = new msa::Tree(T->root, option.reroot);

@@ -123,3 +123,32 @@ def test_single_process_cpucheck_library_equals_cpu_checker(tmp_path):
         tot, levels = m.report()
         assert tot.n_levels == len(levels) and tot.aln_len > 0
     assert _md5(out) == _md5(ref)
+
+
+@pytest.mark.timeout(300)
+def test_a_handle_with_lowered_thresholds_leaves_the_next_one_alone(tmp_path):
+    """--test-cal-profile-th / --test-update-seq-th are per RUN (round 5: as process globals, like the reference's two constants, a handle that lowered them changed
+    the cached-profile and compressed-group branches -- and with them the band cells and the rows -- of every later handle of the process)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from twilight_amd import msa
+
+    tmp = str(tmp_path)
+    tree, fasta = _family(tmp, 50, 300, 6, seed=17, sub=0.08, indel=0.03)
+    ref = os.path.join(tmp, "ref.aln")
+    r = subprocess.run([os.path.join(ROOT, "oracle", "e2e_oracle"), "-t", tree, "-i", fasta, "-o", ref, "--threads", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref_cells = int([l for l in r.stdout.splitlines() if l.startswith("E2E")][-1].split("band_cells=")[1].split()[0])
+    low = os.path.join(tmp, "low.aln")
+    with msa.Msa(["-t", tree, "-i", fasta, "-o", low, "--host-staged", "--test-cal-profile-th", "2", "--test-update-seq-th", "3"], lib_path=CPUCHECK) as m:
+        m.align()
+        m.write()
+        low_cells = m.report()[0].band_cells
+    out = os.path.join(tmp, "lib.aln")
+    with msa.Msa(["-t", tree, "-i", fasta, "-o", out, "--host-staged"], lib_path=CPUCHECK) as m:
+        m.align()
+        m.write()
+        cells = m.report()[0].band_cells
+    assert cells == ref_cells and _md5(out) == _md5(ref)
+    assert low_cells > 0

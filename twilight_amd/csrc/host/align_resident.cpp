@@ -245,7 +245,7 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
     for (int i = 0; i < n; ++i) {
         PairState &s = ps[i];
         Node *nd[2] = {nodes[i].first, nodes[i].second};
-        const bool storeFreq = (s.refNum >= alignment_helper::_CAL_PROFILE_TH || s.qryNum >= alignment_helper::_CAL_PROFILE_TH) || (sides[2 * (size_t)i].cache_id >= 0 || sides[2 * (size_t)i + 1].cache_id >= 0);
+        const bool storeFreq = (s.refNum >= option->calProfileTh || s.qryNum >= option->calProfileTh) || (sides[2 * (size_t)i].cache_id >= 0 || sides[2 * (size_t)i + 1].cache_id >= 0);
         for (int sd = 0; sd < 2; ++sd) {
             twl_side &x = sides[2 * (size_t)i + sd];
             x.member_off = (int32_t)nMembers;

@@ -45,6 +45,7 @@ int twl_msa_open(int argc, const char *const *argv, twl_msa **out)
     m->hostStaged = m->option.hostStaged;
     msa::progressive::gpu::beginInit(&m->option);
     m->db = new msa::SequenceDB();
+    m->db->updateSeqTh = m->option.updateSeqTh;
     m->db->lazyRows = true;        // the rows stay in HBM after the main pass until twl_msa_write (or a deferred pass) needs them
     m->param = new msa::Params(m->option, m->option.type);
     m->T = new msa::Tree(m->option.treeFile);                                     // twilight-main.cpp:122

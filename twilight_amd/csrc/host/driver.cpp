@@ -66,8 +66,8 @@ bool parseCommandLine(int argc, char **argv, Option &o)
         else if (flag(a, "-v", "--verbose")) o.printDetail = true;
         else if (flag(a, "--host-staged", "--host-staged")) o.hostStaged = true;
         // development / test switches (documented in include/twl_msa.h): the reference's two thresholds, replicas of the store on one device
-        else if (flag(a, nullptr, "--test-cal-profile-th")) { const int v = atoi(val()); if (v > 0) alignment_helper::_CAL_PROFILE_TH = v; }
-        else if (flag(a, nullptr, "--test-update-seq-th")) { const int v = atoi(val()); if (v > 0) alignment_helper::_UPDATE_SEQ_TH = v; }
+        else if (flag(a, nullptr, "--test-cal-profile-th")) { const int v = atoi(val()); if (v > 0) o.calProfileTh = v; }
+        else if (flag(a, nullptr, "--test-update-seq-th")) { const int v = atoi(val()); if (v > 0) o.updateSeqTh = v; }
         else if (flag(a, nullptr, "--test-virtual-devices")) o.testVirtualDevices = std::max(0, atoi(val()));
         else if (flag(a, nullptr, "--test-no-ownership")) o.testNoOwnership = true;
         else if (flag(a, nullptr, "--overwrite")) {}
@@ -94,6 +94,7 @@ int runDefaultAlignment(Option &option, alnFunction kernel, alnFunction deferred
     auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = clk();
     SequenceDB database;
+    database.updateSeqTh = option.updateSeqTh;
     Params param(option, option.type);
     Tree *T = new Tree(option.treeFile);                                    // twilight-main.cpp:122
     phylogeny::assignSinglePartition(T->root);                              // :129-130 with maxSubtree = INT32_MAX

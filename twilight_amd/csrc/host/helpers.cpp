@@ -13,7 +13,6 @@
 
 namespace msa {
 namespace alignment_helper {
-int _CAL_PROFILE_TH = 1000, _UPDATE_SEQ_TH = 1000;      // msa.hpp:179-180
 
 
 static std::mutex g_mapMutex;      // plays database->mapMutex (alignment-helper.cpp:406,420)
@@ -62,7 +61,7 @@ void calculateProfile(float *profile, NodePair &nodes, SequenceDB *database, Opt
     const int P = (option->type == 'n') ? 6 : 22;
     const int refNum = nodes.first->getAlnNum(database->currentTask), qryNum = nodes.second->getAlnNum(database->currentTask);
     const int refLen = nodes.first->getAlnLen(database->currentTask), qryLen = nodes.second->getAlnLen(database->currentTask);
-    const bool storeFreq = (refNum >= _CAL_PROFILE_TH || qryNum >= _CAL_PROFILE_TH) || (!nodes.first->msaFreq.empty() || !nodes.second->msaFreq.empty());
+    const bool storeFreq = (refNum >= option->calProfileTh || qryNum >= option->calProfileTh) || (!nodes.first->msaFreq.empty() || !nodes.second->msaFreq.empty());
     profileOfSide(profile, nodes.first, database, option, P, refLen, refNum, storeFreq);
     profileOfSide(profile + (size_t)P * memLen, nodes.second, database, option, P, qryLen, qryNum, storeFreq);
 }
@@ -354,11 +353,11 @@ void updateAlignment(NodePair &nodes, SequenceDB *database, Option *, alnPath &a
     nodes.first->alnWeight += nodes.second->alnWeight;
     for (int idx : nodes.second->seqsIncluded) nodes.first->seqsIncluded.push_back(idx);
     nodes.second->seqsIncluded.clear();
-    if (nodes.first->seqsIncluded.size() > (size_t)_UPDATE_SEQ_TH && !nodes.first->msaFreq.empty() && database->currentTask != 2) {   // :479-500
+    if (nodes.first->seqsIncluded.size() > (size_t)database->updateSeqTh && !nodes.first->msaFreq.empty() && database->currentTask != 2) {   // :479-500
         int seqCount = 0, firstSeqID = 0;
         for (int idx : nodes.first->seqsIncluded)
             if (idx > 1) { if (firstSeqID == 0) firstSeqID = -idx; seqCount++; }
-        if (seqCount >= _UPDATE_SEQ_TH) {
+        if (seqCount >= database->updateSeqTh) {
             { std::lock_guard<std::mutex> lk(g_mapMutex); database->subtreeAln[firstSeqID] = alnPath(totalLen, 0); }
             std::vector<int> kept{firstSeqID};
             for (int idx : nodes.first->seqsIncluded) {

@@ -120,6 +120,9 @@ struct Option {
     bool alignGappy = true;
     std::string treeFile, seqFile, outFile;
     bool printDetail = false;    // -v
+    // msa.hpp:179-180 (_CAL_PROFILE_TH, _UPDATE_SEQ_TH): 1000 in the reference; tests lower them per RUN (--test-cal-profile-th / --test-update-seq-th: small trees
+    // then reach the cached-profile and compressed-group branches).  Per run since round 5: as process globals a handle with lowered thresholds changed every later one
+    int calProfileTh = 1000, updateSeqTh = 1000;
     bool testNoOwnership = false; // --test-no-ownership: a sharded run deals and exchanges every level (no subtree ownership below a cut)
     int testVirtualDevices = 0;  // --test-virtual-devices n: n replicas of the store on the first device (the several-replica path of the resident kernel on a one-GPU box)
     bool hostStaged = false;     // --host-staged: build profiles on the host and stage them per level (default: device-resident rows)
@@ -163,6 +166,7 @@ struct SequenceDB {
         ~SequenceInfo();
     };
     int currentTask = 0;
+    int updateSeqTh = 1000;                        // Option::updateSeqTh of the run (updateAlignment has no Option)
     std::vector<SequenceInfo *> sequences;
     std::vector<Node *> fallback_nodes;
     std::unordered_map<std::string, SequenceInfo *> name_map;
@@ -190,9 +194,6 @@ char detectType(const std::string &seqFile);
 using alnFunction = std::function<void(Tree *, NodePairVec &, SequenceDB *, Option *, Params &)>;
 
 namespace alignment_helper {
-// msa.hpp:179-180.  The two thresholds are 1000 in the reference; tests lower them (--test-cal-profile-th / --test-update-seq-th, parseCommandLine: small
-// trees then reach the cached-profile and compressed-group branches) for the product CLI, the library and the CPU checker alike.  Nothing in the environment touches them.
-extern int _CAL_PROFILE_TH, _UPDATE_SEQ_TH;
 void calculateProfile(float *profile, NodePair &nodes, SequenceDB *database, Option *option, int32_t memLen);
 void removeGappyColumns(float *hostFreq, NodePair &nodes, Option *option, std::pair<IntPairVec, IntPairVec> &gappyColumns, int32_t memLen,
                         IntPair &lens, int currentTask);

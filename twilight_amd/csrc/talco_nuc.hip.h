@@ -939,7 +939,11 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #pragma unroll
                         for (int r = 0; r < RPL; ++r) {
                             const int bb = 64 * blk[r];
+#if defined(TWL_TB_ALWAYS)      // experiment builds: every window row stores its word, as until round 4
+                            (void)bb;
+#else
                             if (((tbMust >> r) & 1u) != 0u || (bb + 63 >= tbL0 && bb <= tbU0 + 8))
+#endif
                                 *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
                             tbacc[r] = 0;
                         }
