@@ -1,7 +1,7 @@
-# Round-4 evidence under gpurun_out/prof_r04 (copied to profiles/r04 by hand): bash tools/final_profiles.sh   (GPU box)
+# Round-5 evidence under gpurun_out/prof_r05 (copied to profiles/r05 by hand): bash tools/final_profiles.sh   (GPU box)
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r04
+O=gpurun_out/prof_r05
 mkdir -p $O
 bash tools/profile_bench.sh $O/pmc --no-survey8d > $O/pmc.log 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -17,7 +17,7 @@ python bench.py --config rnasim100k --no-cpu --no-peak --no-e2e > $O/bench_line_
 python bench.py --config rnasim1k_band512 --no-e2e > $O/bench_line_rnasim1k_band512.json 2>/dev/null
 python bench.py --workload survey8d --steps 2 --warmup 1 --no-cpu --no-peak --no-e2e > $O/bench_line_survey8d.json 2>/dev/null
 TWL_BENCH_FORCE_SHARD=1 python bench.py --no-cpu --no-peak --no-e2e --no-survey8d > $O/bench_line_forced_shard_1rank_rccl.json 2> $O/shard1.err
-TWL_BENCH_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu --no-peak --no-e2e > $O/bench_line_two_ranks_one_gpu_gloo.json 2> $O/two_ranks.err
+TWL_BENCH_ONE_GPU=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu --no-peak --no-e2e > $O/bench_line_two_ranks_one_gpu_gloo.json 2> $O/two_ranks.err      # (a plain command: bench.py starts its own launcher)
 TWL_BENCH_VERBOSE=1 python bench.py --no-cpu --no-peak --no-e2e --no-survey8d --steps 1 > /dev/null 2> $O/verbose10k.err
 TWL_BENCH_VERBOSE=1 python bench.py --config rnasim100k --no-cpu --no-peak --no-e2e --steps 1 > /dev/null 2> $O/verbose100k.err
 TWL_BENCH_VERBOSE=1 python bench.py --workload survey8d --no-cpu --no-peak --no-e2e --steps 1 --warmup 0 > /dev/null 2> $O/verbose_survey8d.err
