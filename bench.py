@@ -534,9 +534,9 @@ def main():
             if isa.get("source_hash") != (lib_ver.split("src ")[-1] if lib_ver else ""):
                 isa_note = f"static counts are of kernel sources {isa.get('source_hash')}, this library is {lib_ver}"
             if dom:
-                key = next((k for k in isa["kernels"] if k in dom["kernel"] or dom["kernel"].startswith(k.split("(")[0])), None)
-                if key is None and "tile-parallel" not in dom["kernel"]:
-                    key = next(iter(isa["kernels"]))
+                key = next((k for k in sorted(isa["kernels"], key=len, reverse=True) if k in dom["kernel"]), None)
+                if key is None:
+                    isa_note = (isa_note + "; " if isa_note else "") + f"no static count for {dom['kernel']} (profiles/r05/isa_block_step.json holds the nucleotide throughput kernels): frac not formed"
                 if key:
                     # (one-letter query rows with single-sequence references have neither gap letters nor a denominator: the leaf level; everything else pays both)
                     which = "no_gap_letters_denominator_1" if ", 5, 5, false" in key else "profiles_with_gap_letters_and_division"

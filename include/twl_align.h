@@ -197,10 +197,13 @@ int twl_comm_destroy(int device);
      TWL_KNOB_FORCE_GLOBAL   1: every pair of every call runs on the global-memory kernel, the last stage of the re-run chain (bands of any width; normally only
                              reached by bands beyond 4480 rows, i.e. fLen > 4608 in a retry of the deferred pass): tests of that kernel on small cases
      TWL_KNOB_LEAF_STEP      1 (default): device-resident levels (twl_level.h) whose pairs are all single sequences on both sides run the throughput kernels' step
-                             without the gap-letter terms, the division and their per-block tests; 0: the general step (tests hold the two to each other) */
+                             without the gap-letter terms, the division and their per-block tests; 0: the general step (tests hold the two to each other)
+     TWL_KNOB_POISON_TB      1: the traceback scratch is filled with 0xFF bytes in front of every DP launch.  A block writes its traceback word only when it can have
+                             held band cells in the group of 8 diagonals; a word wrongly skipped would read as the zeros of a fresh allocation (a "match" pointer,
+                             often right) -- with the knob it reads as garbage and the parity tests see it.  tests/conftest.py sets it for every GPU test */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16, TWL_KNOB_LEAF_STEP = 17 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16, TWL_KNOB_LEAF_STEP = 17, TWL_KNOB_POISON_TB = 18 };
 int twl_set_knob(int key, int value);
 /* The launch plan of a nucleotide call in words ("throughput; mode 2; window 768; bulk 1024 tail 277"), made by the very function the launch path
    uses, without touching a device: len[n_pairs][2] as twl_align_batch, num_cu / qry_onehot / wide_streak the facts the device would supply. */

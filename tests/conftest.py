@@ -27,5 +27,8 @@ def gpu(built):
     import twilight_amd as twl
 
     twl.init([0])
+    # every DP launch of the GPU tests starts from a traceback scratch full of 0xFF bytes: a block stores its traceback word only when it can have held band cells,
+    # and a word wrongly skipped must not look like the zeros of a fresh allocation (include/twl_align.h, TWL_KNOB_POISON_TB)
+    twl.set_knob(twl.knobs.KNOB_POISON_TB, 1)
     yield twl
     twl.shutdown()

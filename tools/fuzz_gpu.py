@@ -7,6 +7,7 @@ from test_gpu_fuzz import check_case
 
 start, count = int(sys.argv[1]), int(sys.argv[2])
 twl.init([0])
+twl.set_knob(twl.knobs.KNOB_POISON_TB, 1)      # a traceback word whose store was wrongly skipped must read as garbage, not as zeros
 bad = 0
 kinds = {0: 0, 1: 0}
 for seed in range(start, start + count):

@@ -8,6 +8,7 @@ from test_gpu_mt import check_mt_case
 
 start, count = int(sys.argv[1]), int(sys.argv[2])
 twl.init([0])
+twl.set_knob(twl.knobs.KNOB_POISON_TB, 1)      # a traceback word whose store was wrongly skipped must read as garbage, not as zeros
 bad = took = errs = 0
 for seed in range(start, start + count):
     try:

@@ -145,6 +145,7 @@ KNOB_PROT_MODE, KNOB_ASSUME_ONEHOT_QUERY, KNOB_MT_TAIL_PCT, KNOB_MT_WIDE, KNOB_N
 KNOB_THR_SMALL = 15
 KNOB_FORCE_GLOBAL = 16
 KNOB_LEAF_STEP = 17
+KNOB_POISON_TB = 18
 PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 
 

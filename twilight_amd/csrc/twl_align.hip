@@ -1065,6 +1065,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_NO_SPEC: g_no_spec = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_FORCE_GLOBAL: g_force_global = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_LEAF_STEP: g_leaf_step = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_POISON_TB: g_poison_tb = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;

@@ -13,4 +13,5 @@ int g_prot_mode = 0;                 // twl_set_knob(TWL_KNOB_PROT_MODE): force 
 int g_force_global = 0;             // twl_set_knob(TWL_KNOB_FORCE_GLOBAL): every pair of every call runs on the global-memory kernel (tests of that kernel on small cases)
 int g_assume_onehot_query = 0;       // twl_set_knob(TWL_KNOB_ASSUME_ONEHOT_QUERY): the host form too takes the one-letter-query kernels
 int g_leaf_step = 1;                 // twl_set_knob(TWL_KNOB_LEAF_STEP): 0 = leaf x leaf levels too run the general step (talco_lean_kernel, SP 0; tests hold the two to each other)
+int g_poison_tb = 0;                 // twl_set_knob(TWL_KNOB_POISON_TB): the traceback scratch is filled with 0xFF bytes in front of every DP launch (tests: a word whose store was wrongly skipped then reads as garbage, not as the zeros of a fresh allocation)
 struct Knobs;

@@ -24,6 +24,7 @@ int launch_dp(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     const size_t tbw = tb_words_for<CfgT>(base.marker);
     int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
+    if (g_poison_tb) HIP_TRY(hipMemsetAsync(d->tb.p, 0xFF, tbw * sizeof(uint32_t) * (size_t)grid, st));
     twl::KArgs a = base;
     a.tb = (uint32_t *)d->tb.p;
     a.tb_words = (int32_t)tbw;
@@ -70,6 +71,7 @@ int launch_global(Device *d, hipStream_t st, const twl::KArgs &base, const int32
     grid = std::min(grid, d->num_cu);
     int rc = d->tb.ensure(words * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
+    if (g_poison_tb) HIP_TRY(hipMemsetAsync(d->tb.p, 0xFF, words * sizeof(uint32_t) * (size_t)grid, st));
     twl::GArgs g;
     g.k = base;
     g.k.tb = (uint32_t *)d->tb.p;
@@ -110,6 +112,7 @@ int launch_lean(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t
     const size_t tbw = ((size_t)(base.marker >> 3) + 1) * (size_t)CfgT::WINDOW;
     int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
+    if (g_poison_tb) HIP_TRY(hipMemsetAsync(d->tb.p, 0xFF, tbw * sizeof(uint32_t) * (size_t)grid, st));
     twl::NArgs a{};
     a.cols = base.cols; a.len = base.len; a.num = base.num; a.aln = base.aln; a.aln_len = base.aln_len; a.err = base.err;
     a.cells = base.cells; a.tb = (uint32_t *)d->tb.p; a.queue = base.queue; a.items = d_items; a.n_items = n_items;
@@ -164,6 +167,7 @@ int launch_mt_kernel(Device *d, hipStream_t st, twl::NArgs a, int n_items, int *
     if (tb_groups) grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)8 << 30) / (tbw * sizeof(uint32_t))));      // (at most 8 GB of them: fewer workgroups take the pairs in turn)
     int rc = d->tb.ensure(tbw * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
+    if (g_poison_tb) HIP_TRY(hipMemsetAsync(d->tb.p, 0xFF, tbw * sizeof(uint32_t) * (size_t)grid, st));
     a.tb = (uint32_t *)d->tb.p; a.tb_words = (int32_t)tbw; a.n_items = n_items;
     // (every launch of a tile-parallel level has its own work counter: launch_mt zeroed the 16 of them in one go)
     a.queue = (int32_t *)d->queue.p + (d->mt_launch++ % kMtCounters);
