@@ -523,8 +523,9 @@ def main():
         # A CU issues at most ~3.97 instructions per ns over its four SIMDs whatever their kind (tools/micro/issue_rates.hip, profiles/r02/issue_rates.log:
         # 16 waves of interleaved vector and scalar instructions; vector alone 3.88, scalar alone 2.27) -- measured, so no clock enters.  One 64-row block on
         # one anti-diagonal costs a wave a fixed number of instructions, counted in the disassembly (profiles/r05/isa_block_step.json + the listings next to
-        # it).  peak = the cells/s at which every issue slot of the chip would carry a block-step instruction and every lane a band cell;
-        # achieved = the dominant kernel's band cells per launch / its average launch time (HIP events of the library, live in this run);
+        # it).  peak = the cells/s at which every issue slot of the chip would carry a block-step instruction (of the dominant kernel's step) and every lane a band cell;
+        # achieved = band cells of a pass / DP-kernel time of a pass (HIP events of the library around every DP launch, live in this run; the rocprofv3 trace of the
+        # same command gives the same time: sum of the talco_* rows of profiles/r05/bench_kernel_stats.csv / passes);
         # frac = achieved / peak <= 1.  What separates them: lanes of a block outside the band (~16 %), the per-diagonal bookkeeping every wave runs
         # (~60 instructions: barrier, band update), idle issue slots while a workgroup's waves wait for each other.
         isa, isa_note, peak_cells, step_ins, ceiling = None, None, None, None, None
@@ -546,8 +547,9 @@ def main():
             isa_note = f"no static counts: {ex}"
         dom_cells_per_s = (dom["cells_per_launch"] / (dom["avg_ms"] * 1e-3)) if dom and dom["avg_ms"] > 0 else None
         out["roofline"] = {
-            "bound": "issue", "achieved": dom_cells_per_s, "peak": peak_cells, "unit": "cells/s",
-            "frac": (dom_cells_per_s / peak_cells) if (dom_cells_per_s and peak_cells) else None,
+            "bound": "issue", "achieved": (cells / (kernel_ms * 1e-3)) if kernel_ms > 0 else None, "peak": peak_cells, "unit": "cells/s",
+            "frac": (cells / (kernel_ms * 1e-3) / peak_cells) if (kernel_ms > 0 and peak_cells) else None,
+            "frac_levels_of_dominant_kernel": (dom_cells_per_s / peak_cells) if (dom_cells_per_s and peak_cells) else None,
             "issue_ceiling_instr_per_s": ceiling, "instructions_per_block_step": step_ins, "cells_per_block_step": 64, "static_counts": "profiles/r05/isa_block_step.json",
             "static_counts_note": isa_note,
             "contract_bound": "hbm", "contract_achieved_gb_s": achieved, "contract_peak_gb_s": HBM_PEAK_GBS, "contract_frac": achieved / HBM_PEAK_GBS,
@@ -561,8 +563,9 @@ def main():
             "issue": issue,
             "algorithmic_bytes_per_cell": bcell, "cells": int(cells // steps), "kernel_ms": kernel_ms / steps,
             "dominant_kernel": dom, "kernels": kernels,
-            "note": "what binds this path is instruction issue along the anti-diagonal chain, so `frac` is measured against the chip's instruction-issue ceiling: band cells/s of the "
-                    "dominant kernel / (256 CUs x 3.97e9 instructions/s x 64 cells / instructions of a block step).  `contract_frac` keeps the figure of BASELINE.md section 3 -- band "
+            "note": "what binds this path is instruction issue along the anti-diagonal chain, so `frac` is measured against the chip's instruction-issue ceiling: band cells of a pass / "
+                    "DP-kernel time of a pass / (256 CUs x 3.97e9 instructions/s x 64 cells / instructions of the dominant kernel's block step); `frac_levels_of_dominant_kernel` = "
+                    "the same for the levels that start on the dominant kernel alone.  `contract_frac` keeps the figure of BASELINE.md section 3 -- band "
                     "cells x 64 (192) operand bytes / DP-kernel time over ALL launches of a pass against 8 TB/s; that operand stream is notional (columns are reused from LDS / registers), "
                     "so it exceeds 1 and measures nothing.  Real HBM traffic (`traffic`, counters) is ~1.1 B per cell, most of it traceback words; compulsory 0.07 B per cell.  "
                     "`issue` = the counters of the profiled run per kernel.  DESIGN.md section 3",

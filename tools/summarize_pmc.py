@@ -77,6 +77,38 @@ if "pass1" in out and dur:
             e["hbm_gb_per_s"] = (2 * p3[name]["sum"].get("FETCH_SIZE", 0.0) + p4[name]["sum"].get("WRITE_SIZE", 0.0)) * 1024 / t / 1e9
         issue[name] = e
     out["issue_per_kernel"] = issue
+# ---- the dominant kernel in ONE place: launches and average duration from the kernel trace of this command, band cells per launch from the
+# bench line of the same command, instructions of a block step from the disassembly -> the issue-ceiling fraction, recomputable from these few numbers ----
+try:
+    isa = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05", "isa_block_step.json")))
+    dk = (bench or {}).get("roofline", {}).get("dominant_kernel")
+    if dk and ks:
+        # (the profiler spells a defaulted last template argument out: "..., false, 0>" of the library is "..., false, 0, 0>" in the trace)
+        names = (dk["kernel"] + "(", dk["kernel"][:-1] + ", 0>(")
+        rows = [r for r in csv.DictReader(open(ks[0])) if any(nm in r["Name"] for nm in names)]
+        key = next((k for k in sorted(isa["kernels"], key=len, reverse=True) if k in dk["kernel"]), None)
+        if rows and key:
+            allrows = [r for r in csv.DictReader(open(ks[0])) if "talco_" in r["Name"]]
+            dp_s_per_pass = sum(float(r["TotalDurationNs"]) for r in allrows) * 1e-9 / passes
+            cells_per_pass = bench["roofline"]["cells"]
+            avg_ns = sum(float(r["TotalDurationNs"]) for r in rows) / max(1, sum(int(r["Calls"]) for r in rows))
+            step = isa["kernels"][key]["block_step"]["no_gap_letters_denominator_1" if ", 5, 5, false" in key else "profiles_with_gap_letters_and_division"]
+            peak = isa["issue_ceiling"]["cus"] * isa["issue_ceiling"]["instr_per_ns_per_cu"] * 1e9 * 64.0 / step
+            out["dominant_kernel"] = {"kernel": dk["kernel"], "calls_in_trace": sum(int(r["Calls"]) for r in rows), "avg_ns_in_trace": avg_ns,
+                                      "instructions_per_block_step": step, "cells_per_block_step": 64,
+                                      "issue_ceiling_instr_per_ns_per_cu": isa["issue_ceiling"]["instr_per_ns_per_cu"], "cus": isa["issue_ceiling"]["cus"],
+                                      "peak_cells_per_s": peak,
+                                      # what bench.py calls a launch of this kernel is a LEVEL that starts on it (its remainder runs as tile jobs of the same family):
+                                      "bench_level_cells_per_launch": dk["cells_per_launch"], "bench_level_dp_ms_per_launch": dk["avg_ms"],
+                                      "frac_levels_of_this_kernel": dk["cells_per_launch"] / (dk["avg_ms"] * 1e-3) / peak,
+                                      # the whole pass, from the trace alone: every talco_* launch of the command / passes of the family in it
+                                      "trace_dp_kernel_s_per_pass": dp_s_per_pass, "bench_dp_kernel_s_per_pass": bench["roofline"]["kernel_ms"] * 1e-3,
+                                      "band_cells_per_pass": cells_per_pass,
+                                      "frac_whole_pass": cells_per_pass / dp_s_per_pass / peak,
+                                      "note": "frac_whole_pass = band_cells_per_pass / (sum of TotalDurationNs of the talco_* rows of bench_kernel_stats.csv / passes in that command) / "
+                                              "(cus x ceiling x 1e9 x 64 / instructions_per_block_step); the leaf level's step is shorter (101 instructions), so a pass-weighted peak would be higher"}
+except Exception as ex:  # noqa: BLE001
+    out["dominant_kernel"] = {"note": f"not formed: {ex}"}
 try:      # which code these counters belong to: the hash of the kernel sources the profiled library was built from (twl_version carries the same)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import __graft_entry__ as _g
