@@ -148,3 +148,49 @@ def test_bench_with_gpus_2_as_a_plain_command(built, tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert "n_ranks_seen_by_rccl" in line and line["n_ranks_seen_by_rccl"] is None      # (gloo carried this run's exchange)
     assert line["config"]["msa_md5"]
+
+
+def _two_devices():
+    import torch
+
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("no_ownership", [False, True])
+def test_cli_on_two_gpus_writes_the_single_gpu_msa(built, tmp_path, no_ownership):
+    """twilight-mi355x --gpu-index 0,1: one forked process per GPU, the library's own RCCL communicator (twl_comm_*), subtree ownership below the cut and one all-gather per
+    level above it.  Needs a box with two devices (the multi-rank RCCL path had no hardware test); skipped on the one-GPU pool."""
+    if not _two_devices():
+        pytest.skip("needs two GPUs")
+    name = "nuc_deferrals_cache_compress"
+    _, fam, ins, flags, env = [v for v in VARIANTS if v[0] == name][0]
+    d = str(tmp_path)
+    t, f, typ = write_family(d, fam, ins)
+    out = os.path.join(d, "two.aln")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import subprocess
+
+    r = subprocess.run([os.path.join(root, "twilight_amd", "twilight-mi355x"), "-t", t, "-i", f, "-o", out, "--type", typ, "--gpu-index", "0,1"] + list(flags) +
+                       (["--test-no-ownership"] if no_ownership else []), capture_output=True, text=True, env=dict(os.environ, **env), timeout=800)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == FIX[name]["md5"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_on_two_gpus_reports_two_ranks_in_the_communicator(built, tmp_path):
+    if not _two_devices():
+        pytest.skip("needs two GPUs")
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, TWL_BENCH_DIR=str(tmp_path / "fam"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TWL_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--leaves", "600", "--length", "1500",
+                        "--no-cpu", "--no-peak", "--no-e2e", "--no-survey8d"], capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen_by_rccl"] == 2 and line["config"]["msa_md5"]
