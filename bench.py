@@ -339,6 +339,8 @@ def main():
         twl.set_knob(twl.knobs.KNOB_MT_TAIL_PCT, int(os.environ["TWL_BENCH_MT_TAIL_PCT"]))
     if os.environ.get("TWL_BENCH_THR_SMALL"):            # development: the 512-row throughput window never (1) / on every throughput level (2)
         twl.set_knob(twl.knobs.KNOB_THR_SMALL, int(os.environ["TWL_BENCH_THR_SMALL"]))
+    if os.environ.get("TWL_BENCH_MT_LEAD"):              # development: anti-diagonals a scout starts ahead of its tile boundary (default 320)
+        twl.set_knob(twl.knobs.KNOB_MT_LEAD, int(os.environ["TWL_BENCH_MT_LEAD"]))
     if os.environ.get("TWL_BENCH_LEAF_STEP"):            # development: 0 = leaf x leaf levels on the general step
         twl.set_knob(twl.knobs.KNOB_LEAF_STEP, int(os.environ["TWL_BENCH_LEAF_STEP"]))
     if os.environ.get("TWL_BENCH_SCOUT_XDROP_PCT"):      # development: what a narrower band of the pair scouts costs and saves
