@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
             // ---- the wave's rows: sub-block r = rows 128 (R2 sblk + r) + 2 lane + {0, 1}, every per-row quantity a packed pair {even row, odd row} ----
             unsigned S1[R2], I1[R2], D1[R2], LS2[R2];
             unsigned CS1[R2], CI1[R2], CD1[R2], LCS2[R2];
-            unsigned TA[R2], TB[R2];                  // score bytes of the two rows against reference letter A, C, G, T (+ bias)
+            unsigned TabE[R2], TabO[R2];                  // score bytes of the two rows against reference letter A, C, G, T (+ bias)
             unsigned pOut[R2], pLeftOut[R2];          // last diagonal's masks (0xFFFF = NOT): row in band(k-1); row i-1 in band(k-1)
             uint32_t tbA[R2], tbB[R2];
             int sblk;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                         for (int l = 0; l < 4; ++l) t |= (unsigned)((int)a.M[5 * l + m] + bias) << (8 * l);
                         tab[h] = t;
                     }
-                    TA[r] = tab[0]; TB[r] = tab[1];
+                    TabE[r] = tab[0]; TabO[r] = tab[1];
                     guardBad = guardBad | (__builtin_amdgcn_ballot_w64(bad) != 0ull);
                 }
             };
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
 
             // ---- Tile, TALCO-XDrop.cpp:233-689 ----
             int Lk = 0, Uk = 0, sLo1 = 0x3fffffff, sLo2p = 0x3fffffff;      // bands: k; k-1 as (low, width-1); k-2 as (low + 1, width-1); empty = unreachable low
-            int sW1 = -1, sW2 = -1;
+            int sW1 = 0, sW2 = 0;                        // (an empty band: unreachable low, width-1 = 0: no row matches)
             int vwid1 = 0;                               // width of diagonal k-1 (0 when empty): the stale CD slot
             unsigned vcells = 0;
             int msp = NEG, convS = 0;                    // running maximum (:259), score at convergence (:594)
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
             const unsigned mbRel = (lane == 63) ? O_EXCH + 16u * (unsigned)w : relTrash;
             const unsigned exRel = O_EXCH + 16u * (unsigned)((w + W - 1) % W);
             int tbL0 = 0, tbU0 = 0;                      // (traceback words only where the band was: see talco_lean_kernel)
-            bool tbMust = false;
+            int tbMust = 0;
 
             // 0xFFFF in a half whose row lies OUTSIDE [lo, hi]
             auto out_mask = [&](int r, int lo, int hi, int shift) __attribute__((always_inline)) {
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                 // the super block takes part when the band touches it or will reach its first row on the next diagonal: Lk - (SBR - 1) <= b <= Uk + 1
                 if ((unsigned)(b - (Lk - (SBR - 1))) <= (unsigned)(width1 + SBR)) {
                     TWL_SETPRIO(2);
-                    const uint4 e = lds_ld<uint4>(vprev + exRel);      // lane 63 of the wave below: its packed {S, I, CS, CI}
-                    unsigned belowS = e.x, belowI = e.y, belowCS = e.z, belowCI = e.w;
+                    const nuc_i4 e = lds_ld<nuc_i4>(vprev + exRel);      // lane 63 of the wave below: its packed {S, I, CS, CI}
+                    unsigned belowS = (unsigned)e.x, belowI = (unsigned)e.y, belowCS = (unsigned)e.z, belowCI = (unsigned)e.w;
                     unsigned belowOut = ((unsigned)(b - 1 - sLo1) <= (unsigned)sW1) ? 0u : 0xFFFF0000u;      // row b-1 in band(k-1)?  (its mask, as the upper half of a lane below)
 #pragma unroll
                     for (int r = 0; r < R2; ++r) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                             const unsigned aSel = raB - (unsigned)(128 * 4 * r) + ((raB < lds_off(s_sel) + (unsigned)(128 * 4 * r)) ? (unsigned)(CAP * 4) : 0u);
                             const unsigned wOdd = lds_ld<unsigned>(aSel), wEven = lds_ld<unsigned>(aSel + 4u);
                             const unsigned sel = bfi(0x0000FFFFu, wEven, wOdd);
-                            const unsigned sim = pk_sub(__builtin_amdgcn_perm(TB[r], TA[r], sel), BIAS2);
+                            const unsigned sim = pk_sub(__builtin_amdgcn_perm(TabO[r], TabE[r], sel), BIAS2);
                             // ---- recurrence, :445-497 ----
                             unsigned match = bfi(diagOut, NEG2, pk_add(LS2[r], sim));
                             if (__builtin_expect(special, 0)) {
@@ -334,11 +334,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                                 const unsigned long long gm = __builtin_amdgcn_ballot_w64(smax > msp);
                                 if (gm != 0ull) ds_max_i32_off<O_RED>(__builtin_amdgcn_inverse_ballot_w64(gm) ? vcur : vTrashRed, smax);
                             }
-                            const unsigned long long vmE = __builtin_amdgcn_ballot_w64((dead & 0x0000FFFFu) == 0u), vmO = __builtin_amdgcn_ballot_w64((int)~dead < 0);
-                            if ((vmE | vmO) != 0ull) {
-                                const int fE = vmE ? 2 * (int)__builtin_ctzll(vmE) : 0x7fffffff, fO = vmO ? 2 * (int)__builtin_ctzll(vmO) + 1 : 0x7fffffff;
-                                const int lE = vmE ? 2 * (63 - (int)__builtin_clzll(vmE)) : -1, lO = vmO ? 2 * (63 - (int)__builtin_clzll(vmO)) + 1 : -1;
-                                const int first = min(fE, fO), last = max(lE, lO);
+                            // first / last unpruned row of the sub-block: the end lanes of "some half alive", then which half of each
+                            const unsigned long long vmAny = __builtin_amdgcn_ballot_w64(dead != 0xFFFFFFFFu);
+                            if (vmAny != 0ull) {
+                                const int fl = (int)__builtin_ctzll(vmAny), ll = 63 - (int)__builtin_clzll(vmAny);
+                                const unsigned dF = (unsigned)__builtin_amdgcn_readlane((int)dead, fl), dL = (unsigned)__builtin_amdgcn_readlane((int)dead, ll);
+                                const int first = 2 * fl + (((dF & 0xFFFFu) == 0u) ? 0 : 1), last = 2 * ll + (((dL >> 16) == 0u) ? 1 : 0);
                                 sLowC = min(sLowC, b128 + first); sHighC = max(sHighC, b128 + last);
                                 if constexpr (PH == 2) {       // pointer words of the sub-block's first / last unpruned row, for the pre-test of the convergence test
                                     const unsigned cf = (unsigned)__builtin_amdgcn_readlane((int)CS1[r], first >> 1), cl = (unsigned)__builtin_amdgcn_readlane((int)CS1[r], last >> 1);
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                     }
                     fresh = 0;
                     // mailbox: lane 63 of the last sub-block (its odd row is row i - 1 of the next wave's first row)
-                    lds_st<uint4>(vcur + mbRel, uint4{S1[R2 - 1], I1[R2 - 1], CS1[R2 - 1], CI1[R2 - 1]});
+                    lds_st<nuc_i4>(vcur + mbRel, nuc_i4{(int)S1[R2 - 1], (int)I1[R2 - 1], (int)CS1[R2 - 1], (int)CI1[R2 - 1]});
                 } else {
 #pragma unroll
                     for (int r = 0; r < R2; ++r) { pOut[r] = 0xFFFFFFFFu; pLeftOut[r] = 0xFFFFFFFFu; }
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                     while (SBR * sblk + SBR - 1 < Lk) sblk += W;
                     sel_addr(k);
                     load_q();
-                    fresh = 1; tbMust = true;
+                    fresh = 1; tbMust = 1;
                 }
                 raB += 4u;
                 if (raB == lds_off(s_sel) + CAP * 4u) raB = lds_off(s_sel);
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                 if (hook) {
                     if constexpr (TB) {
                         const int bb = SBR * sblk;
-                        const bool live = tbMust || (bb + SBR - 1 >= tbL0 && bb <= tbU0 + 8);
+                        const bool live = tbMust != 0 || (bb + SBR - 1 >= tbL0 && bb <= tbU0 + 8);
 #pragma unroll
                         for (int r = 0; r < R2; ++r) {
                             if (live) {
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                             }
                             tbA[r] = tbB[r] = 0u;
                         }
-                        tbMust = false; tbL0 = Lk; tbU0 = Uk;
+                        tbMust = 0; tbL0 = Lk; tbU0 = Uk;
                         tbOff += (unsigned)WINDOW * 4u;
                         tbPending = false;
                     }
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_i16_kernel(NArgs a)
                         else if (Uk / SBR - Lk / SBR >= W) { tile_err = kErrOverflow; go_on = false; }      // it really outgrew this window
                         else if (SBR * sblk + SBR - 1 < Lk) {
                             while (SBR * sblk + SBR - 1 < Lk) sblk += W;
-                            sel_addr(k); load_q(); fresh = 1; tbMust = true;
+                            sel_addr(k); load_q(); fresh = 1; tbMust = 1;
                         }
                     }
                 }
