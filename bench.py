@@ -341,6 +341,10 @@ def main():
         twl.set_knob(twl.knobs.KNOB_THR_SMALL, int(os.environ["TWL_BENCH_THR_SMALL"]))
     if os.environ.get("TWL_BENCH_MT_LEAD"):              # development: anti-diagonals a scout starts ahead of its tile boundary (default 320)
         twl.set_knob(twl.knobs.KNOB_MT_LEAD, int(os.environ["TWL_BENCH_MT_LEAD"]))
+    if os.environ.get("TWL_BENCH_MT_ANCHOR"):            # development: 0 = every scout from the straight line with the long lead
+        twl.set_knob(twl.knobs.KNOB_MT_ANCHOR, int(os.environ["TWL_BENCH_MT_ANCHOR"]))
+    if os.environ.get("TWL_BENCH_MT_LEAD2"):             # development: the lead of an anchored scout (default 96)
+        twl.set_knob(twl.knobs.KNOB_MT_LEAD2, int(os.environ["TWL_BENCH_MT_LEAD2"]))
     if os.environ.get("TWL_BENCH_LEAF_STEP"):            # development: 0 = leaf x leaf levels on the general step
         twl.set_knob(twl.knobs.KNOB_LEAF_STEP, int(os.environ["TWL_BENCH_LEAF_STEP"]))
     if os.environ.get("TWL_BENCH_SCOUT_XDROP_PCT"):      # development: what a narrower band of the pair scouts costs and saves

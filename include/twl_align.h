@@ -200,10 +200,14 @@ int twl_comm_destroy(int device);
                              without the gap-letter terms, the division and their per-block tests; 0: the general step (tests hold the two to each other)
      TWL_KNOB_POISON_TB      1: the traceback scratch is filled with 0xFF bytes in front of every DP launch.  A block writes its traceback word only when it can have
                              held band cells in the group of 8 diagonals; a word wrongly skipped would read as the zeros of a fresh allocation (a "match" pointer,
-                             often right) -- with the knob it reads as garbage and the parity tests see it.  tests/conftest.py sets it for every GPU test */
+                             often right) -- with the knob it reads as garbage and the parity tests see it.  tests/conftest.py sets it for every GPU test
+     TWL_KNOB_MT_ANCHOR      1 (default): the nucleotide scouts of the tile-parallel path start from the cell on which the consensus letters of the two profiles agree
+                             (one small kernel per level finds it for every tile boundary), TWL_KNOB_MT_LEAD2 (default 96) anti-diagonals ahead of the boundary, where
+                             that cell is trusted; elsewhere, and with 0 everywhere, from the straight line between the corners TWL_KNOB_MT_LEAD ahead.  Predictions
+                             only: the results are the same either way (tests hold the two to each other) */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16, TWL_KNOB_LEAF_STEP = 17, TWL_KNOB_POISON_TB = 18 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16, TWL_KNOB_LEAF_STEP = 17, TWL_KNOB_POISON_TB = 18, TWL_KNOB_MT_ANCHOR = 19, TWL_KNOB_MT_LEAD2 = 20 };
 int twl_set_knob(int key, int value);
 /* The launch plan of a nucleotide call in words ("throughput; mode 2; window 768; bulk 1024 tail 277"), made by the very function the launch path
    uses, without touching a device: len[n_pairs][2] as twl_align_batch, num_cu / qry_onehot / wide_streak the facts the device would supply. */

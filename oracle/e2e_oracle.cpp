@@ -54,7 +54,8 @@ void alignmentKernel_CPU(msa::Tree *, msa::NodePairVec &nodes, msa::SequenceDB *
         if (database->currentTask == 1 || database->currentTask == 2 || in.refNum > 10000 || in.qryNum > 10000) tp.gap_char = 0;   // :88
         if (const char *dumpDir = getenv("TWLO_DUMP_PAIRS")) {      // study aid: the DP inputs of the pairs of small levels, one file per pair
             const char *mx = getenv("TWLO_DUMP_MAX_PAIRS");
-            if (n <= (mx ? atoi(mx) : 64) && in.lens.first > 0 && in.lens.second > 0 && !in.lowQ_r && !in.lowQ_q) {
+            const char *every = getenv("TWLO_DUMP_EVERY");      // ... of larger levels every n-th pair only
+            if (n <= (mx ? atoi(mx) : 64) && (!every || i % std::max(1, atoi(every)) == 0) && in.lens.first > 0 && in.lens.second > 0 && !in.lowQ_r && !in.lowQ_q) {
                 char path[512];
                 snprintf(path, sizeof path, "%s/L%03zu_p%04d.bin", dumpDir, g_pairsPerLevel.size() + 1, i);
                 if (FILE *f = fopen(path, "wb")) {

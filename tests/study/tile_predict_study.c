@@ -70,6 +70,9 @@ int main(int argc, char **argv)
        diagonal offset on which the consensus letters of the two profiles agree most often (argument 6: window half-width, 0 = off) ---- */
     const int seedW = argc > 6 ? atoi(argv[6]) : 0;
     const int seedOff = argc > 7 ? atoi(argv[7]) : 256;
+    const int fbLead = argc > 8 ? atoi(argv[8]) : 0;        /* an anchor that is not trusted: the straight line with this lead (0 = always trust) */
+    const int minPct = argc > 9 ? atoi(argv[9]) : 60;       /* trusted: matches >= minPct % of the window and the runner-up (not a neighbour offset) at least gapPct % of the window behind */
+    const int gapPct = argc > 10 ? atoi(argv[10]) : 15;
     if (argc > 6) {
         unsigned char *cr = malloc(R), *cq = malloc(Q);
         for (int side = 0; side < 2; ++side) {
@@ -80,13 +83,17 @@ int main(int argc, char **argv)
                 cc[i] = (bc > 0.0f && bc >= pf[(size_t)P * i + P - 1]) ? (unsigned char)best : (unsigned char)(100 + side);   /* gap-dominated / empty: matches nothing */
             }
         }
-        int shits = 0, stot = 0, maxd = 0; long sumd = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : shits, stot, sumd) reduction(max : maxd)
+        /* pass 1: the anchor of every boundary (offset of q - r with the most agreeing consensus letters) and whether it is trusted;
+           pass 2: an untrusted one takes the interpolation of its trusted neighbours (the path's drift from the straight line is smooth:
+           a few rows per tile) when they are near, else the straight line with the long lead; pass 3: the scouts */
+        const int interp = argc > 11 ? atoi(argv[11]) : 0;      /* 0 = no interpolation; n = neighbours up to n boundaries away */
+        int *aO = calloc(nt + 1, sizeof(int)), *aOk = calloc(nt + 1, sizeof(int)), *aLead = calloc(nt + 1, sizeof(int));
+#pragma omp parallel for schedule(dynamic, 1)
         for (int t = 1; t < nt; ++t) {
             const int dT = starts[t].r + starts[t].q;
             int d0 = dT - lead; if (d0 < 2) d0 = 2;
-            int q0 = (int)((long long)d0 * Q / (R + Q)), r0 = d0 - q0;
-            int bestO = 0, bestC = -1;
+            const int q0 = (int)((long long)d0 * Q / (R + Q)), r0 = d0 - q0;
+            int bestO = 0, bestC = -1, secondC = -1;
             if (seedW > 0) {
                 for (int oo = 0; oo < 2 * seedOff; ++oo) {
                     const int o = (oo & 1) ? -((oo + 1) / 2) : oo / 2;       /* 0, -1, 1, -2, 2, ...: ties go to the smallest |o| */
@@ -97,7 +104,41 @@ int main(int argc, char **argv)
                     }
                     if (c > bestC) { bestC = c; bestO = o; }
                 }
+                for (int o = -seedOff; o < seedOff; ++o) {
+                    if (abs(o - bestO) <= 2) continue;
+                    int c = 0;
+                    for (int i = -seedW; i < seedW; ++i) {
+                        const int rr = r0 + i, qq2 = q0 + i + o;
+                        if (rr >= 0 && rr < R && qq2 >= 0 && qq2 < Q && cr[rr] == cq[qq2]) ++c;
+                    }
+                    if (c > secondC) secondC = c;
+                }
             }
+            aO[t] = bestO;
+            aOk[t] = !(fbLead > 0 && (bestC * 100 < minPct * 2 * seedW || (bestC - secondC) * 100 < gapPct * 2 * seedW));
+        }
+        int nint = 0;
+        for (int t = 1; t < nt; ++t) {
+            aLead[t] = lead;
+            if (aOk[t]) continue;
+            int l = -1, r = -1;
+            for (int u = t - 1; u >= 1 && t - u <= interp; --u) if (aOk[u] == 1) { l = u; break; }
+            for (int u = t + 1; u < nt && u - t <= interp; ++u) if (aOk[u] == 1) { r = u; break; }
+            const int maxJump = argc > 12 ? atoi(argv[12]) : 1000;      /* neighbours whose offsets differ by more than this per boundary say nothing about what lies between */
+            if (l > 0 && r > 0 && abs(aO[r] - aO[l]) <= maxJump * (r - l)) { aO[t] = aO[l] + (aO[r] - aO[l]) * (t - l) / (r - l); aOk[t] = 2; nint++; }
+            else if (l > 0 && r > 0) { aO[t] = 0; aLead[t] = fbLead; }
+            else { aO[t] = 0; aLead[t] = fbLead; }
+        }
+        if (getenv("TPS_VERBOSE")) for (int t = 1; t < nt; ++t) { const int dd = starts[t].r + starts[t].q - lead; int tq0 = pathq[dd]; if (tq0 < 0) tq0 = pathq[dd - 1]; printf("    t %d kind %d offset %d (true %d)\n", t, aOk[t], aO[t], 2 * (tq0 - (int)((long long)dd * Q / (R + Q)))); }
+        int shits = 0, stot = 0, maxd = 0, nfb = 0; long sumd = 0, sdiag = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : shits, stot, sumd, nfb, sdiag) reduction(max : maxd)
+        for (int t = 1; t < nt; ++t) {
+            const int dT = starts[t].r + starts[t].q;
+            int d0 = dT - aLead[t]; if (d0 < 2) d0 = 2;
+            const int q0 = (int)((long long)d0 * Q / (R + Q));
+            const int bestO = aO[t];
+            if (!aOk[t]) nfb++;
+            sdiag += dT - d0 + marg;
             /* keep the anti-diagonal: q - r changes by bestO (rounded to even) */
             int gq = q0 + (bestO >= 0 ? (bestO + 1) / 2 : -((-bestO + 1) / 2)) , gr = d0 - gq;
             if (gq < 0) { gq = 0; gr = d0; } if (gr < 0) { gr = 0; gq = d0; }
@@ -110,17 +151,21 @@ int main(int argc, char **argv)
             int32_t sr = gr, sq = gq; int sl = 0; int16_t se = 0; bytes_t sg = {0, 0, 0};
             tile_run(&sc, &sr, &sq, &sg, &sl, g_stop_at_marker ? 7777 : 1, &se);
             stot++;
+            int hit = 0;
             if (sg.n) {
                 int r = gr, q = gq;
                 for (long i = (long)sg.n - 2; i >= 0; --i) {
                     if (sg.d[i] == 0) { r++; q++; } else if (sg.d[i] == 1) q++; else r++;
-                    if (r == starts[t].r && q == starts[t].q) { shits++; break; }
+                    if (r == starts[t].r && q == starts[t].q) { hit = 1; break; }
                     if (r + q > dT) break;
                 }
             }
+            shits += hit;
+            if (!hit && getenv("TPS_VERBOSE")) printf("    miss t %d kind %d offset %d dev %d rows lead %d\n", t, aOk[t], bestO, dev, aLead[t]);
             free(sg.d);
         }
-        printf("  seeded (window +-%d, offsets +-%d): %d / %d hit; rough start off the path by avg %.1f max %d rows\n", seedW, seedOff, shits, stot, stot ? (double)sumd / stot : 0.0, maxd);
+        printf("  interpolated %d;", nint);
+        printf("  seeded (window +-%d, offsets +-%d): %d / %d hit; rough start off the path by avg %.1f max %d rows; %d on the fallback lead; %ld scout diagonals\n", seedW, seedOff, shits, stot, stot ? (double)sumd / stot : 0.0, maxd, nfb, sdiag);
         return 0;
     }
     const int deltas[] = {0, 8, -8, 40, -40, 120, -120, 250, -250};

@@ -27,6 +27,8 @@ def knobs(gpu):
     gpu.set_knob(api.KNOB_MT_THR_JOBS, 256)
     gpu.set_knob(api.KNOB_MT_WIDE, 1)
     gpu.set_knob(api.KNOB_THR_SMALL, 0)
+    gpu.set_knob(api.KNOB_MT_ANCHOR, 1)
+    gpu.set_knob(api.KNOB_MT_LEAD2, 96)
 
 
 def _compare(twl, batch, **pk):
@@ -92,6 +94,31 @@ def test_short_lead_and_margin(knobs):
     batch = synth.make_level_batch(4, 5000, members=((2, 6), (2, 6)), seed=44, indel=0.02)
     st, ost = _compare(knobs, batch)
     assert st.speculative == 3
+
+
+@pytest.mark.parametrize("thr_jobs", [256, 0])
+def test_anchored_scouts_find_the_starts_a_late_straight_line_scout_cannot(knobs, thr_jobs):
+    """The scouts start from the cell on which the consensus letters of the two profiles agree (mt_anchor_kernel), a short lead ahead.  With the
+    LONG lead cut to 16 diagonals a scout that starts on the straight line is too late to run into the path; the anchored ones still predict
+    most tiles.  Predictions only: the results are the oracle's either way."""
+    knobs.set_knob(api.KNOB_MT_LEAD, 16)
+    knobs.set_knob(api.KNOB_MT_THR_JOBS, thr_jobs)
+    batch = synth.make_level_batch(6, 8000, members=((2, 8), (2, 8)), seed=77, indel=0.01)
+    knobs.set_knob(api.KNOB_MT_ANCHOR, 0)
+    plain, ost = _compare(knobs, batch)
+    knobs.set_knob(api.KNOB_MT_ANCHOR, 1)
+    anchored, _ = _compare(knobs, batch)
+    assert anchored.mt_tiles_predicted + anchored.mt_tiles_inline == ost.tiles
+    assert anchored.mt_tiles_predicted >= 0.7 * ost.tiles, (anchored.mt_tiles_predicted, ost.tiles)
+    assert anchored.mt_tiles_predicted > plain.mt_tiles_predicted + ost.tiles // 4, (anchored.mt_tiles_predicted, plain.mt_tiles_predicted, ost.tiles)
+
+
+@pytest.mark.parametrize("lead2", [16, 48, 200])
+def test_anchored_scouts_with_other_leads_and_leaf_pairs(knobs, lead2):
+    """Leaf x leaf pairs (one-letter columns) and profiles, anchored scouts 16 / 48 / 200 diagonals ahead: whatever they predict, the oracle's paths."""
+    knobs.set_knob(api.KNOB_MT_LEAD2, lead2)
+    _compare(knobs, synth.make_level_batch(5, 6000, members=(1, 1), seed=78 + lead2, indel=0.01))
+    _compare(knobs, synth.make_level_batch(5, 6000, members=((1, 30), (1, 30)), seed=79 + lead2, indel=0.02, gap_col_rate=0.1))
 
 
 def test_error_types_through_the_tile_parallel_path(knobs):

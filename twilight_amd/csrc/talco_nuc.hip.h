@@ -70,6 +70,8 @@ struct NArgs {
     unsigned long long *mt_stat;   // [4] {tiles taken from the records, tiles run in line, scouts that failed, -}
     int32_t *mt_front;        // [row][8] how far the stitch launches have come: {0 untouched / 1 suspended at a tile without a record / 2 done, tile, ref_idx, qry_idx, pos, -, cells lo, cells hi}
     int32_t mt_slots, mt_segcap, mt_sp_pitch, mt_lead, mt_marg;
+    const int32_t *mt_anchor; // [row][mt_slots] scouts (nucleotide): 128 + the offset of q - r at which the consensus letters of the two profiles agree, trusted; < 0: none (nullptr: no anchors at all)
+    int32_t mt_lead2;         // anti-diagonals an anchored scout starts ahead of its tile boundary
     int32_t mt_inline;        // MT 3: 1 = a tile without a matching record is computed in line (last round); 0 = the pair is suspended there
 };
 
@@ -241,6 +243,101 @@ __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_
     for (; t < slots; ++t) { ch[2 * t] = -1; ch[2 * t + 1] = -1; }
 }
 
+// ---- anchored scouts (round 5) ----
+// A scout needs its long lead (320 anti-diagonals) because the straight line between the corners is up to ~55 rows off the path on the families
+// measured: the band has to open that far before the scout can run into the path.  Where the path IS can be read off the profiles before any DP: around
+// the cell of the straight line the consensus letters of the two profiles agree on one diagonal offset and on no other (tests/study/tile_predict_study.c:
+// +-32 columns, offsets -128..127).  mt_anchor_kernel finds that offset for every tile boundary; a scout whose anchor is trusted -- or lies between two
+// trusted ones that agree (the path drifts by a few rows per tile; an offset that jumps is a long indel and says nothing about its neighbours) -- starts
+// from the anchored cell only mt_lead2 (96) anti-diagonals ahead.  On the top 52 pairs of 10 000 x 10 kbp: 82 % of the scouts anchored, the same 1039 of
+// 1040 true starts found, 51 % fewer scout diagonals.  Predictions only: a wrong anchor costs what any wrong prediction costs.
+constexpr int kAnchorHalf = 32, kAnchorOffsets = 256, kAnchorNear = 3, kAnchorJump = 12;
+constexpr int kAnchorMinMatches = 36, kAnchorMinGap = 8;      // trusted: >= 55 % of the 64 columns agree and the best other offset (not a neighbour) is >= 12 % behind
+
+// the cell of anti-diagonal d0 on the straight line between the corners (false: none)
+__device__ __forceinline__ bool scout_line_cell(int d0, int R, int Q, int &r, int &q)
+{
+    q = (int)(((long long)d0 * Q) / (R + Q));
+    q = min(q, Q - 1);
+    r = d0 - q;
+    if (r > R - 1) { r = R - 1; q = d0 - r; }
+    return !(q > Q - 1 || r < 0);
+}
+// the anchor of boundary `slot` of a pair from the table of its row: its own when trusted, else between two trusted neighbours that agree
+__device__ __forceinline__ bool scout_anchor(const int32_t *an, int slot, int slots, int &o)
+{
+    const int w = __builtin_amdgcn_readfirstlane(an[slot]);
+    if (w >= 0) { o = w - 128; return true; }
+    int l = -1, r = -1, ol = 0, orr = 0;
+    for (int u = 1; u <= kAnchorNear; ++u) {
+        if (l < 0 && slot - u >= 1) { const int v = __builtin_amdgcn_readfirstlane(an[slot - u]); if (v >= 0) { l = slot - u; ol = v - 128; } }
+        if (r < 0 && slot + u < slots) { const int v = __builtin_amdgcn_readfirstlane(an[slot + u]); if (v >= 0) { r = slot + u; orr = v - 128; } }
+    }
+    if (l < 0 || r < 0 || abs(orr - ol) > kAnchorJump * (r - l)) return false;
+    o = ol + (orr - ol) * (slot - l) / (r - l);
+    return true;
+}
+// the anchored start cell on anti-diagonal d0: q - r moved by o (rounded away from zero to an even step)
+__device__ __forceinline__ bool scout_anchored_cell(int d0, int R, int Q, int o, int &r, int &q)
+{
+    int r0, q0;
+    if (!scout_line_cell(d0, R, Q, r0, q0)) return false;
+    q = q0 + (o >= 0 ? (o + 1) / 2 : -((-o + 1) / 2));
+    r = d0 - q;
+    if (q < 0) { q = 0; r = d0; }
+    if (r < 0) { r = 0; q = d0; }
+    return q < Q && r < R;
+}
+
+// one workgroup of 256 threads per scout job {pair, slot, row}: thread o counts the columns i in [-32, 32) with consensus(ref, r0 + i) == consensus(qry, q0 + i + o - 128)
+template <int P>
+__global__ __launch_bounds__(256) void mt_anchor_kernel(const float *cols, const int32_t *len, int seq_len, const int32_t *jobs, int n_jobs, int32_t *anchor, int slots, int marker, int lead2)
+{
+    __shared__ unsigned char s_r[2 * kAnchorHalf], s_q[2 * kAnchorHalf + kAnchorOffsets];
+    __shared__ int s_cnt[kAnchorOffsets], s_best[4];
+    const int job = blockIdx.x;
+    if (job >= n_jobs) return;
+    const int pair = jobs[3 * job], slot = jobs[3 * job + 1], row = jobs[3 * job + 2];
+    const int R = len[2 * pair], Q = len[2 * pair + 1];
+    const int spLo = (marker - 1) * slot - 1;
+    const int d0 = max(spLo - lead2, 0);
+    int r0, q0;
+    if (spLo > R + Q - 2 || R < 2 || Q < 2 || !scout_line_cell(d0, R, Q, r0, q0)) return;      // (the table is filled with -1)
+    // consensus letter of a column: the most frequent of A, C, G, T when it is at least as frequent as the gap; else a letter that matches nothing
+    auto letter = [&](int side, int col, int n) -> unsigned char {
+        if (col < 0 || col >= n) return (unsigned char)(100 + side);
+        const float *pf = cols + (((size_t)pair * 2 + side) * (size_t)seq_len + col) * (P + 2);
+        int best = 0; float bc = pf[0];
+        for (int j = 1; j < 4; ++j) if (pf[j] > bc) { bc = pf[j]; best = j; }
+        return (bc > 0.0f && bc >= pf[P - 1]) ? (unsigned char)best : (unsigned char)(100 + side);
+    };
+    const int t = threadIdx.x;
+    if (t < 2 * kAnchorHalf) s_r[t] = letter(0, r0 - kAnchorHalf + t, R);
+    for (int u = t; u < 2 * kAnchorHalf + kAnchorOffsets; u += 256) s_q[u] = letter(1, q0 - kAnchorHalf - kAnchorOffsets / 2 + u, Q);
+    __syncthreads();
+    int c = 0;
+    for (int i = 0; i < 2 * kAnchorHalf; ++i) c += (s_r[i] == s_q[i + t]) ? 1 : 0;      // offset o = t - 128: column q0 - 32 + i + o = s_q[i + t]
+    s_cnt[t] = c;
+    __syncthreads();
+    if (t < 64) {
+        // the best offset: most matches, ties to the smallest |o|, the negative one first (the order 0, -1, 1, -2, 2, ... of the study)
+        int key = -1;
+        for (int u = t; u < kAnchorOffsets; u += 64) {
+            const int o = u - kAnchorOffsets / 2;
+            const int rank = (o == 0) ? 0 : (o < 0 ? -2 * o - 1 : 2 * o);
+            key = max(key, (s_cnt[u] << 16) | (0xFFFF - rank));
+        }
+        for (int m = 32; m >= 1; m >>= 1) key = max(key, __shfl_xor(key, m, 64));
+        const int rank = 0xFFFF - (key & 0xFFFF);
+        const int bo = (rank == 0) ? 0 : ((rank & 1) ? -(rank + 1) / 2 : rank / 2);
+        int second = -1;
+        for (int u = t; u < kAnchorOffsets; u += 64) if (abs(u - kAnchorOffsets / 2 - bo) > 2) second = max(second, s_cnt[u]);
+        for (int m = 32; m >= 1; m >>= 1) second = max(second, __shfl_xor(second, m, 64));
+        const int bc = key >> 16;
+        if (t == 0 && bc >= kAnchorMinMatches && bc - second >= kAnchorMinGap) anchor[(size_t)row * slots + slot] = 128 + bo;
+    }
+}
+
 template <int W, int RPL>
 struct NCfg {
     static constexpr int NV = W * RPL;          // 64-row blocks resident at once
@@ -338,7 +435,16 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         const unsigned long long gcMask = gcNZ ? ~0ull : 0ull;
         // MT 2 (scout of tile boundary `slot`): the anti-diagonals it reports and its own marker behind them
         const int spLo = (a.marker - 1) * slot - 1, spHi = a.marker * slot + 1;
-        const int scoutD0 = max(spLo - a.mt_lead, 0);
+        // ... from the cell the profiles' consensus letters point at, a short lead ahead, when there is one (mt_anchor_kernel); else from the straight line
+        int anchRef = -1, anchQry = -1;
+        bool anchored = false;
+        if constexpr (MT == 2) {
+            if (a.mt_anchor && !(spLo > R + Q - 2 || R < 2 || Q < 2)) {
+                int o = 0;
+                if (scout_anchor(a.mt_anchor + (size_t)mtx * a.mt_slots, slot, a.mt_slots, o)) anchored = scout_anchored_cell(max(spLo - a.mt_lead2, 0), R, Q, o, anchRef, anchQry);
+            }
+        }
+        const int scoutD0 = max(spLo - (anchored ? a.mt_lead2 : a.mt_lead), 0);
         // MT 4 (the scout of a whole pair): no marker at all -- phase A to the last anti-diagonal, every traceback word kept
         const int marker = (MT == 2) ? min(spHi + a.mt_marg - scoutD0, kMaxMarker) : ((MT == 4) ? R + Q + 8 : a.marker);
         const float denom = (float)a.num[2 * pair] * (float)a.num[2 * pair + 1];   // :255,:269
@@ -370,13 +476,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
         if constexpr (MT == 2) {          // the cell of diagonal scoutD0 on the straight line between the corners
             tile = 1;
             if (spLo > R + Q - 2 || R < 2 || Q < 2) last_tile = true;
-            else {
-                qry_idx = (int)(((long long)scoutD0 * Q) / (R + Q));
-                qry_idx = min(qry_idx, Q - 1);
-                ref_idx = scoutD0 - qry_idx;
-                if (ref_idx > R - 1) { ref_idx = R - 1; qry_idx = scoutD0 - ref_idx; }
-                if (qry_idx > Q - 1 || ref_idx < 0) last_tile = true;
-            }
+            else if (anchored) { ref_idx = anchRef; qry_idx = anchQry; }
+            else if (!scout_line_cell(scoutD0, R, Q, ref_idx, qry_idx)) last_tile = true;
         }
         if constexpr (MT == 4) {          // the row tags hold k + 1 in 16 bits; every group of 8 diagonals needs its traceback words
             if (R < 2 || Q < 2 || R + Q > 65000 || (size_t)(((R + Q) >> 3) + 2) * (size_t)WINDOW > (size_t)a.tb_words) last_tile = true;

@@ -104,7 +104,7 @@ struct Device {
     Buf cols, tb, cells, queue, items, errs, dbg;
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
     Buf team;                                                                    // mailboxes of the speculative tile start
-    Buf mt_chain, mt_rec, mt_seg, mt_spath, mt_stat, mt_jobs;                    // tile-parallel alignment (talco_nuc.hip.h, MT kernels)
+    Buf mt_chain, mt_rec, mt_seg, mt_spath, mt_stat, mt_jobs, mt_anchor;                    // tile-parallel alignment (talco_nuc.hip.h, MT kernels)
     Buf simdump;                                                                 // twl_dp_column_scores: [Q][R] scores written by the DUMP kernels
     bool dump_on = false;
     std::vector<int32_t> dbg_host;
@@ -748,7 +748,7 @@ void twl_shutdown(void)
         twl_level_pool_release(d);
         if (d->comm) { comm_destroy_raw(d->comm); d->comm = nullptr; }
         d->comm_send.release(); d->comm_recv.release();
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs, &d->gc_zero,
+        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs, &d->mt_anchor, &d->gc_zero,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -1066,6 +1066,8 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_FORCE_GLOBAL: g_force_global = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_LEAF_STEP: g_leaf_step = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_POISON_TB: g_poison_tb = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_MT_ANCHOR: g_mt_anchor = value ? 1 : 0; return TWL_OK;
+    case TWL_KNOB_MT_LEAD2: g_mt_lead2 = std::max(16, value); return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
