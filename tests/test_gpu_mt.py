@@ -440,7 +440,8 @@ def random_mt_case(seed):
     if rng.random() < 0.25:
         pk["gap_char"] = 0.0
     knobs = {api.KNOB_MT_MIN_MARKER: 64, api.KNOB_MT_PERTURB: int(rng.choice([0, 0, 1, 2, 5])), api.KNOB_MT_ROUNDS: int(rng.choice([1, 2, 3])),
-             api.KNOB_MT_LEAD: int(rng.choice([16, 128, 320])), api.KNOB_MT_MARGIN: int(rng.choice([2, 16, 40])), api.KNOB_MT_THR_JOBS: int(rng.choice([0, 256]))}
+             api.KNOB_MT_LEAD: int(rng.choice([16, 128, 320])), api.KNOB_MT_MARGIN: int(rng.choice([2, 16, 40])), api.KNOB_MT_THR_JOBS: int(rng.choice([0, 256])),
+             api.KNOB_MT_ANCHOR: int(rng.choice([1, 1, 0])), api.KNOB_MT_LEAD2: int(rng.choice([16, 64, 96, 160]))}
     return batch, (PM if prot else M), pk, knobs
 
 
