@@ -94,25 +94,33 @@ int main(int argc, char **argv)
             int d0 = dT - lead; if (d0 < 2) d0 = 2;
             const int q0 = (int)((long long)d0 * Q / (R + Q)), r0 = d0 - q0;
             int bestO = 0, bestC = -1, secondC = -1;
-            if (seedW > 0) {
+            /* the window around the straight line's cell first; when its verdict is not trusted, windows moved along the diagonal (argument 13: how many
+               on either side, 24 columns apart) -- the path's offset is the same a few columns on unless an indel lies between */
+            const int nShift = argc > 13 ? atoi(argv[13]) : 0;
+            int trusted = 0;
+            for (int sh = 0; sh <= 2 * nShift && !trusted && seedW > 0; ++sh) {
+                const int shift = (sh == 0) ? 0 : ((sh & 1) ? 24 * ((sh + 1) / 2) : -24 * (sh / 2));
+                int bO = 0, bC = -1, sC = -1;
                 for (int oo = 0; oo < 2 * seedOff; ++oo) {
                     const int o = (oo & 1) ? -((oo + 1) / 2) : oo / 2;       /* 0, -1, 1, -2, 2, ...: ties go to the smallest |o| */
                     int c = 0;
                     for (int i = -seedW; i < seedW; ++i) {
-                        const int rr = r0 + i, qq2 = q0 + i + o;
+                        const int rr = r0 + shift + i, qq2 = q0 + shift + i + o;
                         if (rr >= 0 && rr < R && qq2 >= 0 && qq2 < Q && cr[rr] == cq[qq2]) ++c;
                     }
-                    if (c > bestC) { bestC = c; bestO = o; }
+                    if (c > bC) { bC = c; bO = o; }
                 }
                 for (int o = -seedOff; o < seedOff; ++o) {
-                    if (abs(o - bestO) <= 2) continue;
+                    if (abs(o - bO) <= 2) continue;
                     int c = 0;
                     for (int i = -seedW; i < seedW; ++i) {
-                        const int rr = r0 + i, qq2 = q0 + i + o;
+                        const int rr = r0 + shift + i, qq2 = q0 + shift + i + o;
                         if (rr >= 0 && rr < R && qq2 >= 0 && qq2 < Q && cr[rr] == cq[qq2]) ++c;
                     }
-                    if (c > secondC) secondC = c;
+                    if (c > sC) sC = c;
                 }
+                trusted = !(bC * 100 < minPct * 2 * seedW || (bC - sC) * 100 < gapPct * 2 * seedW);
+                if (sh == 0 || trusted) { bestO = bO; bestC = bC; secondC = sC; }
             }
             aO[t] = bestO;
             aOk[t] = !(fbLead > 0 && (bestC * 100 < minPct * 2 * seedW || (bestC - secondC) * 100 < gapPct * 2 * seedW));
