@@ -307,12 +307,12 @@ __global__ __launch_bounds__(256) void mt_anchor_kernel(const float *cols, const
     const int d0 = max(spLo - lead2, 0);
     int r0, q0;
     if (spLo > R + Q - 2 || R < 2 || Q < 2 || !scout_line_cell(d0, R, Q, r0, q0)) return;      // (the table is filled with -1)
-    // consensus letter of a column: the most frequent of A, C, G, T when it is at least as frequent as the gap; else a letter that matches nothing
+    // consensus letter of a column: the most frequent of A, C, G, T (of the twenty amino acids) when it is at least as frequent as the gap; else a letter that matches nothing
     auto letter = [&](int side, int col, int n) -> unsigned char {
         if (col < 0 || col >= n) return (unsigned char)(100 + side);
         const float *pf = cols + (((size_t)pair * 2 + side) * (size_t)seq_len + col) * (P + 2);
         int best = 0; float bc = pf[0];
-        for (int j = 1; j < 4; ++j) if (pf[j] > bc) { bc = pf[j]; best = j; }
+        for (int j = 1; j < P - 2; ++j) if (pf[j] > bc) { bc = pf[j]; best = j; }
         return (bc > 0.0f && bc >= pf[P - 1]) ? (unsigned char)best : (unsigned char)(100 + side);
     };
     const int t = threadIdx.x;

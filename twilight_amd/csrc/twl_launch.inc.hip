@@ -248,8 +248,8 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     if ((rc = d->mt_spath.ensure(np * (size_t)sp_pitch * sizeof(int32_t)))) return rc;
     if ((rc = d->mt_stat.ensure(4 * sizeof(unsigned long long) + np * 8 * sizeof(int32_t)))) return rc;      // counters, then the per-pair frontier
     if ((rc = d->mt_jobs.ensure(jobs.size() * sizeof(int32_t)))) return rc;
-    // nucleotide scouts of the narrow geometries start from an anchored cell where the profiles give one (talco_nuc.hip.h, mt_anchor_kernel)
-    const bool anchors = (P == 6) && !WIDE && g_mt_anchor && nScout > 0;
+    // scouts of the narrow geometries start from an anchored cell where the profiles give one (talco_nuc.hip.h, mt_anchor_kernel)
+    const bool anchors = !WIDE && g_mt_anchor && nScout > 0;
     if (anchors && (rc = d->mt_anchor.ensure(np * slots * sizeof(int32_t)))) return rc;
     HIP_TRY(hipMemcpyAsync(d->mt_jobs.p, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     FILL_TRY(queue_fill(d, st, d->mt_rec.p, np * slots * twl::kMtRec * sizeof(int32_t), 0));
@@ -292,7 +292,7 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         }
     } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
-        if constexpr (P == 6) {
+        {
             if (anchors) {
                 FILL_TRY(flush_fills(d, st));
                 hipLaunchKernelGGL(twl::mt_anchor_kernel<P>, dim3(nScout), dim3(256), 0, st, base.cols, base.len, base.seq_len, a.mt_jobs, nScout, (int32_t *)d->mt_anchor.p, slots, marker, g_mt_lead2);
