@@ -160,7 +160,7 @@ def cpu_baseline(batch, matrix, pk, gpu_paths, gpu_lens, target_seconds=12.0):
             "gpu_paths_equal_on_sample": parity}
 
 
-def peak_level(twl, dev, local_rank, cfg, pairs=2048, pool=64, reps=3):
+def peak_level(twl, dev, local_rank, cfg, pairs=2048, pool=512, reps=3):
     """One wide level through twl_align_batch_device (HBM in, HBM out): what the DP kernel does when the GPU is full."""
     import torch
 
@@ -596,6 +596,11 @@ def main():
                 out["survey8d"] = survey8d_record(cfg, local_rank, base)
             except Exception as e:  # noqa: BLE001
                 out["survey8d"] = {"note": f"failed: {e}"}
+            # ... and its headline figures where a reader of `config` sees them
+            s8 = out["survey8d"]
+            if "cells_per_s" in s8:
+                out["config"]["survey8d_family_as_written"] = {"cells_per_s": s8["cells_per_s"], "s_per_pass": s8["s_per_pass"], "contract_frac": s8["frac_of_hbm_roofline"],
+                                                               "msa_md5": s8["msa_md5"], "note": "one pass over the family generated with SURVEY.md 8d's parameters (record `survey8d` of this line)"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if family and not args.keep:
