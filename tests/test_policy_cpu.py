@@ -74,3 +74,18 @@ def test_a_level_that_outgrew_the_small_window_keeps_the_rest_of_the_pass_off_it
         assert "window 512;" in api.plan_describe(p, _lens(5000, 10000), small_state=-1)
     finally:
         twl.set_knob(api.KNOB_THR_SMALL, 0)
+
+
+def test_every_knob_the_header_names_is_known_to_the_library_and_to_the_bindings(built):
+    """include/twl_align.h's enum twl_knob, twilight_amd/api.py's KNOB_* constants and twl_set_knob's switch are three lists of the same keys."""
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "twl_align.h")).read()
+    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"TWL_(KNOB_[A-Z0-9_]+) = (\d+)", hdr[hdr.index("enum twl_knob"):]))
+    assert len(enum) >= 20 and sorted(enum.values()) == list(range(1, len(enum) + 1))
+    defaults = {"KNOB_MT_MAX_PAIRS": 1024, "KNOB_MT_MIN_MARKER": 512, "KNOB_MT_LEAD": 320, "KNOB_MT_MARGIN": 40, "KNOB_MT_ROUNDS": 2, "KNOB_MT_THR_JOBS": 256,
+                "KNOB_MT_TAIL_PCT": 70, "KNOB_MT_WIDE": 1, "KNOB_SCOUT_XDROP_PCT": 100, "KNOB_LEAF_STEP": 1, "KNOB_MT_ANCHOR": 1, "KNOB_MT_LEAD2": 96}
+    for name, key in enum.items():
+        assert getattr(api, name) == key, name
+        twl.set_knob(key, defaults.get(name, 0))          # (every key is accepted; the value is the library's default)
+    with pytest.raises(Exception):
+        twl.set_knob(len(enum) + 1, 0)
