@@ -5,7 +5,11 @@
  * then for every tile boundary starts a "scout" tile LEAD diagonals earlier from a cell DELTA rows off the true path and asks
  * whether the scout's traceback path runs through the true start cell of the next tile.
  *   cc -O2 -ffp-contract=off -fopenmp -o /tmp/tps tests/study/tile_predict_study.c -lm
- *   /tmp/tps pair.bin [lead] [tailmarg]
+ *   /tmp/tps pair.bin [lead] [tailmarg] [scout xdrop] [1 = stop at the marker like the kernel's scouts]
+ *   /tmp/tps pair.bin lead tailmarg xdrop 1 W OFF [fallback lead] [min %] [gap %] [interpolate over n boundaries] [max jump per boundary] [windows on either side]
+ *       the anchored scouts of round 5 (talco_nuc.hip.h, mt_anchor_kernel): the start cell moved to the diagonal offset (-OFF .. OFF-1) on which the consensus letters of
+ *       the two profiles agree most often within +-W columns; the kernel's setting is  96 40 5000 1 32 128 320 55 12 3 12 4.  TPS_VERBOSE=1 prints every boundary.
+ *   Pairs come from  TWLO_DUMP_PAIRS=<dir> [TWLO_DUMP_MAX_PAIRS=n] [TWLO_DUMP_EVERY=k] oracle/e2e_oracle -t tree -i fasta -o out.aln
  */
 /* scouts that do not wait for convergence: after the marker diagonal take the better of the best cells of diagonals marker-1 / marker
  * (the rule of the speculative tile start, talco_nuc.hip.h) and trace back from there */
