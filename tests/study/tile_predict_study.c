@@ -96,6 +96,7 @@ int main(int argc, char **argv)
         for (int t = 1; t < nt; ++t) {
             const int dT = starts[t].r + starts[t].q;
             int d0 = dT - lead; if (d0 < 2) d0 = 2;
+            if (getenv("TPS_NOMINAL")) { d0 = (p.marker - 1) * t - 1 - lead; if (d0 < 0) d0 = 0; }      /* as the kernel: the boundary's nominal range, not the true start */
             const int q0 = (int)((long long)d0 * Q / (R + Q)), r0 = d0 - q0;
             int bestO = 0, bestC = -1, secondC = -1;
             /* the window around the straight line's cell first; when its verdict is not trusted, windows moved along the diagonal (argument 13: how many
@@ -147,6 +148,8 @@ int main(int argc, char **argv)
         for (int t = 1; t < nt; ++t) {
             const int dT = starts[t].r + starts[t].q;
             int d0 = dT - aLead[t]; if (d0 < 2) d0 = 2;
+            int smarker = 0;
+            if (getenv("TPS_NOMINAL")) { d0 = (p.marker - 1) * t - 1 - aLead[t]; if (d0 < 0) d0 = 0; smarker = p.marker * t + 1 + marg - d0; }
             const int q0 = (int)((long long)d0 * Q / (R + Q));
             const int bestO = aO[t];
             if (!aOk[t]) nfb++;
@@ -158,7 +161,7 @@ int main(int argc, char **argv)
             int tq = pathq[d0]; if (tq < 0) tq = pathq[d0 - 1];
             const int dev = abs(gq - tq);
             sumd += dev; if (dev > maxd) maxd = dev;
-            twlo_params sp = p; sp.marker = dT - d0 + marg; sp.xdrop = sxdrop;
+            twlo_params sp = p; sp.marker = smarker ? smarker : dT - d0 + marg; sp.xdrop = sxdrop;
             ctx_t sc = c; sc.p = &sp;
             int32_t sr = gr, sq = gq; int sl = 0; int16_t se = 0; bytes_t sg = {0, 0, 0};
             tile_run(&sc, &sr, &sq, &sg, &sl, g_stop_at_marker ? 7777 : 1, &se);
