@@ -70,7 +70,7 @@ struct NArgs {
     unsigned long long *mt_stat;   // [4] {tiles taken from the records, tiles run in line, scouts that failed, -}
     int32_t *mt_front;        // [row][8] how far the stitch launches have come: {0 untouched / 1 suspended at a tile without a record / 2 done, tile, ref_idx, qry_idx, pos, -, cells lo, cells hi}
     int32_t mt_slots, mt_segcap, mt_sp_pitch, mt_lead, mt_marg;
-    const int32_t *mt_anchor; // [row][mt_slots] scouts (nucleotide): 128 + the offset of q - r at which the consensus letters of the two profiles agree, trusted; < 0: none (nullptr: no anchors at all)
+    const int32_t *mt_anchor; // [row][mt_slots] scouts: 128 + the offset of q - r at which the consensus letters of the two profiles agree, trusted; < 0: none (nullptr: no anchors at all)
     int32_t mt_lead2;         // anti-diagonals an anchored scout starts ahead of its tile boundary
     int32_t mt_inline;        // MT 3: 1 = a tile without a matching record is computed in line (last round); 0 = the pair is suspended there
 };
@@ -249,8 +249,9 @@ __global__ void mt_chain_kernel(const int32_t *spath, int sp_pitch, const int32_
 // the cell of the straight line the consensus letters of the two profiles agree on one diagonal offset and on no other (tests/study/tile_predict_study.c:
 // +-32 columns, offsets -128..127).  mt_anchor_kernel finds that offset for every tile boundary; a scout whose anchor is trusted -- or lies between two
 // trusted ones that agree (the path drifts by a few rows per tile; an offset that jumps is a long indel and says nothing about its neighbours) -- starts
-// from the anchored cell only mt_lead2 (96) anti-diagonals ahead.  On the top 52 pairs of 10 000 x 10 kbp: 82 % of the scouts anchored, the same 1039 of
-// 1040 true starts found, 51 % fewer scout diagonals.  Predictions only: a wrong anchor costs what any wrong prediction costs.
+// from the anchored cell only mt_lead2 (96) anti-diagonals ahead.  On the 154 pairs of levels 15-31 of 10 000 x 10 kbp (the CPU study, with the nine windows of
+// mt_anchor_kernel): all but 2 of 3080 boundaries anchored, 3078 true starts found against 3079 with the long lead, 61 % fewer scout diagonals; on the device the scouts of a
+// pass 39 -> 15 ms.  Predictions only: a wrong anchor costs what any wrong prediction costs -- a second round of its level.
 constexpr int kAnchorHalf = 32, kAnchorOffsets = 256, kAnchorNear = 3, kAnchorJump = 12;
 constexpr int kAnchorMinMatches = 36, kAnchorMinGap = 8;      // trusted: >= 55 % of the 64 columns agree and the best other offset (not a neighbour) is >= 12 % behind
 

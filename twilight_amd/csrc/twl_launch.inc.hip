@@ -292,13 +292,11 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         }
     } else if (nScout > 0) {
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
-        {
-            if (anchors) {
-                FILL_TRY(flush_fills(d, st));
-                hipLaunchKernelGGL(twl::mt_anchor_kernel<P>, dim3(nScout), dim3(256), 0, st, base.cols, base.len, base.seq_len, a.mt_jobs, nScout, (int32_t *)d->mt_anchor.p, slots, marker, g_mt_lead2);
-                HIP_TRY(hipGetLastError());
-                a.mt_anchor = (const int32_t *)d->mt_anchor.p; a.mt_lead2 = g_mt_lead2;
-            }
+        if (anchors) {
+            FILL_TRY(flush_fills(d, st));
+            hipLaunchKernelGGL(twl::mt_anchor_kernel<P>, dim3(nScout), dim3(256), 0, st, base.cols, base.len, base.seq_len, a.mt_jobs, nScout, (int32_t *)d->mt_anchor.p, slots, marker, g_mt_lead2);
+            HIP_TRY(hipGetLastError());
+            a.mt_anchor = (const int32_t *)d->mt_anchor.p; a.mt_lead2 = g_mt_lead2;
         }
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
         // (nucleotide scouts of the throughput geometry run ~330 diagonals from one cell: their band opens by a row per diagonal and cannot outgrow 449 rows, so
