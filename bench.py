@@ -37,6 +37,8 @@ import numpy as np  # noqa: E402
 from twilight_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz); SURVEY.md 8d(ii) prices F_cell against it
+F_CELL = {6: 120.0, 22: 1460.0}  # SURVEY.md 8d(ii) / BASELINE.md 3: fp32 operations of one band cell (column score + recurrence), nucleotide / protein
 # algorithmic operand bytes per band cell (SURVEY.md 8d / BASELINE.md 3): 2 profile columns + 4 gap penalties = 2*P*4 + 16
 CONFIGS = {
     "rnasim10k": dict(kind="family", leaves=10000, length=10000, type="n", P=6, bcell=64, sub=0.015, indel=0.001,
@@ -148,15 +150,22 @@ def cpu_baseline(batch, matrix, pk, gpu_paths, gpu_lens, target_seconds=12.0):
     t0 = time.perf_counter()
     _, _, _, fcells1 = O.align_batch_faithful(p, sub(np.arange(k1) % n), threads=1)
     dtf1 = time.perf_counter() - t0
-    return {"value": st.cells / dt, "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
-            "one_thread_value": st1.cells / dt1,
+    flat = {"value": st.cells / dt, "one_thread_value": st1.cells / dt1, "unit": "cells/s", "cores": threads,
             "sample": f"{k} pairs of ~{batch.seq_len}-column profiles of this workload's shape ({st.cells} band cells) in {dt:.1f} s on {threads} threads "
                       f"(OpenMP over pairs); 1 thread: {k1} pairs in {dt1:.1f} s",
-            "reference_layout": {"value": fcells / dtf, "one_thread_value": fcells1 / dtf1, "unit": "cells/s", "cores": threads,
-                                 "sample": f"{kf} of those pairs in {dtf:.1f} s on {threads} threads; 1 thread: {k1} pairs in {dtf1:.1f} s", "paths_equal_to_port": same,
-                                 "note": "oracle/talco_faithful.cpp: the same algorithm with the reference's data layout and allocation pattern (vector<vector<float>> "
-                                         "profiles, 14 new[] per tile, AVX2 masked loads; TALCO-XDrop.cpp:279-312,378-395), measured on this box"},
-            "note": "flat-array restatement of the reference CPU path (oracle/talco_oracle.c)",
+            "note": "flat-array restatement of the reference CPU path (oracle/talco_oracle.c)"}
+    layout = {"value": fcells / dtf, "one_thread_value": fcells1 / dtf1, "unit": "cells/s", "cores": threads,
+              "sample": f"{kf} of those pairs in {dtf:.1f} s on {threads} threads; 1 thread: {k1} pairs in {dtf1:.1f} s", "paths_equal_to_port": same,
+              "note": "oracle/talco_faithful.cpp: the same algorithm with the reference's data layout and allocation pattern (vector<vector<float>> "
+                      "profiles, 14 new[] per tile, AVX2 masked loads; TALCO-XDrop.cpp:279-312,378-395), measured on this box"}
+    # the stated baseline is the FASTER of the two restatements (the reference's layout with its AVX2 loads beats the flat port on
+    # this box, and a baseline must not understate the reference); the other one stays beside it
+    best, which = (layout, "reference_layout") if layout["value"] >= flat["value"] else (flat, "flat_port")
+    return {"value": best["value"], "unit": "cells/s", "cores": threads, "kind": "port", "which": which, "cpu_model": cpu_model(),
+            "one_thread_value": best["one_thread_value"], "sample": best["sample"],
+            "note": "the faster of two CPU restatements of the reference path, both timed here: `flat_port` (oracle/talco_oracle.c, the checker) and `reference_layout` "
+                    "(oracle/talco_faithful.cpp, the reference's own data layout with AVX2 masked loads); the reference itself cannot be built in this image",
+            "flat_port": flat, "reference_layout": layout,
             "gpu_paths_equal_on_sample": parity}
 
 
@@ -189,6 +198,7 @@ def peak_level(twl, dev, local_rank, cfg, pairs=2048, pool=512, reps=3, warm=1, 
     params = twl.make_params(matrix, **pk)
     torch.cuda.synchronize()        # the inputs above were produced on torch's stream; the library runs on its own
     cells = kms = 0.0
+    nominal = 0
     timed_s = None
     for r in range(warm + reps):
         if r == warm and fence is not None:
@@ -200,10 +210,11 @@ def peak_level(twl, dev, local_rank, cfg, pairs=2048, pool=512, reps=3, warm=1, 
         if r >= warm:
             cells += st.band_cells
             kms += st.kernel_ms
+            nominal = int(st.nominal_cells)
     if fence is not None:
         fence()
         timed_s = time.perf_counter() - t0
-    out = {"pairs": pairs, "seq_len": sl, "band_cells_per_launch": int(cells // reps), "kernel_ms_per_launch": kms / reps,
+    out = {"pairs": pairs, "seq_len": sl, "band_cells_per_launch": int(cells // reps), "nominal_cells_per_launch": nominal, "kernel_ms_per_launch": kms / reps,
            "cells_per_s": cells / (kms * 1e-3), "frac_of_hbm_roofline": cells * cfg["bcell"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "deferred_pairs": int((err != 0).sum().item()), "relaunched_pairs": int(st.n_relaunched), "window_rows": int(st.window),
            "persistent_workgroups": int(st.grid), "timed_s": timed_s,
@@ -416,10 +427,12 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         cells = 0
+        nominal_cells = 0
         kernel_ms = exch_ms = 0.0
         for m in handles[args.warmup:]:
             tot, levels = m.report()
             cells += tot.band_cells
+            nominal_cells += int(tot.nominal_cells)
             kernel_ms += tot.kernel_ms
             exch_ms += tot.exchange_ms
         md5 = None
@@ -436,6 +449,7 @@ def main():
         peak, pk_batch, matrix, pk, gp, gl = peak_level(twl, dev, local_rank, cfg, reps=max(1, args.steps), warm=max(1, args.warmup), fence=fence)
         dt = peak["timed_s"]
         cells = peak["band_cells_per_launch"] * args.steps
+        nominal_cells = peak["nominal_cells_per_launch"] * args.steps
         kernel_ms = peak["kernel_ms_per_launch"] * args.steps
         exch_ms = 0.0
         levels, tot, md5, open_s = [], None, None, 0.0
@@ -564,6 +578,15 @@ def main():
             "frac_levels_of_dominant_kernel": (dom_cells_per_s / peak_cells) if (dom_cells_per_s and peak_cells) else None,
             "issue_ceiling_instr_per_s": ceiling, "instructions_per_block_step": step_ins, "cells_per_block_step": 64, "static_counts": "profiles/r05/isa_block_step.json",
             "static_counts_note": isa_note,
+            # fp32 VALU utilisation = F_cell x band cells / DP-kernel time against the fp32 vector peak (FMA counted as 2: bit-exactness forbids
+            # FMA here -- TALCO-XDrop.cpp:378-395 rounds every product and sum -- so half of that peak is out of reach by construction)
+            "valu_flops_frac": (F_CELL[cfg["P"]] * cells / (kernel_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS) if kernel_ms > 0 else None,
+            "valu_tflops": (F_CELL[cfg["P"]] * cells / (kernel_ms * 1e-3) / 1e12) if kernel_ms > 0 else None,
+            "valu_flops_per_cell": F_CELL[cfg["P"]], "valu_fp32_peak_tflops": VALU_FP32_PEAK_TFLOPS,
+            # ... and the classic figure: NOMINAL R x Q cells (whole matrices, not bands) per second, over the DP kernels and over the timed region
+            "nominal_gcups_dp_kernels": (nominal_cells / (kernel_ms * 1e-3) / 1e9) if (kernel_ms > 0 and nominal_cells and world == 1) else None,
+            "nominal_gcups_whole_job": (nominal_cells / dt_max / 1e9) if (nominal_cells and world == 1) else None,
+            "nominal_cells": (int(nominal_cells // steps) if (nominal_cells and world == 1) else None),
             "contract_bound": "hbm", "contract_achieved_gb_s": achieved, "contract_peak_gb_s": HBM_PEAK_GBS, "contract_frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_live": False,
             "traffic_bytes_per_cell": (traffic / (cells / steps)) if traffic else None,

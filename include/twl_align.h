@@ -201,7 +201,7 @@ int twl_comm_destroy(int device);
      TWL_KNOB_POISON_TB      1: the traceback scratch is filled with 0xFF bytes in front of every DP launch.  A block writes its traceback word only when it can have
                              held band cells in the group of 8 diagonals; a word wrongly skipped would read as the zeros of a fresh allocation (a "match" pointer,
                              often right) -- with the knob it reads as garbage and the parity tests see it.  tests/conftest.py sets it for every GPU test
-     TWL_KNOB_MT_ANCHOR      1 (default): the nucleotide scouts of the tile-parallel path start from the cell on which the consensus letters of the two profiles agree
+     TWL_KNOB_MT_ANCHOR      1 (default): the scouts of the tile-parallel path (nucleotide and protein: the most frequent letter of a column) start from the cell on which the consensus letters of the two profiles agree
                              (one small kernel per level finds it for every tile boundary), TWL_KNOB_MT_LEAD2 (default 96) anti-diagonals ahead of the boundary, where
                              that cell is trusted; elsewhere, and with 0 everywhere, from the straight line between the corners TWL_KNOB_MT_LEAD ahead.  Predictions
                              only: the results are the same either way (tests hold the two to each other) */

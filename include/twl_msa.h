@@ -33,7 +33,9 @@ typedef struct twl_msa twl_msa;
 /* One level-kernel call (= one line of the reference's per-level report, progressive.cpp:178-189). */
 typedef struct twl_msa_level {
     int32_t  pairs;         /* sibling pairs of the level */
-    int32_t  task;          /* 0 main pass, 1 deferred pass */
+    int32_t  task;          /* 0 main pass, 1 deferred pass.  A deferred-pass level holds exactly ONE pair, as the reference's does (progressive.cpp:283-291: each
+                               profile is aligned to the root the previous one was merged into); the level kernel refuses a task-1 level of any other size
+                               with TWL_ERR_UNSUPPORTED (its retries of alignment-cpu.cpp:116-129 re-run the level under a one-pair mask) */
     uint64_t band_cells;    /* DP band cells of the level, all ranks */
     uint64_t relaunched;    /* pairs re-run in a wider window */
     double   kernel_ms;     /* DP kernel time (HIP events; max over the ranks / devices that ran concurrently) */
@@ -50,6 +52,7 @@ typedef struct twl_msa_totals {
     int32_t  n_levels, aln_len, n_sequences, reserved;
     uint64_t pairs, band_cells, relaunched;
     double   kernel_ms, exchange_ms, align_s;
+    uint64_t nominal_cells;   /* sum of R*Q over the pairs of the level calls THIS process made (one GPU: every pair of the run): nominal cells of the classic GCUPS figure */
 } twl_msa_totals;
 
 /* All-gather of equal-sized host blocks between the processes of a sharded run: send = this rank's block of bytes_per_rank

@@ -43,12 +43,19 @@ def main():
     start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3twl17talco_lean_kernel"))
     end = next(i for i, l in enumerate(lines) if l.startswith(".Lfunc_end") and i > start)
     k = lines[start:end]
-    hdr = [i for i, l in enumerate(k) if "Inner Loop Header: Depth=3" in l]
-    a = hdr[1]                                        # loops in text order: SPEC/poll-free kernels have [prologue fill, phase A, phase B, phase C, ...]; the 2nd depth-3 loop is phase A
-    while not k[a].startswith(".LBB"): a -= 1
-    head_label = k[a].split(":")[0]
-    # the loop ends at the unconditional branch back to its header
-    z = next(i for i in range(a + 1, len(k)) if re.match(r"\s+s_branch\s+%s\b" % re.escape(head_label), k[i]))
+    # the step leaves a comment in the listing ("; TWL_STEP PH=p GEN=g"): the loop around the comment of the wanted variant is cut out.
+    # WHICH (argv[3], default "0,0") = phase,general: "0,0" the plain phase-A step most diagonals of a tile run in, "2,0" the plain phase-C step
+    ph, gen = (sys.argv[3] if len(sys.argv) > 3 else "0,0").split(",")
+    mark = next(i for i, l in enumerate(k) if f"TWL_STEP PH={ph} GEN={gen}" in l)
+    best = None
+    for i, l in enumerate(k):
+        if "Loop Header" not in l or i > mark: continue
+        a = i
+        while not k[a].startswith(".LBB"): a -= 1
+        head_label = k[a].split(":")[0]
+        backs = [j for j in range(mark, len(k)) if re.match(r"\s+s_c?branch\w*\s+%s\b" % re.escape(head_label), k[j])]
+        if backs and (best is None or a > best[0]): best = (a, backs[-1])      # the innermost loop that holds the comment: the latest header with a branch back behind it
+    a, z = best
     body = k[a:z + 1]
     blocks, cur = [], None
     for l in body:

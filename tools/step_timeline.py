@@ -11,8 +11,9 @@ import torch  # noqa: F401
 from twilight_amd import synth, api
 
 length = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-so = os.path.join(tempfile.mkdtemp(), "libtwl_stamps.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
+so = os.environ.get("TWL_STAMPS_SO") or os.path.join(tempfile.mkdtemp(), "libtwl_stamps.so")      # (a library cross-compiled with -DTWL_KERNEL_STAMPS -DTWL_DEV saves the GPU box the build)
+if not os.environ.get("TWL_STAMPS_SO"):
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
                        "-DTWL_KERNEL_STAMPS", "-DTWL_DEV", "-o", so, os.path.join(ROOT, "twilight_amd", "csrc", "twl_align.hip")])
 api.LIB_PATH = so
 os.environ["TWL_DEBUG"] = "1"

@@ -26,4 +26,4 @@ from .api import (  # noqa: F401
 )
 from . import api as knobs  # noqa: F401  (KNOB_* constants)
 
-__version__ = "0.4.0"
+__version__ = "0.5.0"

@@ -359,7 +359,7 @@ static void runBatch(RunCtx &ctx, LevelRecord &rec, const twl_params &tp, const 
     double kms = 0, tms = 0;
     for (int dev : g_devices) {      // the devices of one call run concurrently: cells add up, times do not
         twl_stats st{};
-        if (twl_get_stats(dev, &st) == TWL_OK) { rec.band_cells += st.band_cells; rec.relaunched += (uint64_t)st.n_relaunched; kms = std::max(kms, st.kernel_ms); tms = std::max(tms, st.total_ms);
+        if (twl_get_stats(dev, &st) == TWL_OK) { ctx.totals.nominal_cells += st.nominal_cells; rec.band_cells += st.band_cells; rec.relaunched += (uint64_t)st.n_relaunched; kms = std::max(kms, st.kernel_ms); tms = std::max(tms, st.total_ms);
             if (rec.matrix_mode < 0) { rec.matrix_mode = st.matrix_mode; rec.speculative = st.speculative; memcpy(rec.kernel, st.kernel, sizeof rec.kernel); }
             rec.mt_predicted += st.mt_tiles_predicted; rec.mt_inline += st.mt_tiles_inline; }
     }

@@ -380,14 +380,16 @@ void alignmentKernel_Resident(Tree *T, NodePairVec &nodes, SequenceDB *database,
                 }
             };
             addStats();
+            if (d == 0) { twl_stats st0{}; if (twl_get_stats(ctx.storeDev[0], &st0) == TWL_OK) ctx.totals.nominal_cells += st0.nominal_cells; }      // (R*Q of the level's pairs, once: the classic GCUPS figure of bench.py)
             // alignment-cpu.cpp:116-129: in the deferred pass a failed pair is retried, by whoever owns it, with a larger X-drop / band limit until it passes
             if (task == 1) {
+                // a retry is a call of the whole level with a one-pair mask, and a DP call zero-fills the outputs of ALL the level's pairs: with more
+                // than one pair it would wipe what the others have just produced.  The deferred pass aligns one profile per level
+                // (progressive.cpp:283-291); a task-1 level of several pairs is refused up front -- whether or not a pair fails -- rather than silently
+                // wrong or dependent on the data (the limit is part of the contract: include/twl_msa.h)
+                if (n != 1) { std::cerr << "ERROR: a deferred-pass (task 1) level must hold exactly one pair; this one has " << n << ".\n"; return (int)TWL_ERR_UNSUPPORTED; }
                 for (int i = 0; i < n; ++i) {
                     if (!mask[i] || err[i] == 0) continue;
-                    // a retry is a call of the whole level with a one-pair mask, and a DP call zero-fills the outputs of ALL the level's pairs: with more
-                    // than one pair it would wipe what the others have just produced.  The deferred pass aligns one profile per level
-                    // (progressive.cpp:283-291); anything else is refused rather than silently wrong
-                    if (n != 1) { std::cerr << "ERROR: a deferred-pass level of " << n << " pairs cannot be retried pair by pair.\n"; return (int)TWL_ERR_UNSUPPORTED; }
                     twl_params tr = maskZero[i] ? tz : tp;
                     const int minLen = std::min(ps[i].lens.first, ps[i].lens.second);
                     std::vector<uint8_t> one(n, 0);

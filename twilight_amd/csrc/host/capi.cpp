@@ -15,6 +15,12 @@
 #include <string>
 #include <vector>
 
+#ifndef TWL_BUILD_STAMP
+#define TWL_BUILD_STAMP "unstamped"
+#endif
+// digest of this artefact's sources, headers and flags (__graft_entry__.build() rebuilds when the file does not carry the current one)
+__attribute__((used)) static const char twl_build_stamp[] = "TWLSTAMP:" TWL_BUILD_STAMP ";";
+
 namespace {
 thread_local std::string g_msaErr;
 double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -149,6 +155,7 @@ int twl_msa_report(twl_msa *m, twl_msa_totals *t, twl_msa_level *levels, int32_t
     t->n_sequences = (int32_t)m->db->sequences.size();
     t->pairs = tot.pairs; t->band_cells = tot.band_cells; t->relaunched = tot.relaunched;
     t->kernel_ms = tot.kernel_ms; t->exchange_ms = tot.exchange_ms; t->align_s = m->alignS;
+    t->nominal_cells = tot.nominal_cells;
     for (int32_t i = 0; levels && i < max_levels && i < (int32_t)recs.size(); ++i) {
         levels[i].pairs = recs[i].pairs; levels[i].task = recs[i].task; levels[i].band_cells = recs[i].band_cells;
         levels[i].relaunched = recs[i].relaunched; levels[i].kernel_ms = recs[i].kernel_ms; levels[i].level_ms = recs[i].level_ms;

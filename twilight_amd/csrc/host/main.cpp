@@ -20,6 +20,12 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#ifndef TWL_BUILD_STAMP
+#define TWL_BUILD_STAMP "unstamped"
+#endif
+// digest of this artefact's sources, headers and flags (__graft_entry__.build() rebuilds when the file does not carry the current one)
+__attribute__((used)) static const char twl_build_stamp[] = "TWLSTAMP:" TWL_BUILD_STAMP ";";
+
 // --gpu-index a,b,...: one PROCESS per GPU, forked here before anything touches the GPU.  The ranks align the same family
 // together: the pairs of every level are dealt to them, each aligns its share on its device, and the final paths meet in ONE ncclAllGather
 // per level, HBM to HBM over xGMI, made by the library itself (include/twl_align.h, twl_comm_*).  The 128-byte communicator id goes from
@@ -113,6 +119,9 @@ int main(int argc, char **argv)
         });
     }
     msa::progressive::gpu::beginInit(&option);
+    // exit handlers run last-registered first: registered again behind whatever the GPU runtime registered while it came up, the mark is set
+    // BEFORE the runtime's own teardown, which may block while other ranks sit in a collective
+    if (world > 1) atexit(markFailedAtExit);
     // both passes run on the GPU level kernel (the reference hard-wires its CPU kernel for the deferred pass)
     msa::alnFunction kernel = msa::progressive::gpu::alignmentKernel_Resident;
     if (option.hostStaged) kernel = msa::progressive::gpu::alignmentKernel_GPU;
@@ -122,13 +131,15 @@ int main(int argc, char **argv)
         if (rank == 0) {
             msa::progressive::gpu::ensureDevicesUp(&option);
             if (twl_comm_unique_id(page->id) != TWL_OK) { std::cerr << "ERROR: " << twl_last_error() << '\n'; page->failed = 1; exit(1); }
+            atexit(markFailedAtExit);      // (the devices are up: behind the runtime's handlers)
             page->ready = 1;
         } else {
             while (!page->ready.load() && !page->failed.load()) std::this_thread::sleep_for(std::chrono::milliseconds(1));      // (the watcher thread covers a parent that is gone)
             if (page->failed.load()) exit(1);
         }
         const int rcComm = msa::progressive::gpu::initRcclShard(db, &option, rank, world, page->id);
-        if (rcComm != TWL_OK) { std::cerr << "ERROR: twl_comm_init failed (" << rcComm << "): " << twl_last_error() << '\n'; exit(1); }
+        if (rcComm != TWL_OK) { std::cerr << "ERROR: twl_comm_init failed (" << rcComm << "): " << twl_last_error() << '\n'; markFailedAtExit(); exit(1); }
+        atexit(markFailedAtExit);      // (... and behind RCCL's and the device runtime's handlers, see above)
     };
     const int alnLen = msa::runDefaultAlignment(option, kernel, kernel, rank == 0, [&](msa::SequenceDB *db) { g = msa::progressive::gpu::runTotals(db); }, beforeAlign);
     g_finishedOk = 1;

@@ -253,7 +253,7 @@ void beginInit(Option *option);   // optional: start device initialisation early
 // building, gappy-column removal, gap penalties and the row write-back run as kernels.  Falls through to alignmentKernel_GPU
 // for the deferred pass (currentTask != 0), after bringing the rows back.
 void alignmentKernel_Resident(Tree *T, NodePairVec &alnPairs, SequenceDB *database, Option *option, Params &param);
-struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0, exchange_ms = 0; };
+struct LevelTotals { uint64_t band_cells = 0, pairs = 0, relaunched = 0, nominal_cells = 0 /* sum of R*Q over the pairs this process's level calls saw (all of them on one GPU) */; double kernel_ms = 0, total_ms = 0, prepare_ms = 0, stage_ms = 0, call_ms = 0, finish_ms = 0, dev_prepare_ms = 0, dev_commit_ms = 0, exchange_ms = 0; };
 // One level-kernel call, as the reference's per-level report line (progressive.cpp:178-189) plus what the DP did in it.
 struct LevelRecord { int32_t pairs = 0, task = 0; uint64_t band_cells = 0, relaunched = 0; double kernel_ms = 0, level_ms = 0, exchange_ms = 0; int32_t matrix_mode = -1, speculative = 0;
                      int32_t mt_predicted = 0, mt_inline = 0; char kernel[160] = {0}; };

@@ -120,14 +120,14 @@ __global__ __launch_bounds__(1024, 1) void talco_global_kernel(GArgs ga)
             float max_score = 0.0f, msp = -inf, conv_score = 0.0f;       // :259
             bool converged = false, conv_logic = false;
             int conv_value = 0, prev_conv_s = -1, last_k = 0, tile_err = 0;
-            unsigned tcells = 0;
+            unsigned long long tcells = 0;      // (a tile that does not converge runs R + Q diagonals of a band this kernel exists for: > 2^32 cells)
             const int kEnd = refLen + qLen - 1;
             for (int k = 0; k < kEnd; ++k) {                             // :321
                 const int c0 = k % 3, c1 = (k + 2) % 3, c2 = (k + 1) % 3, b0 = k & 1, b1 = (k + 1) & 1;
                 if (L0 >= U0 + 1) { tile_err = 1; break; }               // :323-329
                 if (U0 - L0 + 1 > fLen) { tile_err = 2; break; }         // :331-338
                 if (k <= marker && tid == 0) s_flow[k] = L0;             // :340-344
-                tcells += (unsigned)(U0 - L0 + 1);
+                tcells += (unsigned long long)(unsigned)(U0 - L0 + 1);
                 const int w1 = U1 - L1, w2 = U2 - L2;
                 const float thr = max_score - xdropf;
                 float lmax = -inf;

@@ -419,7 +419,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *tb = a.tb + (size_t)blockIdx.x * (size_t)a.tb_words;
     const float inf = (float)(2.0 * (double)a.xdrop + 1.0);     // TALCO-XDrop.cpp:252
-    const float xdropf = (float)a.xdrop;
+    // (uniform, and wanted as a scalar operand: in a vector register it was the value the 96-register kernels spilled onto the diagonal's path)
+    const float xdropf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)a.xdrop)));
     if constexpr (SPARSE) {
         for (int t = threadIdx.x; t < 21 * 6; t += C::THREADS) s_M4[t] = reinterpret_cast<const float4 *>(a.M24)[t];
     }
@@ -613,13 +614,13 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             float simNext[RPL];            // presim: the score of this row on the NEXT diagonal, loaded one diagonal ahead
             int simFor[RPL];               // ... and the diagonal it belongs to
             const int simK0 = ref_idx + qry_idx;   // global anti-diagonal of the tile's first cell
-            int blk[RPL];
+            int b0[RPL];                   // first row of the 64-row block this slot holds (a scalar: block index * 64)
             unsigned ra[RPL];              // byte address of this lane's reference column in plane 0 of the ring
             uint32_t tbacc[RPL];
             bool q5any[RPL];
 
             auto load_q = [&](int r) __attribute__((always_inline)) {
-                const int i = 64 * blk[r] + lane;
+                const int i = b0[r] + lane;
                 const bool ok = qry_idx + i < Q;
                 if constexpr (PRESIM) {
                     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -709,14 +710,14 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 }
             };
             auto ring_addr = [&](int r, int k) __attribute__((always_inline)) {      // ((k - 64*blk - lane) mod CAP) * 16
-                int rs = (k - 64 * blk[r] - lane) % CAP;
+                int rs = (k - b0[r] - lane) % CAP;
                 rs += (rs < 0) ? CAP : 0;
                 ra[r] = (unsigned)rs * 16u + lds_off(s_ring);
             };
 
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                blk[r] = r * W + w;
+                b0[r] = 64 * (r * W + w);
                 ring_addr(r, 0);
                 tbacc[r] = 0;
                 S1[r] = I1[r] = D1[r] = LS2[r] = -1.0f;       // never read before written for in-band cells
@@ -745,7 +746,12 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             unsigned vw1 = 0, vw2 = 0;
             int vwid1 = 0;                               // width of diagonal k-1 (0 when empty): the stale CD slot, see s_cd
             unsigned vcells = 0;                         // < 2^32 per tile
-            int Lk = 0, Uk = 0;
+            // Scalars of the band of diagonal k, read back once per diagonal: its low end, and what the activity test of a slot compares against --
+            // Lm63 = Lk - 63, W64 = Uk - Lk + 64 (a block takes part when 0 <= b - Lm63 <= W64; it has fallen out of the band when b - Lm63 < 0).
+            // Round 6: the high end itself is only formed where it is rare (hook, stop decoding, first row / column).
+            int Lk = 0, Wk = 0, Lm63 = -63, W64 = 64;
+            int kStop = 0;                               // the innermost loops run while k < kStop; whatever ends the tile also pulls it down
+            int kHook = 8;                               // the next k at which the every-8th-diagonal hook runs (a compare of two scalars per diagonal)
             float msp = -inf, convf = 0.0f;              // running maximum (:259), score at convergence (:594)
             bool converged = false;
             int conv_value = 0, prev_conv_s = -1;
@@ -782,9 +788,41 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 
             // One diagonal.  PH: 0 = A (k < marker-1), 1 = B (k == marker-1 or marker), 2 = C (k > marker).
             // Ends the loops by clearing `go`: tile_err on a stop condition, conv_logic when the tile ended by convergence (:609-612).
-            auto step = [&](auto PHtag) __attribute__((always_inline)) {
+            // GEN (round 6): true = the general step, which tests for the special diagonals (k == 0, tile 0's first row / column); false = the plain step the
+            // loops below switch to once `spec` has gone false for good: the test does not exist in it.  The every-8th-diagonal hook runs at the END of a step,
+            // behind the band update (until round 5 in front of the barrier, behind a five-instruction test).
+            auto stop_tile = [&]() __attribute__((always_inline)) { go = false; kStop = (int)0x80000000; };
+            auto hook = [&](auto PHtag) __attribute__((always_inline)) {
                 constexpr int PH = decltype(PHtag)::value;
+                constexpr bool TB = (PH != 2);
+                const int Uk = Lk + Wk;
+                if constexpr (TB) {
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r) {
+                        const int bb = b0[r];
+#if defined(TWL_TB_ALWAYS)      // experiment builds: every window row stores its word, as until round 4
+                        (void)bb;
+#else
+                        if (((tbMust >> r) & 1u) != 0u || (bb + 63 >= tbL0 && bb <= tbU0 + 8))
+#endif
+                            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
+                        tbacc[r] = 0;
+                    }
+                    tbMust = 0u; tbL0 = Lk; tbU0 = Uk;
+                    tbOff += (unsigned)WINDOW * 4u;
+                    tbPending = false;
+                }
+                // every 8th diagonal: stage the next 64 reference columns when the band gets within 10 + 64 columns of them (the ring has
+                // two blocks more than the window, so a block loaded this early never overwrites one still in use).  The hook runs behind the band update of
+                // diagonal k - 1, k already counted up: the columns are in LDS at the barrier of diagonal k, a diagonal before the next hook's range begins
+                const int need_hi = ((k + 10 - Lk) >> 6) + 1;
+                if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
+            };
+            auto step = [&](auto PHtag, auto GENtag) __attribute__((always_inline)) {
+                constexpr int PH = decltype(PHtag)::value;
+                constexpr bool GEN = decltype(GENtag)::value;
                 constexpr bool TB = (PH != 2), CONV = (PH != 0);
+                asm volatile("; TWL_STEP PH=%c0 GEN=%c1 (a comment: tools/isa_block_step.py finds the diagonal loops by it)" ::"n"(PH), "n"((int)GEN));
                 TWL_STAMP(t_head);
 #if defined(TWL_EXP_SALU)      // timing experiment: 24 extra scalar instructions per wave and diagonal
                 { int xs = k; 
@@ -798,35 +836,39 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                   asm volatile("" :: "v"(xv)); }
 #endif
                 const unsigned kk16 = (unsigned)(k + 1) << 16;                // tag of this diagonal's row reductions (k + 1 <= 65535)
-                const int width1 = Uk - Lk;
                 const unsigned vwidth1 = (unsigned)(vU - vL);
                 vcells += vwidth1 + 1u;
-                const float thr = __int_as_float(max(__float_as_int(msp), 0)) - xdropf;   // :495 with :607 (max(x, 0) of a float is max of its bits as an integer)
+                // :495 with :607 (max(x, 0) of a float is max of its bits as an integer).  The X-drop as a SCALAR operand (v_subrev: vsrc1 - src0): left to the
+                // compiler it sat in a vector register that the 96-register kernels reloaded from scratch at the head of every diagonal
+                float thr;
+                { const float m0 = __int_as_float(max(__float_as_int(msp), 0)); asm("v_subrev_f32_e32 %0, %1, %2" : "=v"(thr) : "s"(xdropf), "v"(m0)); }
                 bool special = false;
-                if (__builtin_expect(spec, 0)) {
-                    special = (k == 0) | ((tile == 0) && (Lk == 0 || Uk == k));
-                    spec = special;                                          // both conditions are monotone: once false, false for the tile
+                if constexpr (GEN) {
+                    if (__builtin_expect(spec, 0)) {
+                        special = (k == 0) | ((tile == 0) && (Lk == 0 || Lk + Wk == k));
+                        spec = special;                                      // both conditions are monotone: once false, false for the tile
+                    }
                 }
                 int staleCD = kDB;
                 if constexpr (PH == 2) staleCD = lds_ld<int>(vprev + 4u * (unsigned)vwid1 + O_CD);   // one broadcast read per diagonal
                 const unsigned vTrashRed = vcur + relTrashRed;
-                const int lkm63 = Lk - 63;
-                const unsigned wlim = (unsigned)(width1 + 64);
-                int nActSlots = 0;
 
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
-                    const int b = 64 * blk[r];
+                    const int b = b0[r];
+                    const int u = b - Lm63;
                     // the block takes part when the band touches it or will reach it on the next diagonal (its lane 0 then needs
                     // S[k-1][b-1] now, to have S[k-2][i-1] next time): Lk - 63 <= b <= Uk + 1
-                    if ((unsigned)(b - lkm63) <= wlim) {
+                    if ((unsigned)u <= (unsigned)W64) {
                         // a wave with cells to compute issues ahead of the idle waves of its SIMD (their per-diagonal bookkeeping otherwise sits
                         // in front of it: an active wave started its step up to 1100 cycles after the first wave of its SIMD); back to 0
                         // in front of the barrier, where the idle waves must not be held up -- keeping the priority across the barrier
                         // gave the gain away again.  Wide level 130 -> 121 ms, 100 pairs in tiles 8.2 -> 7.6 ms (tools/exp_step_cost.py).
                         // ... and a wave that enters a SECOND block of the same diagonal is the one its workgroup will wait for: top priority from there on
                         // (round 4, throughput launches: 2048 pairs of 10 kbp 95.8 -> 93.0 ms; in the tile jobs of the tile-parallel path the same cost 8 %: not there)
-                        if constexpr (MT == 0 && RPL >= 2) { if (nActSlots++ == 0) TWL_SETPRIO(2); else TWL_SETPRIO(3); }
+                        // (round 6: by slot index, not by a count of the active slots -- the count cost up to eight scalar instructions per diagonal; a wave whose
+                        //  only block sits in a later slot takes the top priority too, which it gives back at the barrier)
+                        if constexpr (MT == 0 && RPL >= 2) { if (r == 0) TWL_SETPRIO(2); else TWL_SETPRIO(3); }
                         else TWL_SETPRIO(2);
                         const int i = b + lane;
                         // ---- loads: mailbox of the previous block, reference column of this cell ----
@@ -1035,8 +1077,8 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         LS2[r] = LS1;
                         if constexpr (CONV) LCS2[r] = LCS1;
                     }
-                    if (__builtin_expect(b + 63 < Lk, 0)) {    // block fell out of the band: take the next one
-                        while (64 * blk[r] + 63 < Lk) blk[r] += NV;
+                    if (__builtin_expect(u < 0, 0)) {    // block fell out of the band (b + 63 < Lk): take the next one
+                        while (b0[r] + 63 < Lk) b0[r] += 64 * NV;
                         ring_addr(r, k);
                         load_q(r);
                         tbMust |= 1u << r;
@@ -1045,29 +1087,6 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     if (ra[r] == lds_off(s_ring) + CAP * 16u) ra[r] = lds_off(s_ring);
                 }
                 if constexpr (TB) tbPending = true;
-                const bool hook = ((k & 7) == 7 || (PH == 1 && k == marker));
-                if (hook) {
-                    if constexpr (TB) {
-#pragma unroll
-                        for (int r = 0; r < RPL; ++r) {
-                            const int bb = 64 * blk[r];
-#if defined(TWL_TB_ALWAYS)      // experiment builds: every window row stores its word, as until round 4
-                            (void)bb;
-#else
-                            if (((tbMust >> r) & 1u) != 0u || (bb + 63 >= tbL0 && bb <= tbU0 + 8))
-#endif
-                                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tb) + tbOff + (unsigned)(256 * (r * W + w))) = tbacc[r];
-                            tbacc[r] = 0;
-                        }
-                        tbMust = 0u; tbL0 = Lk; tbU0 = Uk;
-                        tbOff += (unsigned)WINDOW * 4u;
-                        tbPending = false;
-                    }
-                    // every 8th diagonal: stage the next 64 reference columns when the band gets within 8 + 64 columns of them (the ring has
-                    // two blocks more than the window, so a block loaded this early never overwrites one still in use)
-                    const int need_hi = ((k + 9 - Lk) >> 6) + 1;
-                    if (hiBlk < need_hi) { ++hiBlk; if (w == hiBlk % W) load_ring_block(hiBlk); }
-                }
                 TWL_STAMP(t_slots);
                 TWL_SETPRIO(0);
                 wg_barrier_lds();
@@ -1075,7 +1094,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                            // the barrier ahead of the idle ones (lone pair 1.72 -> 1.67 ms); with two workgroups per CU the same cost 6 %
                     bool anyBlk = false;
 #pragma unroll
-                    for (int r = 0; r < RPL; ++r) anyBlk |= ((unsigned)(64 * blk[r] - lkm63) <= wlim);
+                    for (int r = 0; r < RPL; ++r) anyBlk |= ((unsigned)(b0[r] - Lm63) <= (unsigned)W64);
                     if (anyBlk) TWL_SETPRIO(2);
                 }
                 TWL_STAMP(t_bar);
@@ -1115,7 +1134,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             const unsigned cw = (unsigned)(newU - newL);
 #pragma unroll
                             for (int r = 0; r < RPL; ++r) {
-                                const int i = 64 * blk[r] + lane;
+                                const int i = b0[r] + lane;
                                 const bool inr = (unsigned)(i - newL) <= cw;      // (no lane when the band is empty: both differences negative)
                                 const unsigned long long rm = __builtin_amdgcn_ballot_w64(inr);
                                 if (rm) {
@@ -1148,14 +1167,15 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     vL = max(max(newL, k + 2 - refLen), 0);
                     vU = min(newU + 1, qLen - 1);
                     Lk = __builtin_amdgcn_readfirstlane(vL);
-                    Uk = __builtin_amdgcn_readfirstlane(vU);
+                    Wk = __builtin_amdgcn_readfirstlane(vU - vL);
+                    Lm63 = Lk - 63; W64 = Wk + 64;
                     vcur ^= parx; vprev ^= parx;
                 }
 #ifdef TWL_KERNEL_STAMPS
                 {
                     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
                     st_slots += t_slots - t_head; st_bar += t_bar - t_slots; st_post += t_end - t_bar; st_n += 1;
-                    st_act += (64 * blk[0] <= Uk + 1 && 64 * blk[0] + 63 >= Lk) ? 1 : 0;
+                    st_act += (b0[0] <= Lk + Wk + 1 && b0[0] + 63 >= Lk) ? 1 : 0;
                     // timeline (tools/step_timeline.py): raw stamps of 96 diagonals of tile 4 from k = 600 (phase A) and from k = marker + 100 (phase C)
                     const int tlw = (k >= 600 && k < 696) ? k - 600 : ((k >= a.marker + 100 && k < a.marker + 196) ? 96 + k - a.marker - 100 : -1);
                     if (a.dbg && pair == 0 && tile == 4 && tlw >= 0 && lane == 0) {
@@ -1167,22 +1187,25 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 bool ended = false;
                 if constexpr (CONV) {
                     if (converged) {                                                               // :607-612: max(0, max') > score at convergence
-                        if (__builtin_amdgcn_ballot_w64(__int_as_float(max(__float_as_int(msp), 0)) > convf) != 0ull) { conv_logic = true; go = false; ended = true; }
+                        if (__builtin_amdgcn_ballot_w64(__int_as_float(max(__float_as_int(msp), 0)) > convf) != 0ull) { conv_logic = true; stop_tile(); ended = true; }
                     }
                 }
                 if (!ended) {
                     ++k;
+                    // the hook of the group of 8 diagonals that has just ended (and of the marker diagonal: the words up to it are what the traceback reads)
+                    if (k == kHook || (PH == 1 && k == marker + 1)) { hook(PHtag); kHook = (k & ~7) + 8; }
                     // stop conditions of the next diagonal (the reference tests them at its top, :323-338; not after the last one)
-                    if (__builtin_expect((unsigned)(Uk - Lk) >= (unsigned)fcap, 0)) {
+                    if (__builtin_expect((unsigned)Wk >= (unsigned)fcap, 0)) {
+                        const int Uk = Lk + Wk;
                         if (k >= kEnd) {}                                                            // (that was the last diagonal)
-                        else if (Lk > Uk) { tile_err = 1; go = false; }                                  // band emptied by X-drop
-                        else if (Uk - Lk + 1 > fLen) { tile_err = 2; go = false; }                  // wider than fLen
-                        else if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; go = false; }   // it really outgrew this window
+                        else if (Lk > Uk) { tile_err = 1; stop_tile(); }                                 // band emptied by X-drop
+                        else if (Uk - Lk + 1 > fLen) { tile_err = 2; stop_tile(); }                 // wider than fLen
+                        else if ((Uk >> 6) - (Lk >> 6) >= NV) { tile_err = kErrOverflow; stop_tile(); }  // it really outgrew this window
                         else {
                             // a band this wide can need the successor of a block on the diagonal the block leaves it: advance before the activity test
 #pragma unroll
                             for (int r = 0; r < RPL; ++r)
-                                if (64 * blk[r] + 63 < Lk) { while (64 * blk[r] + 63 < Lk) blk[r] += NV; ring_addr(r, k); load_q(r); tbMust |= 1u << r; }
+                                if (b0[r] + 63 < Lk) { while (b0[r] + 63 < Lk) b0[r] += 64 * NV; ring_addr(r, k); load_q(r); tbMust |= 1u << r; }
                         }
                     }
                 }
@@ -1194,6 +1217,17 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
 #endif
             {
                 using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+                // The diagonals k .. kLim - 1 of one phase (round 6).  Special diagonals first, on the general step; then the plain step, whose whole loop
+                // test is `k < kStop` (what ends the tile pulls kStop down).  The two marker diagonals (phase B) keep the general step.
+                auto run = [&](auto PHtag, int kLim) __attribute__((always_inline)) {
+                    constexpr int PH = decltype(PHtag)::value;
+                    if constexpr (PH == 1) { while (go && k < kLim) step(PHtag, std::true_type{}); }
+                    else {
+                        while (go && spec && k < kLim) step(PHtag, std::true_type{});
+                        kStop = go ? kLim : (int)0x80000000;
+                        while (k < kStop) step(PHtag, std::false_type{});
+                    }
+                };
                 const int kA = min(kEnd, marker - 1);
                 // SPEC, while the tile runs on a guess: every 32 diagonals one lane looks whether the partner has published the true start;
                 // the verdict goes through LDS so that every wave leaves the loop at the same diagonal
@@ -1220,11 +1254,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 if constexpr (SPEC) {
                     while (go && k < kA) {
                         const int kc = confirmed ? kA : min(kA, (k | 31) + 1);
-                        while (go && k < kc) step(T0{});
+                        run(T0{}, kc);
                         if (go && !confirmed) poll();
                     }
-                } else
-                while (go && k < kA) step(T0{});
+                } else run(T0{}, kA);
                 const int kB = min(kEnd, marker + 1);
                 // (set here rather than with the tile: through phase A these are constants, not live registers; :306-308)
 #pragma unroll
@@ -1236,7 +1269,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         if (sres == 0) confirmed = true; else { go = false; aborted = true; }
                     }
                 }
-                while (go && k < kB) step(T1{});
+                run(T1{}, kB);
                 if constexpr (SPEC) {
                     if (go && k == marker + 1 && k < kEnd) {     // both marker diagonals are done: tell the partner where the next tile probably starts
                         if (threadIdx.x == 0) {
@@ -1266,7 +1299,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     }
                 }
                 const int kCap = min(kEnd, 65534);      // k + 1 must fit the 16-bit tag
-                while (go && k < kCap) step(T2{});
+                run(T2{}, kCap);
                 if (go && k < kEnd) { tile_err = kErrOverflow; go = false; }      // (never seen: tiles converge within ~1.5 markers)
                 if constexpr (SPEC) {
                     if (aborted || !confirmed) {
@@ -1288,7 +1321,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             const int lo1 = __builtin_amdgcn_readfirstlane(vlo1);
 
             cells += tile_cells;
-            dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Uk;
+            dbg_lastk = last_k; dbg_conv = conv_value; dbg_L = Lk; dbg_U = Lk + Wk;
             if (tile_err != 0) { err = tile_err; break; }
             // a profile entry outside fast_div's range: the IEEE-division kernel re-runs the pair (every wave saw different columns:
             // the verdict goes through LDS so that all of them leave together)
@@ -1314,7 +1347,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 const int Llast = lo1;
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
-                    const int b = 64 * blk[r];
+                    const int b = b0[r];
                     if (Llast >= b && Llast <= b + 63 && lane == Llast - b) s_misc[1] = CS1[r];
                 }
                 __syncthreads();
@@ -1367,7 +1400,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                     uint32_t *s_patch = reinterpret_cast<uint32_t *>(s_ring);
                     int kk2 = start_k, ii = conv_q, qi = conv_q, ri = conv_r, st = tb_state % 3;
                     const bool first = (tile == 0);
-                    bool done = (kk2 < 0);
+                    bool done = (kk2 < 0), walkBad = false;
                     while (!done) {
                         const int g0 = kk2 >> 3, i0 = ii;
                         const int row = i0 - 63 + lane;
@@ -1385,6 +1418,10 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 if (t >= PG || l < 0) break;                      // the path left the patch
                                 const uint32_t word = s_patch[t * 64 + l];
                                 const int v = (int)((word >> (4 * (kk2 & 7))) & 0xFu);
+                                // state bits 3 are never written by the DP (:548-557 has 0, 1, 2): a word that was skipped although the path runs through it -- the
+                                // conditional store of the hook rests on the hook cadence and the band update -- reads as poison (TWL_KNOB_POISON_TB: 0xF) and ends
+                                // the pair with the "bug" code instead of a wrong path
+                                if ((v & 3) == 3) { walkBad = true; done = true; break; }
                                 int dir;
                                 if (st == 0) {
                                     st = v & 3;
@@ -1412,6 +1449,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                         done = __builtin_amdgcn_readfirstlane((int)done) != 0;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the walk's reads, before the next patch overwrites them
                     }
+                    if (__builtin_amdgcn_readfirstlane((int)walkBad) != 0) err = 3;
                     if (lane == 0 && first && MT != 4) {
                         while (ri > -1) { s_rev[n++] = 2; ri--; }
                         while (qi > -1) { s_rev[n++] = 1; qi--; }
@@ -1421,7 +1459,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                 const int skip = (tile > 0) ? 1 : 0;                          // :98-102
                 const int cnt = n - skip;
                 if constexpr (MT == 1) {          // the segment and the record of this tile (read by the stitch launch)
-                    if (cnt <= a.mt_segcap) {
+                    if (err == 0 && cnt <= a.mt_segcap) {
                         for (int t = lane; t < cnt; t += 64) out[t] = s_rev[n - 1 - skip - t];
                         if (lane == 0) {
                             int32_t *rc = a.mt_rec + ((size_t)mtx * a.mt_slots + slot) * kMtRec;

@@ -102,6 +102,7 @@ struct Device {
     hipEvent_t ev[8] = {};                                                       // [6], [7]: the write-back of a level (twl_level_commit, read later by twl_level_timing)
     int num_cu = 0;
     Buf cols, tb, cells, queue, items, errs, dbg;
+    Buf gtb;                                                                     // scratch of the global-memory kernel (DP rows + pointer bytes of its pairs): its own buffer, handed back after the stage when large
     Buf sim, sim_off, blk_off, m24;                                              // precomputed protein scores (matrix mode 4)
     Buf team;                                                                    // mailboxes of the speculative tile start
     Buf mt_chain, mt_rec, mt_seg, mt_spath, mt_stat, mt_jobs, mt_anchor;                    // tile-parallel alignment (talco_nuc.hip.h, MT kernels)
@@ -652,6 +653,8 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     for (int32_t n = 0; n < n_pairs; ++n) { d->pair_cells[n] = cells[n]; total += cells[n]; }
     if (ranMt || redoMt) { d->stats.mt_tiles_predicted = (int32_t)mtStat[0]; d->stats.mt_tiles_inline = (int32_t)mtStat[1]; d->stats.mt_scouts_failed = (int32_t)mtStat[2]; }
     d->last_err = h_err;      // (twl_level_align hands them to its caller without another copy)
+    // the global-memory kernel's scratch does not stay next to a resident store for the rest of the run (every launch of the call has been waited for)
+    if (d->gtb.cap > ((size_t)256 << 20)) d->gtb.release();
     if (want_dbg) {
         d->dbg_host.resize((size_t)n_pairs * 16);
         HIP_TRY(hipMemcpy(d->dbg_host.data(), d->dbg.p, d->dbg_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -684,7 +687,12 @@ const char *twl_last_error(void) { return g_err.c_str(); }
 #ifndef TWL_SOURCE_HASH
 #define TWL_SOURCE_HASH "unstamped"
 #endif
-const char *twl_version(void) { return "twilight_amd 0.4 (gfx950) src " TWL_SOURCE_HASH; }      // (the hash of the kernel sources: __graft_entry__.source_hash)
+#ifndef TWL_BUILD_STAMP
+#define TWL_BUILD_STAMP "unstamped"
+#endif
+// digest of every source, header and flag of this build: __graft_entry__.build() looks for it in the file and rebuilds when it is another
+__attribute__((used)) static const char twl_build_stamp[] = "TWLSTAMP:" TWL_BUILD_STAMP ";";
+const char *twl_version(void) { return "twilight_amd 0.5 (gfx950) src " TWL_SOURCE_HASH; }      // (the hash of the kernel sources: __graft_entry__.source_hash)
 
 int twl_init(const int *device_ids, int n_devices)
 {
@@ -748,7 +756,7 @@ void twl_shutdown(void)
         twl_level_pool_release(d);
         if (d->comm) { comm_destroy_raw(d->comm); d->comm = nullptr; }
         d->comm_send.release(); d->comm_recv.release();
-        for (Buf *b : {&d->cols, &d->tb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs, &d->mt_anchor, &d->gc_zero,
+        for (Buf *b : {&d->cols, &d->tb, &d->gtb, &d->cells, &d->queue, &d->items, &d->errs, &d->dbg, &d->sim, &d->sim_off, &d->blk_off, &d->m24, &d->team, &d->simdump, &d->mt_chain, &d->mt_rec, &d->mt_seg, &d->mt_spath, &d->mt_stat, &d->mt_jobs, &d->mt_anchor, &d->gc_zero,
                        &d->h2d_freq, &d->h2d_gop, &d->h2d_gex, &d->h2d_len, &d->h2d_num, &d->d_aln, &d->d_alnlen, &d->d_err})
             b->release();
         for (auto &e : d->ev) if (e) (void)hipEventDestroy(e);

@@ -3,7 +3,7 @@
 
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
-int g_mt_anchor = 1, g_mt_lead2 = 96;      // twl_set_knob(TWL_KNOB_MT_ANCHOR / TWL_KNOB_MT_LEAD2): nucleotide scouts start from the cell the profiles' consensus letters point at, this many anti-diagonals ahead (talco_nuc.hip.h, mt_anchor_kernel)
+int g_mt_anchor = 1, g_mt_lead2 = 96;      // twl_set_knob(TWL_KNOB_MT_ANCHOR / TWL_KNOB_MT_LEAD2): scouts (either alphabet) start from the cell the profiles' consensus letters point at, this many anti-diagonals ahead (talco_nuc.hip.h, mt_anchor_kernel)
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
 int g_scout_xdrop_pct = 100;         // twl_set_knob(TWL_KNOB_SCOUT_XDROP_PCT): X-drop of the pair scouts in percent of the call's (they only predict: a narrower band is a cheaper scout)
 int g_no_spec = 0;                   // twl_set_knob(TWL_KNOB_NO_SPEC): no speculative two-workgroup teams (tools that time the plain tile loop)

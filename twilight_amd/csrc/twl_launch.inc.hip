@@ -67,14 +67,18 @@ int launch_global(Device *d, hipStream_t st, const twl::KArgs &base, const int32
     const size_t rowcap = (size_t)std::min(std::max(base.flen, 1), std::max(seq_len, 1)) + 2;
     const size_t words = 14 * rowcap + (((size_t)base.marker + 2) * rowcap + 3) / 4;
     const size_t budget = (size_t)4 << 30;
+    // one pair's scratch may not be larger than the budget either: refused (the caller sees TWL_ERR_UNSUPPORTED), not silently pinned in HBM
+    if (words * sizeof(uint32_t) > budget) { g_err = "a pair whose band needs more than 4 GiB of scratch in the global-memory kernel"; return TWL_ERR_UNSUPPORTED; }
     int grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_items, budget / (words * sizeof(uint32_t))));
     grid = std::min(grid, d->num_cu);
-    int rc = d->tb.ensure(words * sizeof(uint32_t) * (size_t)grid);
+    // a buffer of its own, handed back after the stage (run_device: release_global_scratch): d->tb lives until twl_shutdown and a single retry of the deferred
+    // pass would otherwise pin several GiB next to the resident store for the rest of the run
+    int rc = d->gtb.ensure(words * sizeof(uint32_t) * (size_t)grid);
     if (rc) return rc;
-    if (g_poison_tb) HIP_TRY(hipMemsetAsync(d->tb.p, 0xFF, words * sizeof(uint32_t) * (size_t)grid, st));
+    if (g_poison_tb) HIP_TRY(hipMemsetAsync(d->gtb.p, 0xFF, words * sizeof(uint32_t) * (size_t)grid, st));
     twl::GArgs g;
     g.k = base;
-    g.k.tb = (uint32_t *)d->tb.p;
+    g.k.tb = (uint32_t *)d->gtb.p;
     g.k.tb_words = (int32_t)words;
     if ((size_t)g.k.tb_words != words) { g_err = "a pair too long for the global-memory kernel's scratch index"; return TWL_ERR_UNSUPPORTED; }
     g.k.items = d_items;

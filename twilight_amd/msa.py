@@ -20,7 +20,7 @@ class MsaLevel(C.Structure):
 class MsaTotals(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("aln_len", C.c_int32), ("n_sequences", C.c_int32), ("reserved", C.c_int32),
                 ("pairs", C.c_uint64), ("band_cells", C.c_uint64), ("relaunched", C.c_uint64),
-                ("kernel_ms", C.c_double), ("exchange_ms", C.c_double), ("align_s", C.c_double)]
+                ("kernel_ms", C.c_double), ("exchange_ms", C.c_double), ("align_s", C.c_double), ("nominal_cells", C.c_uint64)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
