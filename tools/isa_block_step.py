@@ -36,6 +36,24 @@ def kind(ins):
     return "other"
 
 
+FAST = re.compile(r"^v_(add|sub|subrev|mul|fma|fmac|mac|mad|mov)_(f32|b32)(_e32|_e64)?$")
+
+
+def valu_units(ins):
+    """Issue cost of a vector instruction in units of one full-rate fp32 instruction, as tools/micro/issue_rates5.hip measured it on MI355X at the occupancy of the
+    throughput kernels (profiles/r06/issue_rates5.log): fp32 add / mul / fma / mov on vector registers and inline constants 3.6-3.8 per ns and CU (1 unit); anything with
+    an SGPR operand, every integer, compare, select and DPP form 2.15-2.27 (1.7 units); packed fp32 1.85 (2 units, two operations)."""
+    op, _, rest = ins.partition(" ")
+    if op.startswith("v_pk_"): return 2.0
+    if "dpp" in ins or "sdwa" in ins: return 1.7
+    if FAST.match(op):
+        ops = [o.strip() for o in rest.split(",")]
+        if any(re.match(r"^-?\|?(s\d+|s\[|vcc|exec|m0|ttmp)", o) for o in ops[1:]): return 1.7      # a scalar register among the sources
+        if any(re.match(r"^(0x[0-9a-f]+|-?\d{3,})$", o) for o in ops[1:]): return 1.7                   # a 32-bit literal (not an inline constant)
+        return 1.0
+    return 1.7
+
+
 def main():
     targs = sys.argv[1]
     out_dir = sys.argv[2] if len(sys.argv) > 2 else "."
@@ -76,6 +94,7 @@ def main():
         for ins in b["ins"]:
             c[kind(ins)] = c.get(kind(ins), 0) + 1
         b["count"] = c
+        b["units"] = round(sum(valu_units(i) for i in b["ins"] if kind(i) == "valu"), 1)
         for kk, v in c.items():
             tot[kk] = tot.get(kk, 0) + v
     tag = re.sub(r"[^0-9a-z]+", "_", targs.lower()).strip("_")
@@ -83,10 +102,10 @@ def main():
     with open(os.path.join(out_dir, f"isa_step_{tag}.s"), "w") as f:
         f.write(f"; talco_lean_kernel{targs}: the phase-A loop (one anti-diagonal per iteration), basic blocks with instruction counts -- tools/isa_block_step.py\n")
         for b in blocks:
-            f.write(f"; ---- {b['label']}: {sum(b['count'].values())} instructions {json.dumps(b['count'])}\n")
+            f.write(f"; ---- {b['label']}: {sum(b['count'].values())} instructions {json.dumps(b['count'])}, {b['units']} VALU units\n")
             for ins in b["ins"]:
                 f.write("\t" + ins + "\n")
-    print(json.dumps({"kernel": "talco_lean_kernel" + targs, "loop_text_instructions": sum(tot.values()), "by_kind": tot, "basic_blocks": len(blocks),
+    print(json.dumps({"kernel": "talco_lean_kernel" + targs, "loop_text_instructions": sum(tot.values()), "by_kind": tot, "valu_units_text": round(sum(b["units"] for b in blocks), 1), "basic_blocks": len(blocks),
                       "listing": f"isa_step_{tag}.s"}))
 
 

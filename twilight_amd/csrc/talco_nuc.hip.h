@@ -606,6 +606,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             // one unsigned compare per step covers "band empty", "wider than fLen" and (conservatively) "outgrew the window"
             // (two blocks of margin: below it a block that leaves the band cannot be needed again on the same diagonal)
             const int fcap = min(fLen, 64 * (NV - 2));
+            // the nucleotide matrix values of mode 2 (match / transition / transversion) in vector registers: see the column score of the geometries that form the first products per cell
+            float vmA = a.M[0], vmB = a.M[2], vmC = a.M[1];
+            asm volatile("" : "+v"(vmA), "+v"(vmB), "+v"(vmC));
             // ---- per-slot state ----
             float S1[RPL], I1[RPL], D1[RPL], LS2[RPL];
             int CS1[RPL], CI1[RPL], CD1[RPL], LCS2[RPL];
@@ -896,9 +899,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 s01 = qP[r][0] * r01; s23 = qP[r][1] * r23;
 #pragma unroll
                                 for (int m = 1; m < NM; ++m) { s01 = s01 + qP[r][2 * m] * r01; s23 = s23 + qP[r][2 * m + 1] * r23; }
-                            } else {      // the first products of this row formed here (see QPRE): same operations, same order
+#if defined(TWL_EXP_PACKED_SCORE)      // experiment builds: the packed form of rounds 4-5 (matrix values as scalar operands, v_pk_mul / v_pk_add)
+                            } else if constexpr (true) {
                                 const float mA = a.M[0], mB = a.M[2], mC = a.M[1];
-                                // (two plain multiplies: as ONE packed multiply -- q[m] in both halves, the matrix entries a scalar pair -- the wide level ran 4 % slower, round 4)
                                 auto fp = [&](int m, int h) __attribute__((always_inline)) {
                                     const int l0 = 2 * h, l1 = 2 * h + 1;
                                     return nuc_f2{qv[r][m] * ((l0 == m) ? mA : (((l0 ^ m) == 2) ? mB : mC)), qv[r][m] * ((l1 == m) ? mA : (((l1 ^ m) == 2) ? mB : mC))};
@@ -906,6 +909,23 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                                 s01 = fp(0, 0) * r01; s23 = fp(0, 1) * r23;
 #pragma unroll
                                 for (int m = 1; m < 4; ++m) { s01 = s01 + fp(m, 0) * r01; s23 = s23 + fp(m, 1) * r23; }
+#endif
+                            } else {      // the first products of this row formed here (see QPRE): same operations, same order
+                                // Round 6: as plain fp32 operations on VECTOR registers.  Measured (tools/micro/issue_rates5.hip, profiles/r06/issue_rates5.log): an fp32
+                                // add / mul / fma on vector registers issues at 3.6-3.8 per ns and CU, the same multiply with a scalar register as an operand at 2.2 (as
+                                // does every integer, compare, select and DPP form), a packed one at 1.85.  The three matrix values live in vector registers
+                                // (vmA / vmB / vmC), the twelve distinct first products q[m] * M and the sixteen second products are plain multiplies: 43 full-rate
+                                // instructions where sixteen scalar-operand multiplies and fourteen packed ones stood.  Same operations in the same order;
+                                // 2048 pairs of 10 kbp profiles 91.2 -> 86.5 ms (profiles/r06/exp_step_variants.txt)
+                                auto mv = [&](int l, int m) __attribute__((always_inline)) { return (l == m) ? vmA : (((l ^ m) == 2) ? vmB : vmC); };
+                                float sl[4];
+#pragma unroll
+                                for (int l = 0; l < 4; ++l) {
+                                    sl[l] = (qv[r][0] * mv(l, 0)) * rc[l];
+#pragma unroll
+                                    for (int m = 1; m < 4; ++m) sl[l] = sl[l] + (qv[r][m] * mv(l, m)) * rc[l];
+                                }
+                                s01 = nuc_f2{sl[0], sl[1]}; s23 = nuc_f2{sl[2], sl[3]};
                             }
                             numer = ((s01.x + s01.y) + s23.x) + s23.y;
                             if constexpr (MM == 0) {
