@@ -50,8 +50,13 @@ CONFIGS = {
     "rnasim1k_band512": dict(kind="level", pairs=320, length=1600, type="n", P=6, bcell=64, flen=512, xdrop=4000,
                              name="RNASim-shaped 1k seqs x 1.6 kbp: the leaf level (320 sibling pairs) as ONE batch, fLen 512 / xdrop 4000 (BASELINE configs[1])"),
 }
-PMC = os.path.join(ROOT, "profiles", "r05", "bench_pmc_summary.json")
-ISA = os.path.join(ROOT, "profiles", "r05", "isa_block_step.json")      # static instruction counts of a block step, from the disassembly (tools/isa_block_step.py)
+PROF = "r06"
+ISA = os.path.join(ROOT, "profiles", PROF, "isa_block_step.json")      # static instruction counts / VALU units of a block step, from the disassembly (tools/isa_block_step.py --all)
+
+
+def pmc_path(config, workload):
+    """Counters of the bench command of this configuration, taken on the same kernel sources (tools/final_profiles.sh)."""
+    return os.path.join(ROOT, "profiles", PROF, "bench_pmc_summary.json" if (config == "rnasim10k" and workload == "calibrated") else f"{config}_pmc_summary.json")
 
 
 def parse():
@@ -217,7 +222,7 @@ def peak_level(twl, dev, local_rank, cfg, pairs=2048, pool=512, reps=3, warm=1, 
     out = {"pairs": pairs, "seq_len": sl, "band_cells_per_launch": int(cells // reps), "nominal_cells_per_launch": nominal, "kernel_ms_per_launch": kms / reps,
            "cells_per_s": cells / (kms * 1e-3), "frac_of_hbm_roofline": cells * cfg["bcell"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "deferred_pairs": int((err != 0).sum().item()), "relaunched_pairs": int(st.n_relaunched), "window_rows": int(st.window),
-           "persistent_workgroups": int(st.grid), "timed_s": timed_s,
+           "persistent_workgroups": int(st.grid), "timed_s": timed_s, "kernel": st.kernel.decode(),
            "workload": f"{pairs} sibling pairs of ~{length}-column profiles (1-8 member sequences per side, weighted counts, PSGP gap penalties), "
                        f"{pool} distinct pairs replicated"}
     k = min(pairs, pool)
@@ -522,20 +527,21 @@ def main():
         traffic = issue = None
         pmc_ok, pmc_note, pmc_tb_share = None, None, None
         try:
+            PMC = pmc_path(args.config, args.workload)
             pmc = json.load(open(PMC))
             lib_hash = (twl.version().split("src ")[-1] if hasattr(twl, "version") else "")
-            pmc_ok = (pmc.get("source_hash") == lib_hash) and args.config == "rnasim10k" and args.workload == "calibrated"
+            pmc_ok = (pmc.get("source_hash") == lib_hash) and args.workload == "calibrated"
             if not pmc_ok:
-                pmc_note = (f"counters withheld: profiles/r05/bench_pmc_summary.json was taken on kernel sources {pmc.get('source_hash')} for the default configuration, "
+                pmc_note = (f"counters withheld: profiles/r06/<config>_pmc_summary.json was taken on kernel sources {pmc.get('source_hash')} for the default configuration, "
                             f"this run is {lib_hash} / {args.config} / {args.workload}")
             else:
-                pmc_note = ("profiles/r05/bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, bytes per pass; "
+                pmc_note = ("profiles/r06/<config>_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, bytes per pass; "
                             "FETCH_SIZE doubled per MI355X_MICROARCH.md)")
                 traffic = pmc["hbm_per_pass"]["traffic_bytes"]
                 pmc_tb_share = pmc["hbm_per_pass"]["write_bytes"] / pmc["hbm_per_pass"]["traffic_bytes"]
                 # per kernel of the profiled run: VALU issue slots used (a wave's VALU instruction holds its SIMD-32 for 2 cycles), scalar instructions per
                 # cycle and CU (the scalar unit retires ~1), wave-cycles spent waiting, and the HBM rate the counters saw
-                issue = {"source": "profiles/r05/bench_pmc_summary.json (tools/summarize_pmc.py: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAIT_ANY / SQ_WAVE_CYCLES / "
+                issue = {"source": "profiles/r06/<config>_pmc_summary.json (tools/summarize_pmc.py: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAIT_ANY / SQ_WAVE_CYCLES / "
                                    "FETCH_SIZE / WRITE_SIZE passes and the kernel trace of this command)",
                          "ceiling": "issue_frac_of_measured_ceiling = instructions of every kind issued per ns and CU / 3.97 (the measured ceiling); valu_issue_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time), the figure VERDICT round 4 asked for (a vector instruction holds its SIMD at least 2 cycles; compares, selects and integer forms hold it ~4.5)",
                          "kernels": [{"kernel": k.replace("void twl::", "").replace("(twl::NArgs)", ""), **{f: round(float(v[f]), 4) for f in
@@ -548,35 +554,43 @@ def main():
         # ---- the roofline of this path: INSTRUCTION ISSUE ----
         # A CU issues at most ~3.97 instructions per ns over its four SIMDs whatever their kind (tools/micro/issue_rates.hip, profiles/r02/issue_rates.log:
         # 16 waves of interleaved vector and scalar instructions; vector alone 3.88, scalar alone 2.27) -- measured, so no clock enters.  One 64-row block on
-        # one anti-diagonal costs a wave a fixed number of instructions, counted in the disassembly (profiles/r05/isa_block_step.json + the listings next to
+        # one anti-diagonal costs a wave a fixed number of instructions, counted in the disassembly (profiles/r06/isa_block_step.json + the listings next to
         # it).  peak = the cells/s at which every issue slot of the chip would carry a block-step instruction (of the dominant kernel's step) and every lane a band cell;
         # achieved = band cells of a pass / DP-kernel time of a pass (HIP events of the library around every DP launch, live in this run; the rocprofv3 trace of the
-        # same command gives the same time: sum of the talco_* rows of profiles/r05/bench_kernel_stats.csv / passes);
+        # same command gives the same time: sum of the talco_* rows of profiles/r06/bench_kernel_stats.csv / passes);
         # frac = achieved / peak <= 1.  What separates them: lanes of a block outside the band (~16 %), the per-diagonal bookkeeping every wave runs
         # (~60 instructions: barrier, band update), idle issue slots while a workgroup's waves wait for each other.
         isa, isa_note, peak_cells, step_ins, ceiling = None, None, None, None, None
+        step_units, valu_cap, peak_issue = None, None, None
         try:
             isa = json.load(open(ISA))
             ceiling = isa["issue_ceiling"]["instr_per_ns_per_cu"] * 1e9 * num_cu
+            valu_cap = isa["valu_ceiling"]["units_per_ns_per_cu"] * 1e9 * num_cu
             if isa.get("source_hash") != (lib_ver.split("src ")[-1] if lib_ver else ""):
                 isa_note = f"static counts are of kernel sources {isa.get('source_hash')}, this library is {lib_ver}"
-            if dom:
-                key = next((k for k in sorted(isa["kernels"], key=len, reverse=True) if k in dom["kernel"]), None)
+            dk = dom["kernel"] if dom else (peak or {}).get("kernel")
+            if dk:
+                key = next((k for k in sorted(isa["kernels"], key=len, reverse=True) if k in dk), None)
                 if key is None:
-                    isa_note = (isa_note + "; " if isa_note else "") + f"no static count for {dom['kernel']} (profiles/r05/isa_block_step.json holds the nucleotide throughput kernels): frac not formed"
+                    isa_note = (isa_note + "; " if isa_note else "") + f"no static count for {dk} in profiles/r06/isa_block_step.json: frac not formed"
                 if key:
                     # (one-letter query rows with single-sequence references have neither gap letters nor a denominator: the leaf level; everything else pays both)
-                    which = "no_gap_letters_denominator_1" if ", 5, 5, false" in key else "profiles_with_gap_letters_and_division"
-                    step_ins = isa["kernels"][key]["block_step"][which]
-                    peak_cells = ceiling * 64.0 / step_ins
+                    which = "least" if ", 5, 5, false" in key else "all_paths"
+                    s0 = isa["kernels"][key]["phase_A"]["slot0"][which]
+                    step_ins, step_units = s0["instructions"], s0["valu_units"]
+                    peak_cells = valu_cap * 64.0 / step_units
+                    peak_issue = ceiling * 64.0 / step_ins
         except Exception as ex:  # noqa: BLE001
             isa_note = f"no static counts: {ex}"
         dom_cells_per_s = (dom["cells_per_launch"] / (dom["avg_ms"] * 1e-3)) if dom and dom["avg_ms"] > 0 else None
         out["roofline"] = {
-            "bound": "issue", "achieved": (cells / (kernel_ms * 1e-3)) if kernel_ms > 0 else None, "peak": peak_cells, "unit": "cells/s",
+            "bound": "valu", "achieved": (cells / (kernel_ms * 1e-3)) if kernel_ms > 0 else None, "peak": peak_cells, "unit": "cells/s",
             "frac": (cells / (kernel_ms * 1e-3) / peak_cells) if (kernel_ms > 0 and peak_cells) else None,
             "frac_levels_of_dominant_kernel": (dom_cells_per_s / peak_cells) if (dom_cells_per_s and peak_cells) else None,
-            "issue_ceiling_instr_per_s": ceiling, "instructions_per_block_step": step_ins, "cells_per_block_step": 64, "static_counts": "profiles/r05/isa_block_step.json",
+            "valu_ceiling_units_per_s": valu_cap, "valu_units_per_block_step": step_units, "cells_per_block_step": 64, "static_counts": "profiles/r06/isa_block_step.json",
+            # round 5's definition, kept beside it: every issue slot of the chip (3.97 instructions per ns and CU of any kind) carrying an instruction of the block step
+            "frac_total_issue": (cells / (kernel_ms * 1e-3) / peak_issue) if (kernel_ms > 0 and peak_issue) else None,
+            "issue_ceiling_instr_per_s": ceiling, "instructions_per_block_step": step_ins,
             "static_counts_note": isa_note,
             # fp32 VALU utilisation = F_cell x band cells / DP-kernel time against the fp32 vector peak (FMA counted as 2: bit-exactness forbids
             # FMA here -- TALCO-XDrop.cpp:378-395 rounds every product and sum -- so half of that peak is out of reach by construction)
@@ -598,9 +612,11 @@ def main():
             "issue": issue,
             "algorithmic_bytes_per_cell": bcell, "cells": int(cells // steps), "kernel_ms": kernel_ms / steps,
             "dominant_kernel": dom, "kernels": kernels,
-            "note": "what binds this path is instruction issue along the anti-diagonal chain, so `frac` is measured against the chip's instruction-issue ceiling: band cells of a pass / "
-                    "DP-kernel time of a pass / (256 CUs x 3.97e9 instructions/s x 64 cells / instructions of the dominant kernel's block step); `frac_levels_of_dominant_kernel` = "
-                    "the same for the levels that start on the dominant kernel alone.  `contract_frac` keeps the figure of BASELINE.md section 3 -- band "
+            "note": "what binds this path is the VECTOR unit (round 6: tools/micro/issue_rates5.hip -- an fp32 add / mul / fma on vector registers issues at 3.6-3.8 per ns and CU, every "
+                    "integer, compare, select, DPP or scalar-operand form at 2.15-2.27, packed fp32 at 1.85; 70 % of the step is of the slow kinds, and weighted that way the vector unit of a "
+                    "CU is ~90 % busy in the throughput kernels), so `frac` = band cells of a pass / DP-kernel time of a pass / (256 CUs x 3.7e9 full-rate vector instructions/s x 64 cells / "
+                    "VALU units of the dominant kernel's block step, counted in its disassembly with those weights); `frac_total_issue` = round 5's definition (3.97e9 instructions of any kind, "
+                    "instructions of the block step); `frac_levels_of_dominant_kernel` = `frac` for the levels that start on the dominant kernel alone.  `contract_frac` keeps the figure of BASELINE.md section 3 -- band "
                     "cells x 64 (192) operand bytes / DP-kernel time over ALL launches of a pass against 8 TB/s; that operand stream is notional (columns are reused from LDS / registers), "
                     "so it exceeds 1 and measures nothing.  Real HBM traffic (`traffic`, counters) is ~1.1 B per cell, most of it traceback words; compulsory 0.07 B per cell.  "
                     "`issue` = the counters of the profiled run per kernel.  DESIGN.md section 3",

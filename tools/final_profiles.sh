@@ -1,16 +1,14 @@
-# Round-5 evidence under gpurun_out/prof_r05 (copied to profiles/r05 by hand): bash tools/final_profiles.sh   (GPU box)
+# Round-6 evidence under gpurun_out/prof_r06 (copied to profiles/r06 by tools/copy_profiles.sh): bash tools/final_profiles.sh   (GPU box)
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r05
+O=gpurun_out/prof_r06
 mkdir -p $O
+# the default configuration: kernel trace + the four counter passes of the bench command
 bash tools/profile_bench.sh $O/pmc --no-survey8d > $O/pmc.log 2>&1
-cd /tmp && export TMPDIR=/tmp
-for c in protein5k rnasim100k; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/kt_$c -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --config $c --no-cpu --no-peak --no-e2e > $GRAFT_REPO_ROOT/$O/${c}_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/${c}.err
-  find $GRAFT_REPO_ROOT/$O/kt_$c -name "*kernel_stats.csv" -exec cp {} $GRAFT_REPO_ROOT/$O/${c}_kernel_stats.csv \;
-  rm -rf $GRAFT_REPO_ROOT/$O/kt_$c
-done
-cd $GRAFT_REPO_ROOT
+# the other BASELINE configurations: kernel trace + the same counter passes
+bash tools/profile_bench.sh $O/pmc_protein5k --config protein5k > $O/pmc_protein5k.log 2>&1
+bash tools/profile_bench.sh $O/pmc_rnasim100k --config rnasim100k > $O/pmc_rnasim100k.log 2>&1
+for c in pmc pmc_protein5k pmc_rnasim100k; do rm -rf $O/$c/kt $O/$c/p1 $O/$c/p2 $O/$c/p3 $O/$c/p4; done
 python bench.py > $O/bench_line_default.json 2> $O/bench_line_default.err
 python bench.py --config protein5k --no-e2e > $O/bench_line_protein5k.json 2>/dev/null
 python bench.py --config rnasim100k --no-cpu --no-peak --no-e2e > $O/bench_line_rnasim100k.json 2>/dev/null

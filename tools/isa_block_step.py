@@ -109,5 +109,125 @@ def main():
                       "listing": f"isa_step_{tag}.s"}))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--all"):
     main()
+
+
+# ---- round 6: the summary of every kernel the bench configurations are dominated by, in one file (profiles/r06/isa_block_step.json) ----
+KERNELS = {
+    "talco_lean_kernel<6, 4, 2, 2, 5, false, false, 0>": "throughput, 512-row window, profiles (levels 2+ of the nucleotide configurations)",
+    "talco_lean_kernel<6, 4, 2, 5, 5, false, false, 0>": "throughput, 512-row window, one-letter query rows",
+    "talco_lean_kernel<6, 4, 2, 5, 5, false, false, 0, 1>": "throughput, 512-row window, the leaf x leaf step (SP 1)",
+    "talco_lean_kernel<6, 4, 3, 2, 4, false, false, 0>": "throughput, 768-row window",
+    "talco_lean_kernel<6, 4, 3, 2, 4, false, false, 1>": "tile jobs on the 768-row throughput geometry",
+    "talco_lean_kernel<6, 4, 2, 2, 5, false, false, 1>": "tile jobs on the 512-row throughput geometry",
+    "talco_lean_kernel<6, 16, 1, 2, 1, false, false, 1>": "tile jobs on the latency geometry",
+    "talco_lean_kernel<22, 8, 1, 3, 4, false, false, 0>": "protein throughput: the loop over the non-zero letters of the reference column, counted for ONE letter per column (the least a column can hold)",
+    "talco_lean_kernel<22, 16, 1, 4, 1, false, false, 1>": "protein tile jobs on precomputed scores",
+    "talco_lean_kernel<22, 8, 1, 4, 4, false, false, 1>": "protein tile jobs on precomputed scores, throughput geometry",
+}
+
+
+def slot_summary(blocks):
+    """Slot 0 of the loop = the blocks from the one that raises the wave's priority (the first instruction of an active block) to the one in front of the next such block
+    (or of the barrier).  `optional` = blocks a forward conditional branch inside the slot jumps over (gap-letter terms, division): left out of the `least` sums."""
+    idx = {b["label"]: i for i, b in enumerate(blocks)}
+    prio = [i for i, b in enumerate(blocks) if any(re.match(r"s_setprio [123]$", x) for x in b["ins"])]
+    bar = next(i for i, b in enumerate(blocks) if any(x.startswith("s_barrier") for x in b["ins"]))
+    if not prio: return None
+    lo = prio[0]
+    hi = next((p for p in prio[1:] if p > lo and p < bar), bar)
+    # the slot ends in front of the tests of the next slot / the barrier block: walk back over pure scalar-test blocks
+    while hi - 1 > lo and all(kind(x) in ("salu", "branch") for x in blocks[hi - 1]["ins"]): hi -= 1
+    optional = set()
+    for i in range(lo, hi):
+        last = blocks[i]["ins"][-1].split()
+        if last[0].startswith("s_cbranch") and last[-1] in idx and i < idx[last[-1]] <= hi:
+            for j in range(i + 1, idx[last[-1]]): optional.add(j)
+    def tot(sel):
+        return {"instructions": sum(len(blocks[i]["ins"]) for i in sel), "valu_units": round(sum(blocks[i]["units"] for i in sel), 1),
+                "valu": sum(blocks[i]["count"].get("valu", 0) for i in sel)}
+    every = list(range(lo, hi))
+    return {"blocks": f"{blocks[lo]['label']} .. {blocks[hi - 1]['label']}", "all_paths": tot(every), "least": tot([i for i in every if i not in optional]),
+            "slot_range": (lo, hi)}
+
+
+def summarise(targs, out_dir):
+    global_argv = sys.argv
+    res = {}
+    for which, name in (("0,0", "phase_A"), ("2,0", "phase_C")):
+        sys.argv = [global_argv[0], targs, out_dir, which]
+        lines = compile_one(targs)
+        start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3twl17talco_lean_kernel"))
+        end = next(i for i, l in enumerate(lines) if l.startswith(".Lfunc_end") and i > start)
+        k = lines[start:end]
+        ph, gen = which.split(",")
+        mark = next(i for i, l in enumerate(k) if f"TWL_STEP PH={ph} GEN={gen}" in l)
+        best = None
+        for i, l in enumerate(k):
+            if "Loop Header" not in l or i > mark: continue
+            a = i
+            while not k[a].startswith(".LBB"): a -= 1
+            head_label = k[a].split(":")[0]
+            backs = [j for j in range(mark, len(k)) if re.match(r"\s+s_c?branch\w*\s+%s\b" % re.escape(head_label), k[j])]
+            if backs and (best is None or a > best[0]): best = (a, backs[-1])
+        a, z = best
+        blocks, cur = [], None
+        for l in k[a:z + 1]:
+            if l.startswith(".LBB"):
+                cur = {"label": l.split(":")[0], "ins": []}; blocks.append(cur)
+            elif l.startswith("\t") and not l.strip().startswith((";", ".")) and cur is not None:
+                ins = l.strip()
+                if ins.startswith(";;#"): continue
+                cur["ins"].append(ins)
+                if ins.split()[0].startswith(("s_cbranch", "s_branch")):
+                    cur = {"label": cur["label"] + "+", "ins": []}; blocks.append(cur)
+        blocks = [b for b in blocks if b["ins"]]
+        for b in blocks:
+            c = {}
+            for ins in b["ins"]: c[kind(ins)] = c.get(kind(ins), 0) + 1
+            b["count"] = c
+            b["units"] = round(sum(valu_units(i) for i in b["ins"] if kind(i) == "valu"), 1)
+        ss = slot_summary(blocks)
+        tag = re.sub(r"[^0-9a-z]+", "_", targs.lower()).strip("_")
+        fn = f"isa_step_{tag}_{name}.s"
+        with open(os.path.join(out_dir, fn), "w") as f:
+            f.write(f"; talco_lean_kernel{targs}: the plain {name.replace('_', ' ')} loop (one anti-diagonal per iteration), basic blocks with instruction counts and VALU units -- tools/isa_block_step.py\n")
+            for i, b in enumerate(blocks):
+                inslot = ss and ss["slot_range"][0] <= i < ss["slot_range"][1]
+                f.write(f"; ---- {b['label']}{' [slot 0]' if inslot else ''}: {sum(b['count'].values())} instructions {json.dumps(b['count'])}, {b['units']} VALU units\n")
+                for ins in b["ins"]: f.write("\t" + ins + "\n")
+        if ss: ss.pop("slot_range")
+        res[name] = {"listing": fn, "loop_text_instructions": sum(len(b["ins"]) for b in blocks), "loop_text_valu_units": round(sum(b["units"] for b in blocks), 1), "slot0": ss}
+    sys.argv = global_argv
+    return res
+
+
+def main_all(out_dir):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    os.makedirs(out_dir, exist_ok=True)
+    out = {"source_hash": g.source_hash(),
+           "how": "tools/isa_block_step.py --all: every kernel alone through hipcc -S; the plain phase-A and phase-C loops (one anti-diagonal per iteration) are found by the comment the step "
+                  "leaves in the listing, cut into basic blocks and counted.  slot0 = the text of one ACTIVE 64-row block (from the instruction that raises the wave's priority to the "
+                  "tests of the next slot or the barrier): `all_paths` every instruction in it (profiles with gap letters on both sides and a general denominator run all of it), "
+                  "`least` without the blocks a forward branch jumps over (gap-letter terms :394-395, the division :444).  valu_units = vector instructions weighted by their measured "
+                  "issue cost (issue_rates5.log next to this file): fp32 add / mul / fma / mov on vector registers 1, anything with a scalar operand and every integer, compare, select "
+                  "and DPP form 1.7, packed fp32 2.",
+           "valu_ceiling": {"units_per_ns_per_cu": 3.7, "cus": 256,
+                            "source": "profiles/r06/issue_rates5.log (tools/micro/issue_rates5.hip): full-rate fp32 vector instructions, 5 workgroups x 4 waves per CU 3.59-3.78 per ns and CU, "
+                                      "16 waves 3.89-4.18; the slow classes 2.15-2.27 (ratio 1.7), packed fp32 1.82-1.88 (2)"},
+           "issue_ceiling": {"instr_per_ns_per_cu": 3.97, "cus": 256, "source": "profiles/r02/issue_rates.log (the total-issue ceiling round 5's frac was measured against; kept for continuity)"},
+           "kernels": {}}
+    for targs_full, what in KERNELS.items():
+        targs = targs_full[len("talco_lean_kernel"):]
+        r = summarise(targs, out_dir)
+        r["what"] = what
+        out["kernels"][targs_full] = r
+        s0 = r["phase_A"]["slot0"]
+        print(targs_full, "phase A slot0:", s0["all_paths"] if s0 else None, "least", s0["least"] if s0 else None, file=sys.stderr)
+    json.dump(out, open(os.path.join(out_dir, "isa_block_step.json"), "w"), indent=1)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--all":
+    main_all(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r06"))

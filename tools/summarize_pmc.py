@@ -80,7 +80,7 @@ if "pass1" in out and dur:
 # ---- the dominant kernel in ONE place: launches and average duration from the kernel trace of this command, band cells per launch from the
 # bench line of the same command, instructions of a block step from the disassembly -> the issue-ceiling fraction, recomputable from these few numbers ----
 try:
-    isa = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05", "isa_block_step.json")))
+    isa = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06", "isa_block_step.json")))
     dk = (bench or {}).get("roofline", {}).get("dominant_kernel")
     if dk and ks:
         # (the profiler spells a defaulted last template argument out: "..., false, 0>" of the library is "..., false, 0, 0>" in the trace)
@@ -92,12 +92,14 @@ try:
             dp_s_per_pass = sum(float(r["TotalDurationNs"]) for r in allrows) * 1e-9 / passes
             cells_per_pass = bench["roofline"]["cells"]
             avg_ns = sum(float(r["TotalDurationNs"]) for r in rows) / max(1, sum(int(r["Calls"]) for r in rows))
-            step = isa["kernels"][key]["block_step"]["no_gap_letters_denominator_1" if ", 5, 5, false" in key else "profiles_with_gap_letters_and_division"]
-            peak = isa["issue_ceiling"]["cus"] * isa["issue_ceiling"]["instr_per_ns_per_cu"] * 1e9 * 64.0 / step
+            s0 = isa["kernels"][key]["phase_A"]["slot0"]["least" if ", 5, 5, false" in key else "all_paths"]
+            cap = isa["valu_ceiling"]["cus"] * isa["valu_ceiling"]["units_per_ns_per_cu"] * 1e9
+            peak = cap * 64.0 / s0["valu_units"]
+            peak_issue = isa["issue_ceiling"]["cus"] * isa["issue_ceiling"]["instr_per_ns_per_cu"] * 1e9 * 64.0 / s0["instructions"]
             out["dominant_kernel"] = {"kernel": dk["kernel"], "calls_in_trace": sum(int(r["Calls"]) for r in rows), "avg_ns_in_trace": avg_ns,
-                                      "instructions_per_block_step": step, "cells_per_block_step": 64,
-                                      "issue_ceiling_instr_per_ns_per_cu": isa["issue_ceiling"]["instr_per_ns_per_cu"], "cus": isa["issue_ceiling"]["cus"],
-                                      "peak_cells_per_s": peak,
+                                      "valu_units_per_block_step": s0["valu_units"], "instructions_per_block_step": s0["instructions"], "cells_per_block_step": 64,
+                                      "valu_ceiling_units_per_ns_per_cu": isa["valu_ceiling"]["units_per_ns_per_cu"], "cus": isa["valu_ceiling"]["cus"],
+                                      "peak_cells_per_s": peak, "peak_cells_per_s_total_issue": peak_issue,
                                       # what bench.py calls a launch of this kernel is a LEVEL that starts on it (its remainder runs as tile jobs of the same family):
                                       "bench_level_cells_per_launch": dk["cells_per_launch"], "bench_level_dp_ms_per_launch": dk["avg_ms"],
                                       "frac_levels_of_this_kernel": dk["cells_per_launch"] / (dk["avg_ms"] * 1e-3) / peak,
@@ -105,8 +107,13 @@ try:
                                       "trace_dp_kernel_s_per_pass": dp_s_per_pass, "bench_dp_kernel_s_per_pass": bench["roofline"]["kernel_ms"] * 1e-3,
                                       "band_cells_per_pass": cells_per_pass,
                                       "frac_whole_pass": cells_per_pass / dp_s_per_pass / peak,
-                                      "note": "frac_whole_pass = band_cells_per_pass / (sum of TotalDurationNs of the talco_* rows of bench_kernel_stats.csv / passes in that command) / "
-                                              "(cus x ceiling x 1e9 x 64 / instructions_per_block_step); the leaf level's step is shorter (101 instructions), so a pass-weighted peak would be higher"}
+                                      "frac_whole_pass_total_issue": cells_per_pass / dp_s_per_pass / peak_issue,
+                                      "note": "frac_whole_pass = band_cells_per_pass / (sum of TotalDurationNs of the talco_* rows of the kernel_stats csv / passes in that command) / "
+                                              "(cus x 3.7e9 x 64 / valu_units_per_block_step); ..._total_issue = round 5's definition (3.97e9 instructions of any kind, instructions of the block step)"}
+            # the vector unit's load as the counters see it: vector instructions per ns and CU of the dominant kernel (the slow classes top out at 2.15-2.27, issue_rates5.log)
+            for nm, e in issue.items():
+                if any(x in nm for x in names) and "insts_by_kind" in e:
+                    out["dominant_kernel"]["valu_insts_per_ns_per_cu"] = e["insts_by_kind"]["valu"] / (CUS * e["seconds_in_run"] * 1e9)
 except Exception as ex:  # noqa: BLE001
     out["dominant_kernel"] = {"note": f"not formed: {ex}"}
 try:      # which code these counters belong to: the hash of the kernel sources the profiled library was built from (twl_version carries the same)

@@ -3,6 +3,10 @@
 
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
+// ... of the levels of at most 2048 tile jobs (a round or two of the device's workgroups): there a scout costs ~0.1 ms of the level and a missed start a whole second round (+1.5-1.9 ms), so the
+// margin behind the boundary range and the lead of an anchored scout are longer (round 6: levels 15 and 19 of 10 000 x 10 kbp lost a start each with 40 / 96, none with 64 / 128;
+// on the wide levels the longer scouts cost more than the two rounds, profiles/r06/exp_scout_margins.txt).  TWL_KNOB_MT_MARGIN / TWL_KNOB_MT_LEAD2 set both kinds
+int g_mt_marg_lat = 64, g_mt_lead2_lat = 128;
 int g_mt_anchor = 1, g_mt_lead2 = 96;      // twl_set_knob(TWL_KNOB_MT_ANCHOR / TWL_KNOB_MT_LEAD2): scouts (either alphabet) start from the cell the profiles' consensus letters point at, this many anti-diagonals ahead (talco_nuc.hip.h, mt_anchor_kernel)
 int g_mt_max_pairs = 1024, g_mt_min_marker = 512, g_mt_rounds = 2, g_mt_thr_jobs = 256;
 int g_scout_xdrop_pct = 100;         // twl_set_knob(TWL_KNOB_SCOUT_XDROP_PCT): X-drop of the pair scouts in percent of the call's (they only predict: a narrower band is a cheaper scout)

@@ -274,8 +274,11 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
     a.mt_chain = (int32_t *)d->mt_chain.p; a.mt_rec = (int32_t *)d->mt_rec.p; a.mt_seg = (int8_t *)d->mt_seg.p; a.mt_spath = (int32_t *)d->mt_spath.p;
     a.mt_stat = (unsigned long long *)d->mt_stat.p;
     a.mt_front = (int32_t *)((unsigned long long *)d->mt_stat.p + 4);
-    a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = g_mt_marg;
     const bool thr = !WIDE && nTile > g_mt_thr_jobs;
+    // (see twl_knobs.inc.hip: longer scouts where the tile jobs are at most a round or two of the device's workgroups and a missed start a second round that lasts as long as the first)
+    const bool longScouts = !WIDE && nTile <= 2048;
+    const int lead2 = longScouts ? g_mt_lead2_lat : g_mt_lead2;
+    a.mt_slots = slots; a.mt_segcap = segcap; a.mt_sp_pitch = sp_pitch; a.mt_lead = g_mt_lead; a.mt_marg = longScouts ? g_mt_marg_lat : g_mt_marg;
     TRACE("launch mt pairs=%d scouts=%d tiles=%d slots=%d geometry=%s", n_run, nScout, nTile, slots, WIDE ? "16x3 (wide)" : (thr ? "throughput geometry" : "16x1"));
     if (!d->kname[0]) {
         if (thr && smallT) snprintf(d->kname, sizeof d->kname, "talco_lean_kernel<%d, 4, 2, %d, 5, false, false, 2 / 1> + <%d, 16, 1, %d, 1, false, false, 3> (tile-parallel: scouts, tiles, stitch)", P, MM, P, MM);
@@ -298,9 +301,9 @@ int launch_mt(Device *d, hipStream_t st, const twl::KArgs &base, const int32_t *
         a.mt_jobs = (const int32_t *)d->mt_jobs.p;
         if (anchors) {
             FILL_TRY(flush_fills(d, st));
-            hipLaunchKernelGGL(twl::mt_anchor_kernel<P>, dim3(nScout), dim3(256), 0, st, base.cols, base.len, base.seq_len, a.mt_jobs, nScout, (int32_t *)d->mt_anchor.p, slots, marker, g_mt_lead2);
+            hipLaunchKernelGGL(twl::mt_anchor_kernel<P>, dim3(nScout), dim3(256), 0, st, base.cols, base.len, base.seq_len, a.mt_jobs, nScout, (int32_t *)d->mt_anchor.p, slots, marker, lead2);
             HIP_TRY(hipGetLastError());
-            a.mt_anchor = (const int32_t *)d->mt_anchor.p; a.mt_lead2 = g_mt_lead2;
+            a.mt_anchor = (const int32_t *)d->mt_anchor.p; a.mt_lead2 = lead2;
         }
         const bool thrS = WIDE ? nScout > g_mt_thr_jobs : thr;
         // (nucleotide scouts of the throughput geometry run ~330 diagonals from one cell: their band opens by a row per diagonal and cannot outgrow 449 rows, so
