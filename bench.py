@@ -54,6 +54,18 @@ PROF = "r06"
 ISA = os.path.join(ROOT, "profiles", PROF, "isa_block_step.json")      # static instruction counts / VALU units of a block step, from the disassembly (tools/isa_block_step.py --all)
 
 
+def isa_key(isa, kernel_name):
+    """The entry of profiles/r06/isa_block_step.json a kernel name of the library belongs to.  Plain launches are spelt as the profiler spells them; a tile-parallel level is
+    named by its families ("talco_lean_kernel<6, 4, 3, 2, 4, false, false, 2 / 1> + <6, 16, 1, ...>"): its cells are computed by the TILE jobs (MT 1) of the first family."""
+    import re
+    m = re.search(r"talco_lean_kernel<(\d+, \d+, \d+, \d+, \d+, false, false, )([^>]*)>", kernel_name)
+    if not m: return None
+    pre, rest = m.group(1), m.group(2)
+    want = pre + ("1" if "/" in rest else rest)
+    keys = sorted(isa["kernels"], key=len, reverse=True)
+    return next((k for k in keys if k == "talco_lean_kernel<" + want + ">"), None) or next((k for k in keys if k.startswith("talco_lean_kernel<" + pre) and k.endswith((", 1>" if "/" in rest else ", 0>"))), None)
+
+
 def pmc_path(config, workload):
     """Counters of the bench command of this configuration, taken on the same kernel sources (tools/final_profiles.sh)."""
     return os.path.join(ROOT, "profiles", PROF, "bench_pmc_summary.json" if (config == "rnasim10k" and workload == "calibrated") else f"{config}_pmc_summary.json")
@@ -570,7 +582,7 @@ def main():
                 isa_note = f"static counts are of kernel sources {isa.get('source_hash')}, this library is {lib_ver}"
             dk = dom["kernel"] if dom else (peak or {}).get("kernel")
             if dk:
-                key = next((k for k in sorted(isa["kernels"], key=len, reverse=True) if k in dk), None)
+                key = isa_key(isa, dk)
                 if key is None:
                     isa_note = (isa_note + "; " if isa_note else "") + f"no static count for {dk} in profiles/r06/isa_block_step.json: frac not formed"
                 if key:

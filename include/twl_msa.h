@@ -27,6 +27,8 @@ typedef struct twl_msa twl_msa;
                                 that small trees reach the cached-profile and compressed-group branches
      --test-virtual-devices n   n replicas of the store on ONE device: the several-replica code path of the resident level kernel on a one-GPU box
      --test-no-ownership        a sharded run deals and exchanges every level (the design before subtree ownership; tests hold the two to each other)
+     --test-fork-host-staged    (CLI) one forked process per listed device for the host-staged kernel as well, the paths of every level all-gathered through the library's
+                                communicator: the forked flow (shared page, id hand-over, watchdog) on the CPU-check build, whose communicator is a shared-memory segment
    Environment: TWL_OMP_THREADS (host threads of the library; default: what OpenMP picks) and TWL_DEBUG (traces the launches of libtwl_align on stderr).
    Nothing in the environment changes a result or a launch. */
 

@@ -9,11 +9,31 @@
 #include "../include/twl_level.h"
 #include "talco_oracle.h"
 
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <fcntl.h>
 #include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 twl_stats g_stats{};
+// shared-memory communicator (see twl_comm_* below)
+constexpr int kShmMaxWorld = 8;
+constexpr size_t kShmSlot = (size_t)32 << 20;      // bytes a rank may contribute to one all-gather
+struct ShmHead { std::atomic<int> arrived; std::atomic<int> phase; };
+struct { ShmHead *seg = nullptr; size_t bytes = 0; int rank = 0, world = 1; char name[TWL_COMM_ID_BYTES] = {0}; } g_comm;
+void shm_barrier()
+{
+    ShmHead *h = g_comm.seg;
+    const int ph = h->phase.load();
+    if (h->arrived.fetch_add(1) + 1 == g_comm.world) { h->arrived.store(0); h->phase.store(ph + 1); }
+    else while (h->phase.load() == ph) usleep(50);
+}
 const char *kNoDevice = "CPU check build: the device-resident level path needs the GPU library";
 }  // namespace
 
@@ -79,11 +99,57 @@ int twl_store_write_cache(twl_store *, int32_t, const float *, int32_t) { return
 int twl_store_rows_to_block(twl_store *, int32_t, const int32_t *, void *, int32_t *) { return TWL_ERR_UNSUPPORTED; }
 int twl_store_rows_from_block(twl_store *, int32_t, const int32_t *, const int32_t *, const void *) { return TWL_ERR_UNSUPPORTED; }
 int twl_store_exchange_buffers(twl_store *, int64_t, int64_t, void **, void **) { return TWL_ERR_UNSUPPORTED; }
-int twl_comm_unique_id(void *) { return TWL_ERR_UNSUPPORTED; }
-int twl_comm_init(int, int, int, const void *) { return TWL_ERR_UNSUPPORTED; }
-int twl_comm_all_gather(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }
-int twl_comm_all_gather_host(int, const void *, void *, int64_t) { return TWL_ERR_UNSUPPORTED; }
-int twl_comm_destroy(int) { return TWL_ERR_UNSUPPORTED; }
+// The communicator of a sharded run (include/twl_align.h: RCCL in the product) as a POSIX shared-memory segment between the processes of ONE box: what lets the forked
+// CLI (twilight_amd/csrc/host/main.cpp: fork, shared page, id hand-over, watchdog) and the "the library's own collective" branch of the host-staged level kernel run
+// end to end on a box without a GPU (tests/test_abi_cpu.py).  The id is the segment's name; an all-gather is copy in, barrier, copy out, barrier.
+int twl_comm_unique_id(void *id128)
+{
+    char *id = static_cast<char *>(id128);
+    memset(id, 0, TWL_COMM_ID_BYTES);
+    snprintf(id, TWL_COMM_ID_BYTES, "/twl_cpucheck_%d_%ld", (int)getpid(), (long)time(nullptr));
+    return TWL_OK;
+}
+int twl_comm_init(int, int rank, int world, const void *id128)
+{
+    if (g_comm.seg) return TWL_OK;
+    if (world < 1 || world > kShmMaxWorld || rank < 0 || rank >= world) return TWL_ERR_BAD_ARGUMENT;
+    const char *name = static_cast<const char *>(id128);
+    const size_t bytes = sizeof(ShmHead) + (size_t)world * kShmSlot;
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return TWL_ERR_HIP;
+    } else {
+        for (int t = 0; t < 20000 && fd < 0; ++t) { fd = shm_open(name, O_RDWR, 0600); if (fd < 0) usleep(500); }      // (rank 0 creates it)
+        if (fd < 0) return TWL_ERR_HIP;
+        struct stat sb;
+        for (int t = 0; t < 20000; ++t) { if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break; usleep(500); }
+    }
+    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return TWL_ERR_HIP;
+    g_comm.seg = static_cast<ShmHead *>(m); g_comm.bytes = bytes; g_comm.rank = rank; g_comm.world = world;
+    snprintf(g_comm.name, sizeof g_comm.name, "%s", name);
+    shm_barrier();          // everybody has mapped it: the name can go
+    if (rank == 0) shm_unlink(name);
+    return TWL_OK;
+}
+int twl_comm_all_gather_host(int, const void *send, void *recv, int64_t bytes)
+{
+    if (!g_comm.seg || bytes < 0 || (size_t)bytes > kShmSlot) return TWL_ERR_BAD_ARGUMENT;
+    // test aid: TWL_CPUCHECK_DIE_AT=<n> makes rank 1 die inside its n-th all-gather, the way a rank dies inside a collective: the others are left in the barrier
+    // and only the CLI's watchdog can end the run (tests/test_abi_cpu.py)
+    static int calls = 0;
+    if (const char *e = getenv("TWL_CPUCHECK_DIE_AT")) { if (g_comm.rank == 1 && ++calls == atoi(e)) _exit(3); }
+    char *slots = reinterpret_cast<char *>(g_comm.seg + 1);
+    memcpy(slots + (size_t)g_comm.rank * kShmSlot, send, (size_t)bytes);
+    shm_barrier();
+    for (int r = 0; r < g_comm.world; ++r) memcpy(static_cast<char *>(recv) + (size_t)r * (size_t)bytes, slots + (size_t)r * kShmSlot, (size_t)bytes);
+    shm_barrier();
+    return TWL_OK;
+}
+int twl_comm_all_gather(int d, const void *send, void *recv, int64_t bytes) { return twl_comm_all_gather_host(d, send, recv, bytes); }      // ("device" memory is host memory here)
+int twl_comm_destroy(int) { if (g_comm.seg) { munmap(g_comm.seg, g_comm.bytes); g_comm.seg = nullptr; } return TWL_OK; }
 int twl_plan_describe(const twl_params *, int32_t, const int32_t *, int32_t, int32_t, int32_t, char *, int32_t) { return TWL_ERR_UNSUPPORTED; }
 
 }  // extern "C"

@@ -123,3 +123,72 @@ def test_forked_cli_leaves_nobody_behind_when_a_rank_fails(built, tmp_path):
     else:
         os.killpg(p.pid, signal.SIGKILL)
         raise AssertionError("children of a failed run are still alive")
+
+
+def _nobody_left(p, grace=10.0):
+    import signal
+    import time
+
+    deadline = time.time() + grace
+    while time.time() < deadline:
+        try:
+            os.killpg(p.pid, 0)
+        except ProcessLookupError:
+            return
+        time.sleep(0.05)
+    os.killpg(p.pid, signal.SIGKILL)
+    raise AssertionError("processes of the run are still alive")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_forked_cli_aligns_on_the_cpu_check_build(built, tmp_path, ranks):
+    """The product's CLI flow for several GPUs -- fork one process per listed device, hand the communicator id over through the shared page, deal the pairs of every
+    level, all-gather the paths through the LIBRARY's collective, rank 0 writes -- on a box without a GPU: oracle/twilight-cpucheck is main.cpp linked against the
+    CPU-check host library, whose device is the oracle and whose communicator is a shared-memory segment.  What stays unexecuted without a
+    multi-GPU node is RCCL itself and the device-resident kernel's subtree ownership (its level kernels have no CPU form)."""
+    import gzip
+    import hashlib
+    import signal
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "twilight-cpucheck")
+    assert os.path.exists(exe), "run `make -C oracle` (build() does)"
+    fa = tmp_path / "s.fa"
+    fa.write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", "sars_20.fa.gz")).read())
+    out = tmp_path / "o.aln"
+    p = subprocess.Popen([exe, "-t", os.path.join(ROOT, "tests", "golden", "sars_20.nwk"), "-i", str(fa), "-o", str(out), "--host-staged", "--test-fork-host-staged",
+                          "--gpu-index", ",".join(str(r) for r in range(ranks))], stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, text=True)
+    try:
+        so, se = p.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        raise
+    assert p.returncode == 0, se[-2000:]
+    _nobody_left(p)
+    md5 = hashlib.md5(out.read_bytes()).hexdigest()
+    assert md5.startswith("53ccbd43"), md5                                       # the reference's recorded MSA of sars_20 (SURVEY.md section 6)
+    assert "468765465 band cells" in se, se[-500:]                               # every pair aligned once, by one rank
+
+
+@pytest.mark.timeout(120)
+def test_forked_cli_ends_when_a_rank_dies_inside_a_collective(built, tmp_path):
+    """Rank 1 dies inside its second all-gather; rank 0 is left in the collective, from which no return code ever comes: the watchdog of the CLI must end the run with an
+    error and leave nobody behind (ADVICE rounds 4 and 5)."""
+    import gzip
+    import signal
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "twilight-cpucheck")
+    fa = tmp_path / "s.fa"
+    fa.write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", "sars_20.fa.gz")).read())
+    env = dict(os.environ, TWL_CPUCHECK_DIE_AT="2")
+    p = subprocess.Popen([exe, "-t", os.path.join(ROOT, "tests", "golden", "sars_20.nwk"), "-i", str(fa), "-o", str(tmp_path / "o.aln"), "--host-staged",
+                          "--test-fork-host-staged", "--gpu-index", "0,1"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True, env=env)
+    try:
+        _, err = p.communicate(timeout=100)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        raise AssertionError("the run hung after a rank died inside a collective")
+    assert p.returncode != 0, err
+    _nobody_left(p)

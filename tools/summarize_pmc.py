@@ -86,7 +86,12 @@ try:
         # (the profiler spells a defaulted last template argument out: "..., false, 0>" of the library is "..., false, 0, 0>" in the trace)
         names = (dk["kernel"] + "(", dk["kernel"][:-1] + ", 0>(")
         rows = [r for r in csv.DictReader(open(ks[0])) if any(nm in r["Name"] for nm in names)]
-        key = next((k for k in sorted(isa["kernels"], key=len, reverse=True) if k in dk["kernel"]), None)
+        import re as _re
+        _m = _re.search(r"talco_lean_kernel<(\d+, \d+, \d+, \d+, \d+, false, false, )([^>]*)>", dk["kernel"])
+        key = None
+        if _m:
+            _want = "talco_lean_kernel<" + _m.group(1) + ("1" if "/" in _m.group(2) else _m.group(2)) + ">"
+            key = _want if _want in isa["kernels"] else None
         if rows and key:
             allrows = [r for r in csv.DictReader(open(ks[0])) if "talco_" in r["Name"]]
             dp_s_per_pass = sum(float(r["TotalDurationNs"]) for r in allrows) * 1e-9 / passes

@@ -70,6 +70,7 @@ bool parseCommandLine(int argc, char **argv, Option &o)
         else if (flag(a, nullptr, "--test-update-seq-th")) { const int v = atoi(val()); if (v > 0) o.updateSeqTh = v; }
         else if (flag(a, nullptr, "--test-virtual-devices")) o.testVirtualDevices = std::max(0, atoi(val()));
         else if (flag(a, nullptr, "--test-no-ownership")) o.testNoOwnership = true;
+        else if (flag(a, nullptr, "--test-fork-host-staged")) o.testForkHostStaged = true;
         else if (flag(a, nullptr, "--overwrite")) {}
         else if (flag(a, "-h", "--help")) return false;
         else { std::cerr << "ERROR: unsupported option " << a << " (this build covers the tree+sequences alignment mode only)\n"; exit(1); }

@@ -55,7 +55,7 @@ int main(int argc, char **argv)
     auto t0 = std::chrono::high_resolution_clock::now();
     int rank = 0;
     const std::vector<int> allDevices = option.gpuIdx;
-    const int world = (allDevices.size() > 1 && !option.hostStaged && option.testVirtualDevices == 0) ? (int)allDevices.size() : 1;
+    const int world = (allDevices.size() > 1 && (!option.hostStaged || option.testForkHostStaged) && option.testVirtualDevices == 0) ? (int)allDevices.size() : 1;
     SharedPage *page = nullptr;
     std::vector<pid_t> kids;
     if (world > 1) {
@@ -140,6 +140,7 @@ int main(int argc, char **argv)
         const int rcComm = msa::progressive::gpu::initRcclShard(db, &option, rank, world, page->id);
         if (rcComm != TWL_OK) { std::cerr << "ERROR: twl_comm_init failed (" << rcComm << "): " << twl_last_error() << '\n'; markFailedAtExit(); exit(1); }
         atexit(markFailedAtExit);      // (... and behind RCCL's and the device runtime's handlers, see above)
+        if (option.hostStaged) db->ownedPrefix = nullptr;      // (subtree ownership is the device-resident kernel's: --test-fork-host-staged deals and gathers every level)
     };
     const int alnLen = msa::runDefaultAlignment(option, kernel, kernel, rank == 0, [&](msa::SequenceDB *db) { g = msa::progressive::gpu::runTotals(db); }, beforeAlign);
     g_finishedOk = 1;

@@ -123,6 +123,7 @@ struct Option {
     // msa.hpp:179-180 (_CAL_PROFILE_TH, _UPDATE_SEQ_TH): 1000 in the reference; tests lower them per RUN (--test-cal-profile-th / --test-update-seq-th: small trees
     // then reach the cached-profile and compressed-group branches).  Per run since round 5: as process globals a handle with lowered thresholds changed every later one
     int calProfileTh = 1000, updateSeqTh = 1000;
+    bool testForkHostStaged = false; // --test-fork-host-staged: the CLI forks one process per listed device for the host-staged kernel too (paths all-gathered through the library's communicator per level); lets the forked flow run on the CPU-check build
     bool testNoOwnership = false; // --test-no-ownership: a sharded run deals and exchanges every level (no subtree ownership below a cut)
     int testVirtualDevices = 0;  // --test-virtual-devices n: n replicas of the store on the first device (the several-replica path of the resident kernel on a one-GPU box)
     bool hostStaged = false;     // --host-staged: build profiles on the host and stage them per level (default: device-resident rows)
