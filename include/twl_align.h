@@ -204,10 +204,12 @@ int twl_comm_destroy(int device);
      TWL_KNOB_MT_ANCHOR      1 (default): the scouts of the tile-parallel path (nucleotide and protein: the most frequent letter of a column) start from the cell on which the consensus letters of the two profiles agree
                              (one small kernel per level finds it for every tile boundary), TWL_KNOB_MT_LEAD2 (default 96) anti-diagonals ahead of the boundary, where
                              that cell is trusted; elsewhere, and with 0 everywhere, from the straight line between the corners TWL_KNOB_MT_LEAD ahead.  Predictions
-                             only: the results are the same either way (tests hold the two to each other) */
+                             only: the results are the same either way (tests hold the two to each other)
+     TWL_KNOB_PROT_CORRIDOR  rows (default 448): protein levels of few pairs precompute their column scores (matrix mode 4) only within this many rows of the straight line
+                             between the corners of a pair's matrix; a pair whose band leaves that corridor is re-run by the kernel that scores in line.  0: the whole matrix */
 enum twl_knob { TWL_KNOB_MT_PERTURB = 1, TWL_KNOB_MT_MAX_PAIRS = 2, TWL_KNOB_MT_MIN_MARKER = 3, TWL_KNOB_MT_LEAD = 4, TWL_KNOB_MT_MARGIN = 5,
                 TWL_KNOB_MT_ROUNDS = 6, TWL_KNOB_MT_THR_JOBS = 7, TWL_KNOB_FAIL_ROW_ALLOCS = 8,
-                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16, TWL_KNOB_LEAF_STEP = 17, TWL_KNOB_POISON_TB = 18, TWL_KNOB_MT_ANCHOR = 19, TWL_KNOB_MT_LEAD2 = 20 };
+                TWL_KNOB_PROT_MODE = 9, TWL_KNOB_ASSUME_ONEHOT_QUERY = 10, TWL_KNOB_MT_TAIL_PCT = 11, TWL_KNOB_MT_WIDE = 12, TWL_KNOB_NO_SPEC = 13, TWL_KNOB_SCOUT_XDROP_PCT = 14, TWL_KNOB_THR_SMALL = 15, TWL_KNOB_FORCE_GLOBAL = 16, TWL_KNOB_LEAF_STEP = 17, TWL_KNOB_POISON_TB = 18, TWL_KNOB_MT_ANCHOR = 19, TWL_KNOB_MT_LEAD2 = 20, TWL_KNOB_PROT_CORRIDOR = 21 };
 int twl_set_knob(int key, int value);
 /* The launch plan of a nucleotide call in words ("throughput; mode 2; window 768; bulk 1024 tail 277"), made by the very function the launch path
    uses, without touching a device: len[n_pairs][2] as twl_align_batch, num_cu / qry_onehot / wide_streak the facts the device would supply. */

@@ -22,13 +22,14 @@ def knobs(gpu):
     gpu.set_knob(api.KNOB_MT_MAX_PAIRS, 1024)
     gpu.set_knob(api.KNOB_MT_MIN_MARKER, 512)
     gpu.set_knob(api.KNOB_MT_LEAD, 320)
-    gpu.set_knob(api.KNOB_MT_MARGIN, 40)
+    gpu.set_knob(api.KNOB_MT_MARGIN, -1)         # (negative: the defaults -- 40 diagonals, 64 on levels of at most 2048 tile jobs)
     gpu.set_knob(api.KNOB_MT_ROUNDS, 2)
     gpu.set_knob(api.KNOB_MT_THR_JOBS, 256)
     gpu.set_knob(api.KNOB_MT_WIDE, 1)
     gpu.set_knob(api.KNOB_THR_SMALL, 0)
     gpu.set_knob(api.KNOB_MT_ANCHOR, 1)
-    gpu.set_knob(api.KNOB_MT_LEAD2, 96)
+    gpu.set_knob(api.KNOB_MT_LEAD2, -1)          # (96 / 128)
+    gpu.set_knob(api.KNOB_PROT_CORRIDOR, 448)
 
 
 def _compare(twl, batch, **pk):
@@ -409,6 +410,20 @@ def test_protein_tile_parallel_with_spoiled_predictions(knobs):
     batch = synth.make_level_batch(4, 3000, P=22, members=((2, 5), (2, 5)), seed=92, sub=0.2)
     st, ost = _compare_p(knobs, batch)
     assert st.speculative == 3 and st.mt_tiles_inline >= 1
+
+
+@pytest.mark.parametrize("corridor", [0, 64, 160, 448])
+def test_protein_score_corridor_changes_no_result(knobs, corridor):
+    """Protein levels of few pairs precompute their column scores in a corridor around the straight line between the corners (round 6); the tiles outside it hold NaN, and
+    a pair whose band reads one is re-run by the kernel that scores in line.  64 rows is narrower than any band (every pair re-runs), 160 cuts some, 0 is the whole matrix."""
+    knobs.set_knob(api.KNOB_PROT_CORRIDOR, corridor)
+    batch = synth.make_level_batch(5, 2500, P=22, members=((1, 6), (1, 6)), seed=91, sub=0.15, indel=0.01)
+    batch.len[1, 1] = int(batch.len[1, 1] * 0.6)      # an unequal pair: its path leaves the straight line by hundreds of rows
+    st, ost = _compare_p(knobs, batch)
+    if corridor == 0:
+        assert st.n_relaunched == 0
+    if corridor == 64:
+        assert st.n_relaunched >= 4
 
 
 def test_protein_tile_parallel_small_marker_and_blosum80(knobs):

@@ -82,8 +82,8 @@ def test_every_knob_the_header_names_is_known_to_the_library_and_to_the_bindings
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "twl_align.h")).read()
     enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"TWL_(KNOB_[A-Z0-9_]+) = (\d+)", hdr[hdr.index("enum twl_knob"):]))
     assert len(enum) >= 20 and sorted(enum.values()) == list(range(1, len(enum) + 1))
-    defaults = {"KNOB_MT_MAX_PAIRS": 1024, "KNOB_MT_MIN_MARKER": 512, "KNOB_MT_LEAD": 320, "KNOB_MT_MARGIN": 40, "KNOB_MT_ROUNDS": 2, "KNOB_MT_THR_JOBS": 256,
-                "KNOB_MT_TAIL_PCT": 70, "KNOB_MT_WIDE": 1, "KNOB_SCOUT_XDROP_PCT": 100, "KNOB_LEAF_STEP": 1, "KNOB_MT_ANCHOR": 1, "KNOB_MT_LEAD2": 96}
+    defaults = {"KNOB_MT_MAX_PAIRS": 1024, "KNOB_MT_MIN_MARKER": 512, "KNOB_MT_LEAD": 320, "KNOB_MT_MARGIN": -1, "KNOB_MT_ROUNDS": 2, "KNOB_MT_THR_JOBS": 256,
+                "KNOB_MT_TAIL_PCT": 70, "KNOB_MT_WIDE": 1, "KNOB_SCOUT_XDROP_PCT": 100, "KNOB_LEAF_STEP": 1, "KNOB_MT_ANCHOR": 1, "KNOB_MT_LEAD2": -1, "KNOB_PROT_CORRIDOR": 448}
     for name, key in enum.items():
         assert getattr(api, name) == key, name
         twl.set_knob(key, defaults.get(name, 0))          # (every key is accepted; the value is the library's default)

@@ -122,6 +122,7 @@ KERNELS = {
     "talco_lean_kernel<6, 4, 3, 2, 4, false, false, 1>": "tile jobs on the 768-row throughput geometry",
     "talco_lean_kernel<6, 4, 2, 2, 5, false, false, 1>": "tile jobs on the 512-row throughput geometry",
     "talco_lean_kernel<6, 16, 1, 2, 1, false, false, 1>": "tile jobs on the latency geometry",
+    "talco_lean_kernel<6, 16, 3, 2, 1, false, false, 1>": "tile jobs of the wide re-runs (3072-row window): the family of SURVEY 8d as written",
     "talco_lean_kernel<22, 8, 1, 3, 4, false, false, 0>": "protein throughput: the loop over the non-zero letters of the reference column, counted for ONE letter per column (the least a column can hold)",
     "talco_lean_kernel<22, 16, 1, 4, 1, false, false, 1>": "protein tile jobs on precomputed scores",
     "talco_lean_kernel<22, 8, 1, 4, 4, false, false, 1>": "protein tile jobs on precomputed scores, throughput geometry",

@@ -147,6 +147,7 @@ KNOB_FORCE_GLOBAL = 16
 KNOB_LEAF_STEP = 17
 KNOB_POISON_TB = 18
 KNOB_MT_ANCHOR = 19
+KNOB_PROT_CORRIDOR = 21
 KNOB_MT_LEAD2 = 20
 PROT_MODES = {"auto": 0, "dense": 1, "sparse": 2, "presim": 3, "r1": 4, "lean_sparse": 5, "lean_presim": 6}
 

@@ -794,6 +794,7 @@ struct ScoreArgs {
     const float *M24;              // P = 22: [21][24] matrix rows padded to 24 floats; P = 6: the 5x5 matrix row-major, padded to 28 floats
     float *sim;
     const long long *sim_off;
+    int32_t corridor;              // > 0: only the 64 x 64 tiles within this many rows of the straight line between the corners are scored, the others filled with NaN (round 6)
 };
 
 template <int P>
@@ -811,6 +812,22 @@ __global__ void __launch_bounds__(256) score_matrix_kernel(ScoreArgs a)
     const int local = (int)blockIdx.x - a.blk_off[it];
     const int I0 = (local % nI) * 64, K0 = (local / nI) * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Round 6: the DP band of a pair is 27-37 % of R x Q on 2 kaa profiles and follows the straight line between the corners to within a few dozen rows; tiles further
+    // than `corridor` rows from that line are not scored.  They are filled with NaN instead, and a DP kernel whose band reads one hands the pair to the kernel that
+    // scores in line (talco_lean_kernel, PRESIM: kErrGuard) -- a prediction like the scouts': results do not depend on it.
+    if (a.corridor > 0) {
+        const int ic = (int)(((long long)(K0 + 32) * Q) / (R + Q));
+        if (I0 > ic + a.corridor || I0 + 63 < ic - a.corridor) {
+            const int pitchN = (Q + 63) & ~63;
+            float *outN = a.sim + a.sim_off[pair];
+            const int I = I0 + lane;
+            for (int kk = wave; kk < 64; kk += 4) {
+                const int K = K0 + kk;
+                if (I < pitchN && K < R + Q) outN[(size_t)K * (size_t)pitchN + (size_t)I] = __int_as_float(0x7fc00000);
+            }
+            return;
+        }
+    }
     const int Jmin = K0 - I0 - 63;
     const float4 *colsR = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 0) * (size_t)a.seq_len * CW);
     const float4 *colsQ = reinterpret_cast<const float4 *>(a.cols + ((size_t)pair * 2 + 1) * (size_t)a.seq_len * CW);

@@ -1006,6 +1006,9 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
                             else sim = colOk ? simP[(size_t)(k + simK0) * (size_t)simPitch + col] : 0.0f;
                             simNext[r] = (colOk && k + 1 < kEnd) ? simP[(size_t)(k + 1 + simK0) * (size_t)simPitch + col] : 0.0f;
                             simFor[r] = k + 1;
+                            // Round 6: score_matrix_kernel fills a corridor around the straight line between the corners and leaves NaN in the tiles outside it.  A band
+                            // cell that reads one sends the pair to the kernel that scores in line (kErrGuard: the stage an operand outside fast_div's range takes)
+                            guardBad = guardBad | (__builtin_amdgcn_ballot_w64(inband && sim != sim) != 0ull);
                         } else if (SP == 0 && !denomOne) {      // (a real branch: leaf pairs, a third of all cells, have refNum * qryNum == 1)
                             sim = fast_div(numer, denom, rden);
                             asm volatile("" : "+v"(sim));
@@ -1345,7 +1348,7 @@ __global__ __launch_bounds__(64 * W, MINW) void talco_lean_kernel(NArgs a)
             if (tile_err != 0) { err = tile_err; break; }
             // a profile entry outside fast_div's range: the IEEE-division kernel re-runs the pair (every wave saw different columns:
             // the verdict goes through LDS so that all of them leave together)
-            if (SP == 1 || !denomOne) {
+            if (PRESIM || SP == 1 || !denomOne) {
                 if (guardBad) s_misc[4] = 1;
                 __syncthreads();
                 guardBad = __builtin_amdgcn_readfirstlane(s_misc[4]) != 0;

@@ -351,6 +351,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
                 sa.n_items = n_run; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.gc_zero = a.gc_zero; sa.M24 = (const float *)d->m24.p;
                 sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
+                sa.corridor = lean ? g_prot_corridor : 0;      // (the lean kernels check what they read; the round-1 kernel behind `dense` does not)
                 FILL_TRY(flush_fills(d, st));
                 hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_run]), dim3(256), 0, st, sa);
                 HIP_TRY(hipGetLastError());
@@ -1062,7 +1063,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_MT_MAX_PAIRS: g_mt_max_pairs = std::max(0, value); return TWL_OK;
     case TWL_KNOB_MT_MIN_MARKER: g_mt_min_marker = std::max(2, value); return TWL_OK;
     case TWL_KNOB_MT_LEAD: g_mt_lead = std::max(16, value); return TWL_OK;
-    case TWL_KNOB_MT_MARGIN: g_mt_marg = g_mt_marg_lat = std::max(2, value); return TWL_OK;
+    case TWL_KNOB_MT_MARGIN: if (value < 0) { g_mt_marg = 40; g_mt_marg_lat = 64; } else g_mt_marg = g_mt_marg_lat = std::max(2, value); return TWL_OK;      // (negative: the defaults of both kinds of level)
     case TWL_KNOB_MT_ROUNDS: g_mt_rounds = std::max(1, std::min(7, value)); return TWL_OK;
     case TWL_KNOB_MT_THR_JOBS: g_mt_thr_jobs = std::max(0, value); return TWL_OK;
     case TWL_KNOB_FAIL_ROW_ALLOCS: g_fail_next_row_allocs = std::max(0, value); return TWL_OK;
@@ -1075,7 +1076,8 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_LEAF_STEP: g_leaf_step = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_POISON_TB: g_poison_tb = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_MT_ANCHOR: g_mt_anchor = value ? 1 : 0; return TWL_OK;
-    case TWL_KNOB_MT_LEAD2: g_mt_lead2 = g_mt_lead2_lat = std::max(16, value); return TWL_OK;
+    case TWL_KNOB_MT_LEAD2: if (value < 0) { g_mt_lead2 = 96; g_mt_lead2_lat = 128; } else g_mt_lead2 = g_mt_lead2_lat = std::max(16, value); return TWL_OK;
+    case TWL_KNOB_PROT_CORRIDOR: g_prot_corridor = std::max(0, value); return TWL_OK;
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;

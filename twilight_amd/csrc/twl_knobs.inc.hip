@@ -1,6 +1,7 @@
 // twilight_amd/csrc/twl_knobs.inc.hip -- the development / test knobs of the dispatch (twl_set_knob, include/twl_align.h): their variables and defaults.
 // Included by twl_align.hip (one translation unit: it shares that file's Device bookkeeping, error string and fill queue).
 
+int g_prot_corridor = 448;  // twl_set_knob(TWL_KNOB_PROT_CORRIDOR, rows): half-width of the corridor score_matrix_kernel fills for protein levels of few pairs (0: the whole R x Q matrix, as until round 5)
 int g_mt_perturb = 0;       // twl_set_knob(TWL_KNOB_MT_PERTURB, n): spoil every n-th predicted tile start (tests of the later rounds and of the in-line path)
 int g_mt_lead = 320, g_mt_marg = 40;
 // ... of the levels of at most 2048 tile jobs (a round or two of the device's workgroups): there a scout costs ~0.1 ms of the level and a missed start a whole second round (+1.5-1.9 ms), so the
