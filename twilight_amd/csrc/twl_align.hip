@@ -114,6 +114,7 @@ struct Device {
     std::vector<uint8_t> gc_zero_host;
     std::vector<int16_t> last_err;                                               // error codes of the last run_device call, as read back by it
     void *probe_h = nullptr; size_t probe_cap = 0;                               // pinned: error codes of a level's sample (run_device, Throughput)
+    bool corridor_lost = false; int corridor_last_n = 0;                         // protein: a pair of an earlier level of this pass left the corridor of the precomputed scores (the later levels score the whole matrix)
     int small_state = 0, small_last_n = 0;                                       // plan_nucleotide: what the levels of short pairs of this pass found of the 512-row throughput window (1 fits, -1 outgrown), and the pairs of the last such level
     int live_stores = 0;                                                         // twl_store handles alive on this device (twl_level.h); guarded by mu
     void *comm = nullptr;                                                        // ncclComm_t of a sharded run (twl_comm_init)
@@ -284,6 +285,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
     bool protSmall = false;       // protein, first stage on the 512-row kernel
     int statMode = -1, statSpec = 0;
     bool ranMt = false, leanMid = false, startedWide = false, thr768 = false, thr512 = false;
+    bool usedCorridor = false;            // protein: the scores of this call were precomputed in a corridor only
     bool smallTiles = false;              // the tile jobs of a tile-parallel launch of this call ran on the 512-row window
     bool probed = false;                  // the level's own sample kept the level off the 512-row window (and set the memory of it)
     int from512Pairs = -1;                // pairs of a 512-row throughput launch that outgrew it (-1: no such launch)
@@ -351,7 +353,13 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
                 sa.cols = a.cols; sa.len = d_len; sa.num = d_num; sa.items = items; sa.blk_off = (const int32_t *)d->blk_off.p;
                 sa.n_items = n_run; sa.seq_len = seq_len; sa.gap_char = p->gap_char; sa.gc_zero = a.gc_zero; sa.M24 = (const float *)d->m24.p;
                 sa.sim = (float *)d->sim.p; sa.sim_off = (const long long *)d->sim_off.p;
-                sa.corridor = lean ? g_prot_corridor : 0;      // (the lean kernels check what they read; the round-1 kernel behind `dense` does not)
+                // (the lean kernels check what they read; the round-1 kernel behind `dense` does not.  A pair that leaves the corridor is re-run by the kernel that scores
+                //  in line, at a hundred times what the corridor saved on it: the first such pair takes the rest of the pass off the corridor -- bands widen and paths
+                //  wander up the tree -- and a level LARGER than the one before it is another pass or family and starts afresh, as the 512-row window does)
+                if (n_run > d->corridor_last_n) d->corridor_lost = false;
+                d->corridor_last_n = n_run;
+                sa.corridor = (lean && !d->corridor_lost) ? g_prot_corridor : 0;
+                usedCorridor = sa.corridor > 0;
                 FILL_TRY(flush_fills(d, st));
                 hipLaunchKernelGGL(twl::score_matrix_kernel<22>, dim3((unsigned)blk[n_run]), dim3(256), 0, st, sa);
                 HIP_TRY(hipGetLastError());
@@ -543,6 +551,7 @@ int run_device(Device *d, hipStream_t st, const twl_params *p, int32_t n_pairs, 
         std::vector<int32_t> redo;
         for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrGuard) redo.push_back(n);
         const bool guardRound = !redo.empty();
+        if (guardRound && usedCorridor) d->corridor_lost = true;
         if (guardRound) --stage;      // (the window stages follow once these are done)
         else for (int32_t n = 0; n < n_pairs; ++n) if (h_err[n] == twl::kErrOverflow) redo.push_back(n);
         if (redo.empty()) break;
@@ -1077,7 +1086,7 @@ int twl_set_knob(int key, int value)
     case TWL_KNOB_POISON_TB: g_poison_tb = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_MT_ANCHOR: g_mt_anchor = value ? 1 : 0; return TWL_OK;
     case TWL_KNOB_MT_LEAD2: if (value < 0) { g_mt_lead2 = 96; g_mt_lead2_lat = 128; } else g_mt_lead2 = g_mt_lead2_lat = std::max(16, value); return TWL_OK;
-    case TWL_KNOB_PROT_CORRIDOR: g_prot_corridor = std::max(0, value); return TWL_OK;
+    case TWL_KNOB_PROT_CORRIDOR: g_prot_corridor = std::max(0, value); for (auto *d : g_devs) { d->corridor_lost = false; d->corridor_last_n = 0; } return TWL_OK;      // (and forgets what earlier levels found)
     case TWL_KNOB_SCOUT_XDROP_PCT: g_scout_xdrop_pct = std::max(10, std::min(100, value)); return TWL_OK;
     case TWL_KNOB_THR_SMALL: g_thr_small = std::max(0, std::min(2, value)); for (auto *d : g_devs) d->small_state = d->small_last_n = 0; return TWL_OK;      // (and forgets what earlier levels found)
     default: g_err = "unknown knob"; return TWL_ERR_BAD_ARGUMENT;
