@@ -96,7 +96,7 @@ void exchangePaths(RunCtx &ctx, const std::vector<int> &owner, const std::vector
         if (sh.rccl) { const int rc = twl_comm_all_gather_host(g_devices[0], send, recv, bytes); if (rc != TWL_OK) std::cerr << "ERROR: " << twl_last_error() << '\n'; return rc; }
         return sh.exchange(sh.user, send, bytes, recv);
     };
-    static thread_local RunCtx::Raw sendStage, recvStage;      // (one run aligns at a time per thread)
+    static RunCtx::Raw sendStage, recvStage;      // (one run aligns at a time per process)
     constexpr uint64_t kBlockMagic = 0x54574C50ull << 32;      // "TWLP"
     const double t0 = nowMs();
     const int n = (int)owner.size();
@@ -308,7 +308,7 @@ struct Staging {
         grow(aln, capAln, n * 2 * stride);
     }
 };
-static thread_local Staging g_stage;
+static Staging g_stage;
 
 // Align the pairs `ids` (ascending indices into the level's slots) with one parameter set; results land in paths/errs.  The
 // call covers the slot span [ids.front(), ids.back()]; slots in the span that are not in `ids` are passed with length 0, which the

@@ -39,10 +39,10 @@ namespace {
 // the per-run state (store replicas, cache ids, totals) lives in RunCtx (align_gpu.hpp), reached through the SequenceDB
 inline twl_store *firstStore(RunCtx &ctx) { return ctx.stores.empty() ? nullptr : ctx.stores[0]; }
 
-// Grow-only, never zero-filled staging shared by the runs of a THREAD (round 6: two runs of a process may align side by side, each on a thread of its own): a level of
-// 3 000 pairs x 10 kbp moves ~70 MB per array and first-touch page faults cost more than the copies.
-thread_local std::vector<RunCtx::Raw> g_alnStage;      // per replica: paths as the DP wrote them
-thread_local RunCtx::Raw g_finalStage, g_infoStage;    // final paths as the commit reads them; column info
+// Grow-only, never zero-filled staging shared by the runs of a process (one run aligns at a time): a level of 3 000 pairs x 10 kbp
+// moves ~70 MB per array and first-touch page faults cost more than the copies.
+std::vector<RunCtx::Raw> g_alnStage;      // per replica: paths as the DP wrote them
+RunCtx::Raw g_finalStage, g_infoStage;    // final paths as the commit reads them; column info
 
 void die(const char *what, int rc)
 {
